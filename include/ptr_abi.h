@@ -1,0 +1,256 @@
+/*
+ * ptr_abi.h — C-ABI of the MI355X wavefront path tracer (libptr_hip.so).
+ *
+ * This is the drop-in boundary for the SWRT render path of
+ * dariopagliaricci/Metal-PathTracer-arm64.  Everything a host in any language
+ * needs is plain C: POD structs, raw pointers, sizes.  No C++/torch types.
+ *
+ * Reference interface each entry point replaces (paths relative to the
+ * reference checkout):
+ *   ptr_render / ptr_render_tiles   <- IHeadlessRenderer::render(...)
+ *                                      include/headless/IHeadlessRenderer.h:42-52
+ *                                      (caller: src/main_headless.mm:524-545)
+ *   PtrSceneDesc                    <- HeadlessScene::resources, i.e. the CPU arrays
+ *                                      SceneResources exposes to the Embree backend
+ *                                      (include/renderer/SceneResources.h:165,248-267;
+ *                                      consumed at src/headless/EmbreeHeadlessRenderer.mm:2077-2300,2478-2481)
+ *   PtrSphere/PtrRect/PtrMaterial   <- SphereData/RectData/MaterialData
+ *                                      include/MetalShaderTypes.h:44-97 (32 B / 80 B / 576 B)
+ *   PtrSettings                     <- the RenderSettings fields the integrator reads
+ *                                      include/renderer/RenderSettings.h:16-145
+ *   PtrRenderStats                  <- HeadlessRenderOutput timing fields
+ *                                      (IHeadlessRenderer.h:33-40) + PathtraceStats counters
+ *                                      (include/MetalShaderTypes.h:215-226)
+ *   ptr_scene_upload/release        <- SceneResources::rebuildAccelerationStructures +
+ *                                      SoftwareBvhAccel::rebuild (src/renderer/SceneResources.mm:2055-2259,
+ *                                      src/renderer/SceneAccel.mm:23-325)
+ *   ptr_trace_rays                  <- trace_scene_software closest/any hit
+ *                                      (shaders/pathtrace.metal:2266-2382) == rtcIntersect1/rtcOccluded1
+ *                                      call sites (EmbreeHeadlessRenderer.mm:2302-2433)
+ *   ptr_host_*                      <- SceneManager::loadSceneFromPath (src/renderer/SceneManager.mm:677-722),
+ *                                      WriteImage (src/renderer/ImageWriter.mm:609-627)
+ */
+#ifndef PTR_ABI_H
+#define PTR_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- scene PODs (layouts match the reference's host/device contract) ---- */
+
+typedef struct PtrSphere {          /* 32 B, MetalShaderTypes.h:44-47 */
+    float centerRadius[4];          /* xyz = centre, w = radius */
+    uint32_t materialIndex[4];      /* x = material index */
+} PtrSphere;
+
+typedef struct PtrRect {            /* 80 B, MetalShaderTypes.h:49-55 */
+    float corner[4];
+    float edgeU[4];                 /* w = 1/|U|^2 */
+    float edgeV[4];                 /* w = 1/|V|^2 */
+    float normalAndPlane[4];        /* xyz = unit normal, w = dot(normal, corner) */
+    uint32_t materialTwoSided[4];   /* x = material index, y = two-sided flag */
+} PtrRect;
+
+enum PtrMaterialType {
+    PTR_MAT_LAMBERTIAN = 0,
+    PTR_MAT_METAL = 1,
+    PTR_MAT_DIELECTRIC = 2,
+    PTR_MAT_DIFFUSE_LIGHT = 3,
+    PTR_MAT_PLASTIC = 4,
+    PTR_MAT_SUBSURFACE = 5,
+    PTR_MAT_CARPAINT = 6,
+    PTR_MAT_PBR = 7
+};
+
+typedef struct PtrMaterial {        /* 576 B, MetalShaderTypes.h:57-97 */
+    float baseColorRoughness[4];
+    float typeEta[4];               /* x = type, y = IOR, z = coat IOR, w = thin flag */
+    float emission[4];              /* w = env-portal flag */
+    float conductorEta[4];
+    float conductorK[4];
+    float coatParams[4];            /* roughness, thickness, sample weight, Fresnel average */
+    float coatTint[4];
+    float coatAbsorption[4];
+    float dielectricSigmaA[4];
+    float sssSigmaA[4];
+    float sssSigmaS[4];
+    float sssParams[4];
+    float carpaintBaseParams[4];    /* metallic, roughness, flake scale, flake reflectance scale */
+    float carpaintFlakeParams[4];   /* sample weight, roughness, anisotropy, normal strength */
+    float carpaintBaseEta[4];
+    float carpaintBaseK[4];
+    float carpaintBaseTint[4];
+    uint32_t textureIndices0[4];
+    uint32_t textureIndices1[4];
+    uint32_t materialFlags;
+    uint32_t materialPad[3];
+    float pbrParams[4];             /* metallic, roughness, occlusion strength, normal scale */
+    float pbrExtras[4];
+    uint32_t textureUvSet0[4];
+    uint32_t textureUvSet1[4];
+    float textureTransform[12][4];
+} PtrMaterial;
+
+typedef struct PtrMeshDesc {
+    const float* positions;         /* vertexCount * 3, object space */
+    const float* normals;           /* vertexCount * 3, object space (may be zero vectors) */
+    const uint32_t* indices;        /* indexCount (multiple of 3) */
+    uint32_t vertexCount;
+    uint32_t indexCount;
+    float localToWorld[16];         /* column-major 4x4 */
+    uint32_t materialIndex;
+    uint32_t pad;
+} PtrMeshDesc;
+
+typedef struct PtrSceneDesc {
+    const PtrSphere* spheres;
+    const PtrRect* rects;
+    const PtrMaterial* materials;
+    const PtrMeshDesc* meshes;
+    const float* envRgba;           /* envWidth*envHeight*4 linear floats, row 0 = top; NULL if none */
+    uint32_t sphereCount;
+    uint32_t rectCount;
+    uint32_t materialCount;
+    uint32_t meshCount;
+    uint32_t envWidth;
+    uint32_t envHeight;
+} PtrSceneDesc;
+
+enum PtrBackgroundMode { PTR_BG_GRADIENT = 0, PTR_BG_SOLID = 1, PTR_BG_ENVIRONMENT = 2 };
+
+typedef struct PtrSettings {
+    uint32_t width;
+    uint32_t height;
+    uint32_t maxDepth;
+    uint32_t seed;                      /* fixedRngSeed; 0 -> 0x9e3779b9 */
+    uint32_t enableRussianRoulette;
+    uint32_t enableSpecularNee;
+    uint32_t enableMnee;
+    uint32_t enableMneeSecondary;
+    float cameraTarget[3];
+    float cameraDistance;
+    float cameraYaw;
+    float cameraPitch;
+    float cameraVerticalFov;
+    float cameraDefocusAngle;
+    float cameraFocusDistance;
+    uint32_t backgroundMode;
+    float backgroundColor[3];
+    float environmentRotation;          /* radians */
+    float environmentIntensity;
+    uint32_t fireflyClampEnabled;
+    float fireflyClampFactor;
+    float fireflyClampFloor;
+    float throughputClamp;
+    float specularTailClampBase;
+    float specularTailClampRoughnessScale;
+    float minSpecularPdf;
+    float fireflyClampMaxContribution;
+    float emissionScale;                /* PATH_TRACER_EMBREE_EMISSION_SCALE analogue; 1 = off */
+} PtrSettings;
+
+typedef struct PtrRenderStats {
+    double totalSeconds;                /* integrate phase only (reference: out.totalSeconds) */
+    double avgMsPerSample;
+    double uploadSeconds;               /* BVH build + H2D, reported separately */
+    double traceKernelMs;               /* sum of closest-hit kernel durations (HIP events) */
+    double shadeKernelMs;
+    double shadowKernelMs;
+    uint64_t traceLaunches;
+    uint64_t samples;                   /* pixel-samples integrated */
+    /* PathtraceStats-style counters (filled only when countTraversal != 0) */
+    uint64_t primaryRays;
+    uint64_t extendRays;                /* closest-hit rays (primary + bounce + specular-NEE) */
+    uint64_t shadowRays;
+    uint64_t nodesVisited;              /* nodes popped-and-tested, all rays */
+    uint64_t leafPrimTests;
+    uint64_t extendNodesVisited;        /* subset of the above for the closest-hit kernel */
+    uint64_t extendLeafPrimTests;
+    uint64_t shadedHits;
+    uint64_t triangleHits;
+    uint64_t shadowEarlyExits;
+} PtrRenderStats;
+
+typedef struct PtrHit {                 /* result of ptr_trace_rays */
+    float t;                            /* < 0 on miss */
+    float u, v;
+    uint32_t primType;                  /* 0 mesh triangle, 1 sphere, 2 rectangle */
+    uint32_t geomIndex;                 /* mesh index (primType 0) else 0 */
+    uint32_t primIndex;                 /* triangle / sphere / rectangle index */
+    float ng[3];                        /* unnormalised geometric normal (triangles) */
+    uint32_t pad;
+} PtrHit;
+
+typedef struct PtrDeviceScene PtrDeviceScene;
+
+/* ---- device path (HIP) ---- */
+
+/* Number of visible HIP devices (0 when none / runtime unavailable). */
+int ptr_device_count(void);
+
+/* Build the SAH BVH on the host, flatten to device SoA arrays and upload to `device`. */
+int ptr_scene_upload(const PtrSceneDesc* scene, int device, PtrDeviceScene** out_scene,
+                     char* err, size_t err_cap);
+void ptr_scene_release(PtrDeviceScene* scene);
+
+/* BVH facts for tests/diagnostics: [0]=nodes,[1]=leaves,[2]=triangles,[3]=spheres,[4]=max depth,[5]=max leaf size */
+int ptr_scene_info(const PtrDeviceScene* scene, uint64_t out[8]);
+
+/* Render the whole image, result copied to host `out_rgb` (width*height*3, row 0 = top). */
+int ptr_render(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t spp, int verbose,
+               float* out_rgb, PtrRenderStats* stats, char* err, size_t err_cap);
+
+/*
+ * Render the subset of 16-row image bands owned by `part_index` of `part_count`
+ * (band b belongs to part b % part_count) into a DEVICE buffer laid out
+ * [localBand][16][width][3] floats; `d_out_rgb` must hold
+ * ptr_part_band_count(height, part_index, part_count)*16*width*3 floats.
+ * `stream` is a hipStream_t (NULL = default stream).  Asynchronous unless
+ * stats != NULL (stats need a stream sync to read event timers / counters).
+ * count_traversal != 0 selects the counting build of the same kernels.
+ */
+int ptr_render_bands_device(PtrDeviceScene* scene, const PtrSettings* settings, uint32_t spp,
+                            uint32_t part_index, uint32_t part_count, void* d_out_rgb, void* stream,
+                            int count_traversal, PtrRenderStats* stats, char* err, size_t err_cap);
+uint32_t ptr_part_band_count(uint32_t height, uint32_t part_index, uint32_t part_count);
+
+/* Same partition, host output buffer of the same layout (used by ptr_render and tests). */
+int ptr_render_bands(PtrDeviceScene* scene, const PtrSettings* settings, uint32_t spp,
+                     uint32_t part_index, uint32_t part_count, float* out_rgb_bands,
+                     int count_traversal, PtrRenderStats* stats, char* err, size_t err_cap);
+
+/* Closest-hit (any_hit = 0) or occlusion (any_hit = 1) queries for a ray batch.
+ * rays: n * 8 floats {ox,oy,oz,tmin,dx,dy,dz,tmax}; out: n PtrHit (any-hit: t>=0 means occluded). */
+int ptr_trace_rays(PtrDeviceScene* scene, const float* rays, uint64_t n, int any_hit, PtrHit* out,
+                   PtrRenderStats* stats, char* err, size_t err_cap);
+
+/* ---- host scene layer (no GPU needed) ---- */
+
+typedef struct PtrHostScene PtrHostScene;
+
+/* Parse a .scene file (reference grammar, SceneManager.mm:791-2633). asset_dir resolves relative
+ * mesh/env paths (the reference's "scene directory"); NULL -> directory of the .scene file. */
+int ptr_host_scene_load(const char* scene_path, const char* asset_dir, PtrHostScene** out,
+                        char* err, size_t err_cap);
+void ptr_host_scene_free(PtrHostScene* scene);
+/* Pointers stay valid until ptr_host_scene_free. */
+int ptr_host_scene_desc(const PtrHostScene* scene, PtrSceneDesc* out_desc, PtrSettings* out_settings);
+
+/* format: "pfm" | "exr" | "ppm"; EXR = RGB (channels B,G,R) unless rgba != 0 (B,G,R,A + colorspace attr,
+ * what the reference's Embree backend writes, main_headless.mm:568-583). */
+int ptr_host_write_image(const char* path, const char* format, const float* linear_rgb,
+                         uint32_t width, uint32_t height, int rgba_exr,
+                         uint32_t tonemap_mode, uint32_t aces_variant, float exposure, float reinhard_white,
+                         char* err, size_t err_cap);
+int ptr_host_read_pfm(const char* path, float* out_rgb, uint32_t cap_floats, uint32_t* width, uint32_t* height);
+
+const char* ptr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTR_ABI_H */

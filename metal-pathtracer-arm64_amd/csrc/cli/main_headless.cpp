@@ -1,0 +1,345 @@
+// PathTracerHeadless — command-line front end of the MI355X backend.
+// Flag set, defaults, override order (scene file first, CLI second), default output naming and the final
+// report line follow the reference's src/main_headless.mm:26-606.  Backends: `hip` (default; `metal` is
+// accepted as an alias so existing command lines keep working).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <filesystem>
+#include <iomanip>
+#include <iostream>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "headless.h"
+#include "image_writer.h"
+#include "scene_manager.h"
+
+namespace fs = std::filesystem;
+
+namespace {
+
+struct CliOptions {
+    std::string scene;
+    bool sceneProvided = false;
+    std::string assetDir;
+    std::string outputPath;
+    uint32_t width = 0, height = 0;
+    bool widthSet = false, heightSet = false;
+    uint32_t sppTotal = 1024;
+    uint32_t maxDepth = 0;
+    bool maxDepthSet = false;
+    uint32_t threads = 0;
+    uint32_t seed = 0;
+    bool seedSet = false;
+    float envRotationDegrees = 0.0f;
+    bool envRotationSet = false;
+    float envIntensity = 0.0f;
+    bool envIntensitySet = false;
+    uint32_t tonemapMode = 0;
+    bool tonemapSet = false;
+    float exposure = 0.0f;
+    bool exposureSet = false;
+    bool enableSoftwareRayTracing = false, enableSoftwareRayTracingSet = false;
+    bool enableMnee = false, enableMneeSet = false;
+    std::string formatString = "exr";
+    ptr::ImageFileFormat format = ptr::ImageFileFormat::EXR;
+    bool rgbaExr = false;
+    bool verbose = false;
+};
+
+void printUsage(const char* exe) {
+    std::cout << "Usage: " << exe << " [options]\n\n"
+              << "Required:\n"
+              << "  --scene=<path>                Path to a .scene file\n\n"
+              << "Rendering overrides:\n"
+              << "  --width=<int>                 Override render width (>=8)\n"
+              << "  --height=<int>                Override render height (>=8)\n"
+              << "  --sppTotal=<int>              Total samples to accumulate (default 1024)\n"
+              << "  --maxDepth=<int>              Override max path depth\n"
+              << "  --threads=<int>               Accepted for compatibility (CPU backends only)\n"
+              << "  --seed=<int>                  Fixed RNG seed (0 = default stream)\n"
+              << "  --enableSoftwareRayTracing[=0|1]  Accepted; this backend always traces in software\n"
+              << "  --enableMnee[=0|1]             Enable MNEE caustics (default 0)\n\n"
+              << "Environment overrides:\n"
+              << "  --envRotation=<deg>           Environment rotation in degrees\n"
+              << "  --envIntensity=<float>        Environment intensity multiplier\n\n"
+              << "Backend selection:\n"
+              << "  --backend=<hip|metal>          Headless backend (default hip; metal = alias)\n"
+              << "  --assets=<dir>                 Directory for relative mesh/env paths\n\n"
+              << "Tonemapping overrides (for LDR outputs):\n"
+              << "  --tonemap=<1|2|3|4>           1=Linear, 2=ACES, 3=Reinhard, 4=Hable\n"
+              << "  --exposure=<float>            Exposure in stops\n\n"
+              << "Output controls:\n"
+              << "  --output=<path>               Output filename\n"
+              << "  --format=<exr|pfm|ppm>        Output format (default exr)\n"
+              << "  --rgbaExr[=0|1]               Write RGBA EXR with colorspace attribute (Embree-backend layout)\n"
+              << "  --verbose                     Print progress\n"
+              << "  --help                        Show this message\n";
+}
+
+bool parseBoolFlag(const std::string& value, bool defaultIfEmpty, bool& out) {
+    if (value.empty()) {
+        out = defaultIfEmpty;
+        return true;
+    }
+    std::string l;
+    for (char c : value) l.push_back(static_cast<char>(std::tolower(static_cast<unsigned char>(c))));
+    if (l == "1" || l == "true" || l == "yes") {
+        out = true;
+        return true;
+    }
+    if (l == "0" || l == "false" || l == "no") {
+        out = false;
+        return true;
+    }
+    return false;
+}
+
+bool parseOptions(int argc, const char** argv, CliOptions& o, std::string& error) {
+    for (int i = 1; i < argc; ++i) {
+        std::string arg = argv[i], value;
+        const size_t eq = arg.find('=');
+        const bool inlineValue = eq != std::string::npos;
+        if (inlineValue) {
+            value = arg.substr(eq + 1);
+            arg = arg.substr(0, eq);
+        }
+        auto need = [&](const char* name) {
+            if (inlineValue) return true;
+            if (i + 1 >= argc) {
+                error = std::string(name) + " requires a value";
+                return false;
+            }
+            value = argv[++i];
+            return true;
+        };
+        auto intArg = [&](const char* name, int minValue, uint32_t& dst, bool* setFlag) {
+            if (!need(name)) return false;
+            try {
+                const int parsed = std::stoi(value);
+                if (parsed < minValue) {
+                    error = std::string(name) + " must be >= " + std::to_string(minValue);
+                    return false;
+                }
+                dst = static_cast<uint32_t>(parsed);
+                if (setFlag) *setFlag = true;
+                return true;
+            } catch (...) {
+                error = std::string("Invalid integer for ") + name;
+                return false;
+            }
+        };
+        auto floatArg = [&](const char* name, float& dst, bool& setFlag) {
+            if (!need(name)) return false;
+            try {
+                dst = std::stof(value);
+                setFlag = true;
+                return true;
+            } catch (...) {
+                error = std::string("Invalid float for ") + name;
+                return false;
+            }
+        };
+        auto boolArg = [&](const char* name, bool& dst, bool* setFlag) {
+            bool flag = true;
+            if (!parseBoolFlag(inlineValue ? value : std::string(), true, flag)) {
+                error = std::string("Invalid value for ") + name;
+                return false;
+            }
+            dst = flag;
+            if (setFlag) *setFlag = true;
+            return true;
+        };
+
+        if (arg == "--help" || arg == "-h") {
+            printUsage(argv[0]);
+            std::exit(0);
+        } else if (arg == "--verbose" || arg == "-v") {
+            if (!boolArg("--verbose", o.verbose, nullptr)) return false;
+        } else if (arg == "--scene") {
+            if (!need("--scene")) return false;
+            o.scene = value;
+            o.sceneProvided = true;
+        } else if (arg == "--assets") {
+            if (!need("--assets")) return false;
+            o.assetDir = value;
+        } else if (arg == "--output") {
+            if (!need("--output")) return false;
+            o.outputPath = value;
+        } else if (arg == "--width") {
+            if (!intArg("--width", 8, o.width, &o.widthSet)) return false;
+        } else if (arg == "--height") {
+            if (!intArg("--height", 8, o.height, &o.heightSet)) return false;
+        } else if (arg == "--sppTotal") {
+            if (!intArg("--sppTotal", 1, o.sppTotal, nullptr)) return false;
+        } else if (arg == "--maxDepth") {
+            if (!intArg("--maxDepth", 1, o.maxDepth, &o.maxDepthSet)) return false;
+        } else if (arg == "--threads") {
+            if (!intArg("--threads", 1, o.threads, nullptr)) return false;
+        } else if (arg == "--seed") {
+            if (!need("--seed")) return false;
+            try {
+                o.seed = static_cast<uint32_t>(std::stoul(value));
+                o.seedSet = true;
+            } catch (...) {
+                error = "Invalid integer for --seed";
+                return false;
+            }
+        } else if (arg == "--envRotation") {
+            if (!floatArg("--envRotation", o.envRotationDegrees, o.envRotationSet)) return false;
+        } else if (arg == "--envIntensity") {
+            if (!floatArg("--envIntensity", o.envIntensity, o.envIntensitySet)) return false;
+            o.envIntensity = std::max(o.envIntensity, 0.0f);
+        } else if (arg == "--tonemap") {
+            if (!intArg("--tonemap", 1, o.tonemapMode, &o.tonemapSet)) return false;
+            if (o.tonemapMode > 4) {
+                error = "--tonemap must be in [1,4]";
+                return false;
+            }
+        } else if (arg == "--exposure") {
+            if (!floatArg("--exposure", o.exposure, o.exposureSet)) return false;
+        } else if (arg == "--enableSoftwareRayTracing") {
+            if (!boolArg("--enableSoftwareRayTracing", o.enableSoftwareRayTracing, &o.enableSoftwareRayTracingSet)) return false;
+        } else if (arg == "--enableMnee") {
+            if (!boolArg("--enableMnee", o.enableMnee, &o.enableMneeSet)) return false;
+        } else if (arg == "--rgbaExr") {
+            if (!boolArg("--rgbaExr", o.rgbaExr, nullptr)) return false;
+        } else if (arg == "--format") {
+            if (!need("--format")) return false;
+            o.formatString = value;
+        } else if (arg == "--backend") {
+            if (!need("--backend")) return false;
+            std::string l;
+            for (char c : value) l.push_back(static_cast<char>(std::tolower(static_cast<unsigned char>(c))));
+            if (l != "hip" && l != "metal") {
+                error = "Invalid value for --backend (expected hip)";
+                return false;
+            }
+        } else {
+            error = "Unknown option: " + arg;
+            return false;
+        }
+    }
+    if (!o.sceneProvided) {
+        error = "--scene is required";
+        return false;
+    }
+    if (!ptr::ParseImageFileFormat(o.formatString, o.format)) {
+        error = "Unknown format: " + o.formatString;
+        return false;
+    }
+    return true;
+}
+
+std::string sanitizeSceneName(const std::string& input) {
+    if (input.empty()) return "scene";
+    std::string name = fs::path(input).stem().string();
+    if (name.empty()) name = input;
+    for (char& c : name) {
+        if (!(std::isalnum(static_cast<unsigned char>(c)) || c == '-' || c == '_')) c = '_';
+    }
+    return name;
+}
+
+}  // namespace
+
+int main(int argc, const char** argv) {
+    CliOptions options;
+    std::string error;
+    if (!parseOptions(argc, argv, options, error)) {
+        if (!error.empty()) std::cerr << "Error: " << error << "\n\n";
+        printUsage(argv[0]);
+        return 1;
+    }
+
+    ptr::SceneManager sceneManager(options.assetDir);
+    ptr::SceneResources resources;
+    ptr::RenderSettings settings{};
+    std::string sceneError;
+    if (!sceneManager.loadSceneFromPath(options.scene, resources, settings, &sceneError)) {
+        std::cerr << "Failed to load scene: " << options.scene << std::endl;
+        if (!sceneError.empty()) std::cerr << sceneError << std::endl;
+        return 1;
+    }
+
+    // CLI overrides apply after the scene file (main_headless.mm:418-449)
+    if (options.widthSet) settings.renderWidth = options.width;
+    if (options.heightSet) settings.renderHeight = options.height;
+    if (options.maxDepthSet) settings.maxDepth = options.maxDepth;
+    if (options.seedSet) settings.fixedRngSeed = options.seed;
+    if (options.tonemapSet) settings.tonemapMode = options.tonemapMode;
+    if (options.exposureSet) settings.exposure = options.exposure;
+    if (options.envRotationSet) settings.environmentRotation = options.envRotationDegrees * static_cast<float>(3.14159265358979323846 / 180.0);
+    if (options.envIntensitySet) settings.environmentIntensity = std::max(options.envIntensity, 0.0f);
+    if (options.enableSoftwareRayTracingSet) settings.enableSoftwareRayTracing = options.enableSoftwareRayTracing;
+    if (options.enableMneeSet) settings.enableMnee = options.enableMnee;
+    if (settings.renderWidth == 0) settings.renderWidth = 1280u;
+    if (settings.renderHeight == 0) settings.renderHeight = 720u;
+
+    ptr::HeadlessScene scene{};
+    scene.source = options.scene;
+    scene.isPath = true;
+    scene.resources = &resources;
+    ptr::HeadlessCamera camera{};
+    camera.target = settings.cameraTarget;
+    camera.distance = settings.cameraDistance;
+    camera.yaw = settings.cameraYaw;
+    camera.pitch = settings.cameraPitch;
+    camera.verticalFov = settings.cameraVerticalFov;
+    camera.defocusAngle = settings.cameraDefocusAngle;
+    camera.focusDistance = settings.cameraFocusDistance;
+
+    std::unique_ptr<ptr::IHeadlessRenderer> renderer = std::make_unique<ptr::HipHeadlessRenderer>();
+    ptr::HeadlessRenderOutput output;
+    std::string renderError;
+    if (!renderer->render(scene, camera, settings, options.sppTotal, options.verbose, output, renderError)) {
+        std::cerr << "Render failed: " << renderError << std::endl;
+        return 1;
+    }
+
+    std::string outputPath = options.outputPath;
+    if (outputPath.empty()) {
+        std::ostringstream name;
+        name << sanitizeSceneName(options.scene) << "_" << output.width << "x" << output.height << "."
+             << ptr::FormatExtension(options.format);
+        outputPath = (fs::path("renders") / name.str()).string();
+    }
+    const fs::path outFs(outputPath);
+    if (!outFs.parent_path().empty()) {
+        std::error_code ec;
+        fs::create_directories(outFs.parent_path(), ec);
+    }
+
+    std::string writeError;
+    bool ok;
+    if (options.format == ptr::ImageFileFormat::EXR && options.rgbaExr) {
+        std::vector<float> rgba(static_cast<size_t>(output.width) * output.height * 4u, 1.0f);
+        for (size_t i = 0; i < static_cast<size_t>(output.width) * output.height; ++i) {
+            rgba[i * 4 + 0] = output.linearRGB[i * 3 + 0];
+            rgba[i * 4 + 1] = output.linearRGB[i * 3 + 1];
+            rgba[i * 4 + 2] = output.linearRGB[i * 3 + 2];
+        }
+        ok = ptr::WriteExrRgba(outputPath, rgba.data(), output.width, output.height, "Linear sRGB", &writeError);
+    } else {
+        ptr::TonemapSettings tm;
+        tm.tonemapMode = settings.tonemapMode;
+        tm.acesVariant = settings.acesVariant;
+        tm.exposure = settings.exposure;
+        tm.reinhardWhitePoint = settings.reinhardWhitePoint;
+        ok = ptr::WriteImage(outputPath, options.format, output.linearRGB.data(), output.width, output.height, tm, &writeError);
+    }
+    if (!ok) {
+        std::cerr << "Failed to write output image: " << writeError << std::endl;
+        return 1;
+    }
+
+    std::cout << "Rendered " << output.samples << " spp at " << output.width << "x" << output.height << " in "
+              << std::fixed << std::setprecision(2) << output.totalSeconds << " s"
+              << " (~" << std::setprecision(3) << output.avgMsPerSample << " ms/sample)." << std::endl;
+    std::cout << "Output written to: " << outFs << std::endl;
+    return 0;
+}

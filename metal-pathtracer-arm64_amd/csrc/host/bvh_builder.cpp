@@ -1,0 +1,315 @@
+#include "bvh_builder.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <thread>
+
+#include "../kernels/bvh_layout.h"
+
+namespace ptr {
+namespace {
+
+constexpr int kBins = 16;
+constexpr uint32_t kLeafMax = 4;                                   // SAH may stop at <= 4 primitives
+constexpr uint32_t kDepthLimit = ptrk::kTraversalStackDepth - 2;   // leaves sit at depth <= kDepthLimit
+constexpr uint32_t kParallelThreshold = 1u << 16;
+
+struct Aabb {
+    float lo[3], hi[3];
+    void reset() {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::numeric_limits<float>::infinity();
+            hi[a] = -std::numeric_limits<float>::infinity();
+        }
+    }
+    void grow(const float l[3], const float h[3]) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], l[a]);
+            hi[a] = std::max(hi[a], h[a]);
+        }
+    }
+    void growPoint(const float p[3]) { grow(p, p); }
+    float halfArea() const {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct TempNode {
+    Aabb box;
+    uint32_t left = 0, right = 0;   // children (internal)
+    uint32_t first = 0, count = 0;  // range in `order` (leaf when count > 0)
+    uint32_t sphereLeaf = 0;
+};
+
+struct Builder {
+    const std::vector<BuildPrim>& prims;
+    std::vector<float> centers;       // 3 per prim
+    std::vector<uint32_t> order;
+    std::vector<TempNode> nodes;
+    std::atomic<uint32_t> nextNode{1};
+    std::atomic<int> freeThreads{0};
+
+    explicit Builder(const std::vector<BuildPrim>& p) : prims(p) {}
+
+    uint32_t allocPair() { return nextNode.fetch_add(2); }
+
+    static uint32_t log2Ceil(uint32_t n) {
+        uint32_t l = 0;
+        while ((1u << l) < n) ++l;
+        return l;
+    }
+
+    void makeLeaf(uint32_t node, uint32_t begin, uint32_t end) {
+        nodes[node].first = begin;
+        nodes[node].count = end - begin;
+        nodes[node].sphereLeaf = prims[order[begin]].isSphere;
+    }
+
+    void build(uint32_t node, uint32_t begin, uint32_t end, uint32_t depth) {
+        Aabb box, cbox;
+        box.reset();
+        cbox.reset();
+        uint32_t sphereCount = 0;
+        for (uint32_t i = begin; i < end; ++i) {
+            const BuildPrim& p = prims[order[i]];
+            box.grow(p.lo, p.hi);
+            cbox.growPoint(&centers[static_cast<size_t>(order[i]) * 3]);
+            sphereCount += p.isSphere;
+        }
+        nodes[node].box = box;
+        const uint32_t count = end - begin;
+        const bool mixed = sphereCount != 0 && sphereCount != count;
+
+        uint32_t mid = begin;
+        bool haveSplit = false;
+        const bool forceBalanced = depth + log2Ceil(count) + 1 >= kDepthLimit;
+
+        if (count == 1 || (count <= kLeafMax && !mixed && forceBalanced)) {
+            makeLeaf(node, begin, end);
+            return;
+        }
+
+        if (!forceBalanced) {
+            // binned SAH over the three axes
+            int bestAxis = -1, bestBin = -1;
+            float bestCost = std::numeric_limits<float>::infinity();
+            for (int axis = 0; axis < 3; ++axis) {
+                const float lo = cbox.lo[axis], hi = cbox.hi[axis];
+                if (!(hi > lo)) continue;
+                Aabb binBox[kBins];
+                uint32_t binCount[kBins];
+                for (int b = 0; b < kBins; ++b) {
+                    binBox[b].reset();
+                    binCount[b] = 0;
+                }
+                const float scale = static_cast<float>(kBins) / (hi - lo);
+                for (uint32_t i = begin; i < end; ++i) {
+                    const uint32_t id = order[i];
+                    const int b = std::min(kBins - 1, static_cast<int>((centers[static_cast<size_t>(id) * 3 + axis] - lo) * scale));
+                    binBox[b].grow(prims[id].lo, prims[id].hi);
+                    ++binCount[b];
+                }
+                float rightArea[kBins];
+                uint32_t rightCount[kBins];
+                Aabb acc;
+                acc.reset();
+                uint32_t n = 0;
+                for (int b = kBins - 1; b > 0; --b) {
+                    acc.grow(binBox[b].lo, binBox[b].hi);
+                    n += binCount[b];
+                    rightArea[b] = n ? acc.halfArea() : 0.0f;
+                    rightCount[b] = n;
+                }
+                acc.reset();
+                n = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    acc.grow(binBox[b].lo, binBox[b].hi);
+                    n += binCount[b];
+                    if (n == 0 || rightCount[b + 1] == 0) continue;
+                    const float cost = acc.halfArea() * static_cast<float>(n) + rightArea[b + 1] * static_cast<float>(rightCount[b + 1]);
+                    if (cost < bestCost) {
+                        bestCost = cost;
+                        bestAxis = axis;
+                        bestBin = b;
+                    }
+                }
+            }
+            if (bestAxis >= 0) {
+                const float parentArea = std::max(box.halfArea(), 1e-30f);
+                const float splitCost = 1.0f + bestCost / parentArea;   // c_trav = c_int = 1 (tinybvh defaults)
+                if (count <= kLeafMax && !mixed && splitCost >= static_cast<float>(count)) {
+                    makeLeaf(node, begin, end);
+                    return;
+                }
+                const float lo = cbox.lo[bestAxis];
+                const float scale = static_cast<float>(kBins) / (cbox.hi[bestAxis] - lo);
+                auto it = std::partition(order.begin() + begin, order.begin() + end, [&](uint32_t id) {
+                    return std::min(kBins - 1, static_cast<int>((centers[static_cast<size_t>(id) * 3 + bestAxis] - lo) * scale)) <= bestBin;
+                });
+                mid = static_cast<uint32_t>(it - order.begin());
+                haveSplit = mid != begin && mid != end;
+            }
+        }
+        if (!haveSplit) {
+            if (mixed) {
+                // never mix spheres and triangles in one leaf: separate the kinds first
+                auto it = std::partition(order.begin() + begin, order.begin() + end, [&](uint32_t id) { return prims[id].isSphere == 0; });
+                mid = static_cast<uint32_t>(it - order.begin());
+            } else if (count <= kLeafMax && !forceBalanced) {
+                makeLeaf(node, begin, end);
+                return;
+            } else {
+                // object median along the widest centroid axis (also the depth-bounding fallback)
+                int axis = 0;
+                float widest = -1.0f;
+                for (int a = 0; a < 3; ++a) {
+                    const float w = cbox.hi[a] - cbox.lo[a];
+                    if (w > widest) {
+                        widest = w;
+                        axis = a;
+                    }
+                }
+                mid = begin + count / 2;
+                std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end, [&](uint32_t a, uint32_t b) {
+                    const float ca = centers[static_cast<size_t>(a) * 3 + axis], cb = centers[static_cast<size_t>(b) * 3 + axis];
+                    return ca < cb || (ca == cb && a < b);
+                });
+            }
+        }
+
+        const uint32_t left = allocPair();
+        nodes[node].left = left;
+        nodes[node].right = left + 1;
+        nodes[node].count = 0;
+        if (count >= kParallelThreshold && freeThreads.fetch_sub(1) > 0) {
+            std::thread t([this, left, begin, mid, depth]() { build(left, begin, mid, depth + 1); });
+            build(left + 1, mid, end, depth + 1);
+            t.join();
+            freeThreads.fetch_add(1);
+        } else {
+            if (count >= kParallelThreshold) freeThreads.fetch_add(1);
+            build(left, begin, mid, depth + 1);
+            build(left + 1, mid, end, depth + 1);
+        }
+    }
+};
+
+struct Flattener {
+    const Builder& b;
+    FlatBvh& out;
+    std::vector<uint32_t> primToTri, primToSphere;  // input index -> n-th triangle / sphere
+
+    uint32_t leafRef(const TempNode& n) {
+        const bool sphere = n.sphereLeaf != 0;
+        std::vector<uint32_t>& dst = sphere ? out.sphereOrder : out.triOrder;
+        const uint32_t first = static_cast<uint32_t>(dst.size());
+        for (uint32_t i = 0; i < n.count; ++i) {
+            const uint32_t id = b.order[n.first + i];
+            dst.push_back(sphere ? primToSphere[id] : primToTri[id]);
+        }
+        ++out.leafCount;
+        out.maxLeafSize = std::max(out.maxLeafSize, n.count);
+        return ptrk::kRefLeafBit | (sphere ? ptrk::kRefSphereBit : 0u) | ((n.count - 1u) << ptrk::kRefCountShift) | first;
+    }
+
+    void setChild(uint32_t deviceNode, int slot, const Aabb& box, uint32_t ref) {
+        float* n = out.nodes.data() + static_cast<size_t>(deviceNode) * 16;
+        float* lo = n + (slot == 0 ? 0 : 8);
+        float* hi = n + (slot == 0 ? 4 : 12);
+        std::memcpy(lo, box.lo, 12);
+        std::memcpy(hi, box.hi, 12);
+        if (slot == 0) {
+            std::memcpy(n + 3, &ref, 4);
+        } else {
+            std::memcpy(n + 7, &ref, 4);
+        }
+    }
+
+    // iterative DFS: device node indices are assigned in preorder, left subtree first
+    void run(double rootArea) {
+        struct Item {
+            uint32_t temp, device, depth;
+        };
+        const TempNode& root = b.nodes[0];
+        out.nodes.assign(16, 0.0f);
+        out.nodeCount = 1;
+        const uint32_t empty = ptrk::kRefEmpty;
+        std::memcpy(out.nodes.data() + 3, &empty, 4);
+        std::memcpy(out.nodes.data() + 7, &empty, 4);
+        if (root.count > 0) {  // whole scene fits one leaf: wrap it in a single-child root
+            setChild(0, 0, root.box, leafRef(root));
+            out.maxDepth = 1;
+            out.sahCost = root.count;
+            return;
+        }
+        std::vector<Item> stack{{0u, 0u, 0u}};
+        while (!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            const TempNode& n = b.nodes[it.temp];
+            out.sahCost += n.box.halfArea() / rootArea;
+            const uint32_t kids[2] = {n.left, n.right};
+            uint32_t pendingDevice[2] = {0, 0};
+            bool internal[2] = {false, false};
+            for (int s = 0; s < 2; ++s) {
+                const TempNode& c = b.nodes[kids[s]];
+                if (c.count > 0) {
+                    setChild(it.device, s, c.box, leafRef(c));
+                    out.sahCost += (c.box.halfArea() / rootArea) * c.count;
+                    out.maxDepth = std::max(out.maxDepth, it.depth + 2);
+                } else {
+                    const uint32_t dev = out.nodeCount++;
+                    out.nodes.resize(static_cast<size_t>(out.nodeCount) * 16, 0.0f);
+                    setChild(it.device, s, c.box, dev);
+                    pendingDevice[s] = dev;
+                    internal[s] = true;
+                }
+            }
+            if (internal[1]) stack.push_back({kids[1], pendingDevice[1], it.depth + 1});
+            if (internal[0]) stack.push_back({kids[0], pendingDevice[0], it.depth + 1});
+        }
+    }
+};
+
+}  // namespace
+
+void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t threads) {
+    out = FlatBvh{};
+    const uint32_t n = static_cast<uint32_t>(prims.size());
+    if (n == 0) return;
+
+    Builder b(prims);
+    b.centers.resize(static_cast<size_t>(n) * 3);
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int a = 0; a < 3; ++a) b.centers[static_cast<size_t>(i) * 3 + a] = 0.5f * (prims[i].lo[a] + prims[i].hi[a]);
+    }
+    b.order.resize(n);
+    std::iota(b.order.begin(), b.order.end(), 0u);
+    b.nodes.resize(static_cast<size_t>(2) * n + 1);
+    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+    b.freeThreads = static_cast<int>(std::min(threads, 32u)) - 1;
+    b.build(0, 0, n, 0);
+
+    Flattener f{b, out, {}, {}};
+    f.primToTri.resize(n);
+    f.primToSphere.resize(n);
+    uint32_t tri = 0, sph = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (prims[i].isSphere) {
+            f.primToSphere[i] = sph++;
+        } else {
+            f.primToTri[i] = tri++;
+        }
+    }
+    out.triOrder.reserve(tri);
+    out.sphereOrder.reserve(sph);
+    f.run(std::max(static_cast<double>(b.nodes[0].box.halfArea()), 1e-30));
+    out.rootRef = 0u;
+}
+
+}  // namespace ptr

@@ -1,0 +1,37 @@
+// Host-side SAH BVH construction and flattening to the device node layout (kernels/device_types.h).
+//
+// Takes the place of the reference's SoftwareBvhAccel::rebuild (src/renderer/SceneAccel.mm:23-325: per-mesh
+// tinybvh binned-SAH BLAS + median-split TLAS) and BvhBuilder (src/renderer/BvhBuilder.mm, spheres).  The
+// oracle path (Embree) bakes every mesh to world space and finds the true closest hit over one scene, so
+// this builder does the same: ONE binned-SAH tree over all world-space triangles, rectangle halves and
+// spheres.  Differences from the reference layout, all MI355X-motivated:
+//   * 64 B nodes hold both child boxes + child references (one fetch decides both children),
+//   * leaves are folded into the parent's child reference (no leaf node fetch),
+//   * primitives are re-ordered into leaf order so a leaf is one contiguous run,
+//   * tree depth is bounded (< kTraversalStackDepth) so the traversal stack can never overflow.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+namespace ptr {
+
+struct BuildPrim {
+    float lo[3], hi[3];   // bounds
+    uint32_t isSphere;
+};
+
+struct FlatBvh {
+    std::vector<float> nodes;          // 16 floats per node (see device_types.h)
+    std::vector<uint32_t> triOrder;    // leaf-order -> index into the triangle input
+    std::vector<uint32_t> sphereOrder; // leaf-order -> index into the sphere input
+    uint32_t rootRef = 0xFFFFFFFFu;
+    uint32_t nodeCount = 0, leafCount = 0, maxDepth = 0, maxLeafSize = 0;
+    double sahCost = 0.0;
+};
+
+// prims: triangles and spheres mixed (isSphere flag); indices in triOrder/sphereOrder refer to the n-th
+// triangle / n-th sphere of the input in input order.
+void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t threads = 0);
+
+}  // namespace ptr

@@ -1,0 +1,126 @@
+// Host-side (no GPU) entry points of the C-ABI: scene loading and image output.
+#include <cstdio>
+#include <cstring>
+#include <filesystem>
+#include <memory>
+#include <string>
+
+#include "headless.h"
+#include "image_writer.h"
+#include "ptr_abi.h"
+#include "scene_manager.h"
+
+struct PtrHostScene {
+    ptr::SceneResources resources;
+    ptr::RenderSettings settings;
+    PtrSceneDesc desc{};
+    PtrSettings podSettings{};
+};
+
+namespace {
+void setErr(char* err, size_t cap, const std::string& msg) {
+    if (err && cap > 0) {
+        std::snprintf(err, cap, "%s", msg.c_str());
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int ptr_host_scene_load(const char* scene_path, const char* asset_dir, PtrHostScene** out, char* err, size_t err_cap) {
+    if (!scene_path || !out) {
+        setErr(err, err_cap, "ptr_host_scene_load: null argument");
+        return 1;
+    }
+    auto scene = std::make_unique<PtrHostScene>();
+    ptr::SceneManager manager(asset_dir ? std::string(asset_dir) : std::string());
+    std::string error;
+    if (!manager.loadSceneFromPath(scene_path, scene->resources, scene->settings, &error)) {
+        setErr(err, err_cap, error);
+        return 1;
+    }
+    scene->resources.fillSceneDesc(scene->desc);
+    ptr::FillPtrSettings(scene->settings, scene->podSettings);
+    // unlike render(), keep 0 when the scene gives no size so callers can apply the CLI default (1280x720)
+    if (scene->settings.renderWidth == 0) scene->podSettings.width = 0;
+    if (scene->settings.renderHeight == 0) scene->podSettings.height = 0;
+    *out = scene.release();
+    return 0;
+}
+
+void ptr_host_scene_free(PtrHostScene* scene) { delete scene; }
+
+int ptr_host_scene_desc(const PtrHostScene* scene, PtrSceneDesc* out_desc, PtrSettings* out_settings) {
+    if (!scene) return 1;
+    if (out_desc) *out_desc = scene->desc;
+    if (out_settings) *out_settings = scene->podSettings;
+    return 0;
+}
+
+int ptr_host_write_image(const char* path, const char* format, const float* linear_rgb, uint32_t width,
+                         uint32_t height, int rgba_exr, uint32_t tonemap_mode, uint32_t aces_variant,
+                         float exposure, float reinhard_white, char* err, size_t err_cap) {
+    if (!path || !format || !linear_rgb || width == 0 || height == 0) {
+        setErr(err, err_cap, "ptr_host_write_image: bad argument");
+        return 1;
+    }
+    ptr::ImageFileFormat fmt;
+    if (!ptr::ParseImageFileFormat(format, fmt)) {
+        setErr(err, err_cap, std::string("Unknown format: ") + format);
+        return 1;
+    }
+    std::string error;
+    bool ok;
+    if (fmt == ptr::ImageFileFormat::EXR && rgba_exr) {
+        std::vector<float> rgba(static_cast<size_t>(width) * height * 4u, 1.0f);
+        for (size_t i = 0; i < static_cast<size_t>(width) * height; ++i) {
+            rgba[i * 4 + 0] = linear_rgb[i * 3 + 0];
+            rgba[i * 4 + 1] = linear_rgb[i * 3 + 1];
+            rgba[i * 4 + 2] = linear_rgb[i * 3 + 2];
+        }
+        ok = ptr::WriteExrRgba(path, rgba.data(), width, height, "Linear sRGB", &error);
+    } else {
+        ptr::TonemapSettings tm;
+        tm.tonemapMode = tonemap_mode == 0 ? 1u : tonemap_mode;
+        tm.acesVariant = aces_variant;
+        tm.exposure = exposure;
+        tm.reinhardWhitePoint = reinhard_white;
+        ok = ptr::WriteImage(path, fmt, linear_rgb, width, height, tm, &error);
+    }
+    if (!ok) {
+        setErr(err, err_cap, error);
+        return 1;
+    }
+    return 0;
+}
+
+int ptr_host_read_pfm(const char* path, float* out_rgb, uint32_t cap_floats, uint32_t* width, uint32_t* height) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return 1;
+    char magic[3] = {0};
+    unsigned w = 0, h = 0;
+    float scale = 0.0f;
+    if (std::fscanf(f, "%2s %u %u %f", magic, &w, &h, &scale) != 4 || std::strcmp(magic, "PF") != 0 || !(scale < 0.0f)) {
+        std::fclose(f);
+        return 1;
+    }
+    std::fgetc(f);  // single whitespace after the scale line
+    if (width) *width = w;
+    if (height) *height = h;
+    const size_t need = static_cast<size_t>(w) * h * 3;
+    if (!out_rgb || cap_floats < need) {
+        std::fclose(f);
+        return out_rgb ? 1 : 0;
+    }
+    bool ok = true;
+    for (unsigned y = h; y-- > 0 && ok;) {
+        ok = std::fread(out_rgb + static_cast<size_t>(y) * w * 3, sizeof(float), static_cast<size_t>(w) * 3, f) ==
+             static_cast<size_t>(w) * 3;
+    }
+    std::fclose(f);
+    return ok ? 0 : 1;
+}
+
+const char* ptr_version(void) { return "ptr-hip 0.1 (gfx950)"; }
+
+}  // extern "C"

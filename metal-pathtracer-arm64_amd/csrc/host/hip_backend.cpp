@@ -1,0 +1,783 @@
+// Device side of the C-ABI: scene upload (BVH build + SoA flattening + H2D), the wavefront render loop,
+// and ray-batch queries.  Compiled with hipcc (host code only; kernels live in kernels/wavefront.hip).
+//
+// Reference counterparts: SceneResources::rebuildAccelerationStructures (src/renderer/SceneResources.mm:2055-2259),
+// SoftwareBvhAccel::rebuild (src/renderer/SceneAccel.mm:23-325), the per-sample dispatch loop
+// (src/renderer/RenderLoop.mm:366-386, src/headless/MetalHeadlessRenderer.mm:64-92) and the Embree backend's
+// scene assembly (src/headless/EmbreeHeadlessRenderer.mm:2077-2300, 2484-2522).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../kernels/device_types.h"
+#include "../kernels/launch.h"
+#include "bvh_builder.h"
+#include "env_importance_sampler.h"
+#include "ptr_abi.h"
+#include "vecmath.h"
+
+using namespace ptrk;
+
+namespace {
+
+struct HipError {
+    std::string message;
+};
+
+#define HIP_CHECK(expr)                                                                                     \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) {                                                                             \
+            throw HipError{std::string(#expr) + ": " + hipGetErrorString(_e)};                              \
+        }                                                                                                   \
+    } while (0)
+
+void setErr(char* err, size_t cap, const std::string& msg) {
+    if (err && cap > 0) std::snprintf(err, cap, "%s", msg.c_str());
+}
+
+template <typename T>
+struct DeviceBuffer {
+    T* ptr = nullptr;
+    size_t count = 0;
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    ~DeviceBuffer() { release(); }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+    void ensure(size_t n) {
+        if (n <= count && ptr) return;
+        release();
+        if (n == 0) n = 1;
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T)));
+        count = n;
+    }
+    void upload(const T* src, size_t n) {
+        ensure(n);
+        if (n) HIP_CHECK(hipMemcpy(ptr, src, n * sizeof(T), hipMemcpyHostToDevice));
+    }
+};
+
+using ptr::float3;
+
+struct M4 {
+    float m[4][4];  // m[col][row]
+};
+
+M4 loadM4(const float* p) {
+    M4 r;
+    std::memcpy(r.m, p, sizeof(r.m));
+    return r;
+}
+
+// Cofactor inverse in float (the Embree backend calls simd_inverse for the normal matrix).
+M4 inverse(const M4& a) {
+    const float* s = &a.m[0][0];
+    float c[16];
+    auto d3 = [&](int r0, int r1, int r2, int c0, int c1, int c2) {
+        auto e = [&](int r, int col) { return s[col * 4 + r]; };
+        return e(r0, c0) * (e(r1, c1) * e(r2, c2) - e(r1, c2) * e(r2, c1)) - e(r0, c1) * (e(r1, c0) * e(r2, c2) - e(r1, c2) * e(r2, c0)) +
+               e(r0, c2) * (e(r1, c0) * e(r2, c1) - e(r1, c1) * e(r2, c0));
+    };
+    const int idx[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};
+    for (int row = 0; row < 4; ++row) {
+        for (int col = 0; col < 4; ++col) {
+            const float minor = d3(idx[row][0], idx[row][1], idx[row][2], idx[col][0], idx[col][1], idx[col][2]);
+            c[row * 4 + col] = ((row + col) & 1) ? -minor : minor;   // cofactor of element (row, col)
+        }
+    }
+    float det = 0.0f;
+    for (int col = 0; col < 4; ++col) det += s[col * 4 + 0] * c[0 * 4 + col];
+    M4 r;
+    const float invDet = 1.0f / det;
+    // inverse(row, col) = cofactor(col, row) / det; stored column-major
+    for (int col = 0; col < 4; ++col) {
+        for (int row = 0; row < 4; ++row) r.m[col][row] = c[col * 4 + row] * invDet;
+    }
+    return r;
+}
+
+float3 transformPoint(const M4& t, const float* p) {
+    return {((t.m[0][0] * p[0] + t.m[1][0] * p[1]) + t.m[2][0] * p[2]) + t.m[3][0],
+            ((t.m[0][1] * p[0] + t.m[1][1] * p[1]) + t.m[2][1] * p[2]) + t.m[3][1],
+            ((t.m[0][2] * p[0] + t.m[1][2] * p[1]) + t.m[2][2] * p[2]) + t.m[3][2]};
+}
+
+struct HostTri {
+    float3 v0, e1, e2;
+    float3 n0, n1, n2;
+    uint32_t material, meta, primIndex;
+};
+
+void padBounds(ptr::BuildPrim& p) {
+    for (int a = 0; a < 3; ++a) {
+        const float pad = 1e-5f * std::max(std::max(std::fabs(p.lo[a]), std::fabs(p.hi[a])), 1.0f);
+        p.lo[a] -= pad;
+        p.hi[a] += pad;
+    }
+}
+
+void put4(std::vector<float>& dst, const float3& v, float w) {
+    dst.push_back(v.x);
+    dst.push_back(v.y);
+    dst.push_back(v.z);
+    dst.push_back(w);
+}
+
+float bitsToFloat(uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+}  // namespace
+
+struct PtrDeviceScene {
+    int device = 0;
+    DeviceBuffer<float4> nodes, tris, triNormals, spheres, materials, rects, rectLights, envRgba;
+    DeviceBuffer<uint2> sphereInfo;
+    DeviceBuffer<int32_t> lightIndexByRect;
+    DeviceBuffer<float2> envCond, envMarg;
+    DeviceBuffer<float> envPdf;
+    SceneView view{};
+    uint64_t info[8] = {0};
+    double uploadSeconds = 0.0;
+
+    // render-time resources, grown on demand and kept across calls
+    DeviceBuffer<float4> rayOrg, rayDir, hit, throughput, accum, recBuf;
+    DeviceBuffer<uint4> state;
+    DeviceBuffer<uint32_t> shadowQueue, scalars, pixelOfLocal, spill;
+    DeviceBuffer<uint64_t> counters;
+    DeviceBuffer<float> outBands;
+    DeviceBuffer<float4> rayBatch;
+    DeviceBuffer<PtrHit> hitBatch;
+    uint32_t* pinnedAlive = nullptr;
+    uint32_t traceGrid = 0;
+    // cached partition
+    uint32_t cachedW = 0, cachedH = 0, cachedPart = 0, cachedParts = 0, cachedLocalPixels = 0;
+
+    ~PtrDeviceScene() {
+        if (pinnedAlive) (void)hipHostFree(pinnedAlive);
+    }
+};
+
+namespace {
+
+constexpr uint32_t kAliveRing = 16;   // scalars[0] = shadow count, scalars[1..16] = alive counters
+
+void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<HostTri> tris;
+    std::vector<ptr::BuildPrim> prims;
+
+    auto addTri = [&](const float3& v0, const float3& v1, const float3& v2, const float3& n0, const float3& n1, const float3& n2,
+                      uint32_t material, uint32_t kind, uint32_t geomIndex, uint32_t primIndex) {
+        HostTri t;
+        t.v0 = v0;
+        t.e1 = v0 - v1;
+        t.e2 = v2 - v0;
+        t.n0 = n0;
+        t.n1 = n1;
+        t.n2 = n2;
+        t.material = material;
+        t.meta = (kind << 30) | (geomIndex & 0x3FFFFFFFu);
+        t.primIndex = primIndex;
+        tris.push_back(t);
+        ptr::BuildPrim p;
+        const float3* vs[3] = {&v0, &v1, &v2};
+        for (int a = 0; a < 3; ++a) {
+            p.lo[a] = std::min(std::min((&vs[0]->x)[a], (&vs[1]->x)[a]), (&vs[2]->x)[a]);
+            p.hi[a] = std::max(std::max((&vs[0]->x)[a], (&vs[1]->x)[a]), (&vs[2]->x)[a]);
+        }
+        p.isSphere = 0;
+        padBounds(p);
+        prims.push_back(p);
+    };
+
+    // meshes: baked to world space, normals through the inverse-transpose (EmbreeHeadlessRenderer.mm:2100-2166)
+    for (uint32_t mi = 0; mi < desc.meshCount; ++mi) {
+        const PtrMeshDesc& mesh = desc.meshes[mi];
+        if (mesh.vertexCount == 0 || mesh.indexCount == 0) continue;
+        const M4 l2w = loadM4(mesh.localToWorld);
+        const M4 w2l = inverse(l2w);
+        const float3 nc0{w2l.m[0][0], w2l.m[1][0], w2l.m[2][0]};
+        const float3 nc1{w2l.m[0][1], w2l.m[1][1], w2l.m[2][1]};
+        const float3 nc2{w2l.m[0][2], w2l.m[1][2], w2l.m[2][2]};
+        std::vector<float3> pos(mesh.vertexCount), nrm(mesh.vertexCount);
+        for (uint32_t v = 0; v < mesh.vertexCount; ++v) {
+            pos[v] = transformPoint(l2w, mesh.positions + 3 * v);
+            const float* n = mesh.normals + 3 * v;
+            const float3 wn = (nc0 * n[0] + nc1 * n[1]) + nc2 * n[2];
+            nrm[v] = ptr::length(wn) > 0.0f ? ptr::normalize(wn) : wn;
+        }
+        for (uint32_t t = 0; t + 2 < mesh.indexCount; t += 3) {
+            const uint32_t i0 = mesh.indices[t], i1 = mesh.indices[t + 1], i2 = mesh.indices[t + 2];
+            if (i0 >= mesh.vertexCount || i1 >= mesh.vertexCount || i2 >= mesh.vertexCount) {
+                throw HipError{"mesh index out of range"};
+            }
+            addTri(pos[i0], pos[i1], pos[i2], nrm[i0], nrm[i1], nrm[i2], mesh.materialIndex, 0u, mi, t / 3);
+        }
+    }
+    // rectangles: two triangles each, winding chosen to agree with the stored normal (:2211-2257)
+    for (uint32_t ri = 0; ri < desc.rectCount; ++ri) {
+        const PtrRect& r = desc.rects[ri];
+        const float3 c{r.corner[0], r.corner[1], r.corner[2]}, eu{r.edgeU[0], r.edgeU[1], r.edgeU[2]},
+            ev{r.edgeV[0], r.edgeV[1], r.edgeV[2]};
+        const float3 n = ptr::normalize(float3{r.normalAndPlane[0], r.normalAndPlane[1], r.normalAndPlane[2]});
+        const float3 p[4] = {c, c + eu, c + ev, (c + eu) + ev};
+        const bool flip = ptr::dot(ptr::normalize(ptr::cross(eu, ev)), n) < 0.0f;
+        const int order[2][6] = {{0, 1, 2, 2, 1, 3}, {0, 2, 1, 1, 2, 3}};
+        const int* o = order[flip ? 1 : 0];
+        addTri(p[o[0]], p[o[1]], p[o[2]], n, n, n, r.materialTwoSided[0], 2u, ri, ri * 2u);
+        addTri(p[o[3]], p[o[4]], p[o[5]], n, n, n, r.materialTwoSided[0], 2u, ri, ri * 2u + 1u);
+    }
+    const uint32_t triCount = static_cast<uint32_t>(tris.size());
+    for (uint32_t si = 0; si < desc.sphereCount; ++si) {
+        const PtrSphere& s = desc.spheres[si];
+        ptr::BuildPrim p;
+        const float rad = std::fabs(s.centerRadius[3]);
+        for (int a = 0; a < 3; ++a) {
+            p.lo[a] = s.centerRadius[a] - rad;
+            p.hi[a] = s.centerRadius[a] + rad;
+        }
+        p.isSphere = 1;
+        padBounds(p);
+        prims.push_back(p);
+    }
+    if (prims.size() > kRefOffsetMask) throw HipError{"scene exceeds 64M primitives"};
+
+    ptr::FlatBvh bvh;
+    ptr::BuildFlatBvh(prims, bvh);
+
+    // leaf-order SoA arrays
+    std::vector<float> triData, triNrm, sphData;
+    std::vector<uint2> sphInfo;
+    triData.reserve(static_cast<size_t>(triCount) * 12);
+    triNrm.reserve(static_cast<size_t>(triCount) * 12);
+    for (uint32_t idx : bvh.triOrder) {
+        const HostTri& t = tris[idx];
+        put4(triData, t.v0, bitsToFloat(t.material));
+        put4(triData, t.e1, bitsToFloat(t.meta));
+        put4(triData, t.e2, bitsToFloat(t.primIndex));
+        put4(triNrm, t.n0, 0.0f);
+        put4(triNrm, t.n1, 0.0f);
+        put4(triNrm, t.n2, 0.0f);
+    }
+    for (uint32_t idx : bvh.sphereOrder) {
+        const PtrSphere& s = desc.spheres[idx];
+        sphData.insert(sphData.end(), s.centerRadius, s.centerRadius + 4);
+        sphInfo.push_back(make_uint2(idx, s.materialIndex[0]));
+    }
+
+    // compact materials
+    std::vector<float> mats;
+    mats.reserve(static_cast<size_t>(desc.materialCount) * kMaterialVec4 * 4);
+    for (uint32_t i = 0; i < desc.materialCount; ++i) {
+        const PtrMaterial& m = desc.materials[i];
+        const float* rows[kMaterialVec4] = {m.baseColorRoughness, m.typeEta,        m.emission,           m.conductorEta,
+                                            m.conductorK,         m.coatParams,     m.coatTint,           m.coatAbsorption,
+                                            m.carpaintBaseParams, m.carpaintFlakeParams, m.carpaintBaseEta, m.carpaintBaseK};
+        for (uint32_t r = 0; r < kMaterialVec4; ++r) {
+            float v[4] = {rows[r][0], rows[r][1], rows[r][2], rows[r][3]};
+            if (r == kMatCoatTint) v[3] = m.pbrParams[0];   // PBR metallic rides in the free w lane
+            mats.insert(mats.end(), v, v + 4);
+        }
+    }
+
+    // rectangle lights: DiffuseLight rectangles with non-zero emission (:2484-2522)
+    std::vector<float> lights;
+    std::vector<int32_t> lightIndexByRect(desc.rectCount, -1);
+    uint32_t lightCount = 0;
+    if (desc.rectCount > 0 && desc.materialCount > 0) {
+        for (uint32_t i = 0; i < desc.rectCount; ++i) {
+            const PtrRect& r = desc.rects[i];
+            const PtrMaterial& m = desc.materials[std::min(r.materialTwoSided[0], desc.materialCount - 1u)];
+            if (static_cast<uint32_t>(m.typeEta[0]) != PTR_MAT_DIFFUSE_LIGHT) continue;
+            const float3 e{m.emission[0], m.emission[1], m.emission[2]};
+            if (!(ptr::dot(e, e) > 0.0f)) continue;
+            const float3 c{r.corner[0], r.corner[1], r.corner[2]}, eu{r.edgeU[0], r.edgeU[1], r.edgeU[2]},
+                ev{r.edgeV[0], r.edgeV[1], r.edgeV[2]};
+            const float3 n = ptr::normalize(float3{r.normalAndPlane[0], r.normalAndPlane[1], r.normalAndPlane[2]});
+            put4(lights, c, ptr::length(ptr::cross(eu, ev)));
+            put4(lights, eu, r.materialTwoSided[1] != 0u ? 1.0f : 0.0f);
+            put4(lights, ev, bitsToFloat(i));
+            put4(lights, n, 0.0f);
+            put4(lights, e, 0.0f);
+            lightIndexByRect[i] = static_cast<int32_t>(lightCount++);
+        }
+    }
+
+    HIP_CHECK(hipSetDevice(ds.device));
+    ds.nodes.upload(reinterpret_cast<const float4*>(bvh.nodes.data()), bvh.nodes.size() / 4);
+    ds.tris.upload(reinterpret_cast<const float4*>(triData.data()), triData.size() / 4);
+    ds.triNormals.upload(reinterpret_cast<const float4*>(triNrm.data()), triNrm.size() / 4);
+    ds.spheres.upload(reinterpret_cast<const float4*>(sphData.data()), sphData.size() / 4);
+    ds.sphereInfo.upload(sphInfo.data(), sphInfo.size());
+    ds.materials.upload(reinterpret_cast<const float4*>(mats.data()), mats.size() / 4);
+    ds.rects.upload(reinterpret_cast<const float4*>(desc.rects), static_cast<size_t>(desc.rectCount) * 5);
+    ds.rectLights.upload(reinterpret_cast<const float4*>(lights.data()), lights.size() / 4);
+    ds.lightIndexByRect.upload(lightIndexByRect.data(), lightIndexByRect.size());
+
+    SceneView& v = ds.view;
+    std::memset(&v, 0, sizeof(v));
+    v.nodes = ds.nodes.ptr;
+    v.tris = ds.tris.ptr;
+    v.triNormals = ds.triNormals.ptr;
+    v.spheres = ds.spheres.ptr;
+    v.sphereInfo = ds.sphereInfo.ptr;
+    v.materials = ds.materials.ptr;
+    v.rects = ds.rects.ptr;
+    v.rectLights = ds.rectLights.ptr;
+    v.lightIndexByRect = ds.lightIndexByRect.ptr;
+    v.rootRef = bvh.rootRef;
+    v.materialCount = desc.materialCount;
+    v.rectCount = desc.rectCount;
+    v.rectLightCount = lightCount;
+
+    if (desc.envRgba && desc.envWidth > 0 && desc.envHeight > 0) {
+        const size_t texels = static_cast<size_t>(desc.envWidth) * desc.envHeight;
+        ds.envRgba.upload(reinterpret_cast<const float4*>(desc.envRgba), texels);
+        v.envRgba = ds.envRgba.ptr;
+        v.envWidth = desc.envWidth;
+        v.envHeight = desc.envHeight;
+        ptr::EnvImportanceDistribution dist;
+        if (ptr::BuildEnvImportanceDistribution(desc.envRgba, desc.envWidth, desc.envHeight, &dist)) {
+            static_assert(sizeof(ptr::AliasEntry) == sizeof(float2), "alias entry layout");
+            ds.envCond.upload(reinterpret_cast<const float2*>(dist.conditional.data()), dist.conditional.size());
+            ds.envMarg.upload(reinterpret_cast<const float2*>(dist.marginal.data()), dist.marginal.size());
+            ds.envPdf.upload(dist.texelPdf.data(), dist.texelPdf.size());
+            v.envCond = ds.envCond.ptr;
+            v.envMarg = ds.envMarg.ptr;
+            v.envPdf = ds.envPdf.ptr;
+            v.envSampling = 1u;
+        }
+    }
+
+    ds.info[0] = bvh.nodeCount;
+    ds.info[1] = bvh.leafCount;
+    ds.info[2] = triCount;
+    ds.info[3] = desc.sphereCount;
+    ds.info[4] = bvh.maxDepth;
+    ds.info[5] = bvh.maxLeafSize;
+    ds.info[6] = static_cast<uint64_t>(bvh.sahCost * 1000.0);
+    ds.info[7] = lightCount;
+
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, ds.device));
+    const uint32_t cus = prop.multiProcessorCount > 0 ? static_cast<uint32_t>(prop.multiProcessorCount) : 256u;
+    ds.traceGrid = cus * 8u;   // 8 blocks of 256 threads per CU: fills the wave slots, grid-stride the rest
+    ds.spill.ensure(static_cast<size_t>(kTraversalStackDepth - kLdsStackLevels) * ds.traceGrid * kTraceBlock);
+    ds.scalars.ensure(1 + kAliveRing);
+    ds.counters.ensure(kCounterSlots);
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ds.pinnedAlive), sizeof(uint32_t) * 4, hipHostMallocDefault));
+    ds.uploadSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// Camera basis on the host (BuildCamera, EmbreeHeadlessRenderer.mm:150-198).
+void buildCamera(const PtrSettings& s, CameraParams& c) {
+    constexpr float kPiF = 3.14159265358979323846f;
+    const float aspect = s.width > 0 ? static_cast<float>(s.width) / static_cast<float>(s.height) : 1.0f;
+    const float vfov = std::min(std::max(s.cameraVerticalFov, 1.0f), 179.0f);
+    const float defocus = std::max(s.cameraDefocusAngle, 0.0f);
+    const float theta = vfov * (kPiF / 180.0f);
+    const float h = std::tan(theta * 0.5f);
+    const float viewportHeight = 2.0f * h;
+    const float viewportWidth = aspect * viewportHeight;
+    const float distance = std::max(s.cameraDistance, 0.1f);
+    const float cp = std::cos(s.cameraPitch), sp = std::sin(s.cameraPitch);
+    const float cy = std::cos(s.cameraYaw), sy = std::sin(s.cameraYaw);
+    const float3 offset{distance * cp * cy, distance * sp, distance * cp * sy};
+    const float3 lookAt{s.cameraTarget[0], s.cameraTarget[1], s.cameraTarget[2]};
+    const float3 lookFrom = lookAt + offset;
+    const float3 w = ptr::normalize(lookFrom - lookAt);
+    const float3 u = ptr::normalize(ptr::cross(float3{0.0f, 1.0f, 0.0f}, w));
+    const float3 v = ptr::cross(w, u);
+    float focus = s.cameraFocusDistance;
+    if (focus <= 0.0f) focus = distance;
+    const float3 horizontal = (focus * viewportWidth) * u;
+    const float3 vertical = (focus * viewportHeight) * v;
+    const float3 lowerLeft = ((lookFrom - 0.5f * horizontal) - 0.5f * vertical) - focus * w;
+    auto st = [](float* d, const float3& a) {
+        d[0] = a.x;
+        d[1] = a.y;
+        d[2] = a.z;
+    };
+    st(c.origin, lookFrom);
+    st(c.lowerLeft, lowerLeft);
+    st(c.horizontal, horizontal);
+    st(c.vertical, vertical);
+    st(c.u, u);
+    st(c.v, v);
+    c.lensRadius = focus * std::tan((defocus * 0.5f) * (kPiF / 180.0f));
+}
+
+void fillRenderParams(const PtrSettings& s, uint32_t spp, RenderParams& rp) {
+    std::memset(&rp, 0, sizeof(rp));
+    buildCamera(s, rp.cam);
+    rp.width = s.width;
+    rp.height = s.height;
+    rp.maxDepth = std::min(s.maxDepth, kFlagFieldMask);
+    rp.seedBase = s.seed != 0 ? s.seed : 0x9e3779b9u;
+    rp.spp = std::max(1u, spp);
+    rp.enableRussianRoulette = s.enableRussianRoulette;
+    rp.enableSpecularNee = s.enableSpecularNee;
+    rp.enableMnee = s.enableMnee;
+    rp.enableMneeSecondary = s.enableMneeSecondary;
+    rp.backgroundMode = s.backgroundMode;
+    std::memcpy(rp.backgroundColor, s.backgroundColor, sizeof(rp.backgroundColor));
+    rp.envRotation = s.environmentRotation;
+    rp.envIntensity = s.environmentIntensity;
+    rp.clampFactor = std::max(s.fireflyClampFactor, 0.0f);   // MakeFireflyParams, :381-391
+    rp.clampFloor = std::max(s.fireflyClampFloor, 0.0f);
+    rp.throughputClamp = std::max(s.throughputClamp, 0.0f);
+    rp.tailClampBase = std::max(s.specularTailClampBase, 0.0f);
+    rp.tailClampRoughnessScale = std::max(s.specularTailClampRoughnessScale, 0.0f);
+    rp.minSpecularPdf = std::max(s.minSpecularPdf, 1.0e-8f);
+    rp.clampEnabled = s.fireflyClampEnabled ? 1.0f : 0.0f;
+    rp.emissionScale = (s.emissionScale > 0.0f && std::isfinite(s.emissionScale)) ? s.emissionScale : 1.0f;
+}
+
+// Local pixel order of a partition: its 16-row bands top to bottom, each walked in 8x8 blocks so the
+// 64 lanes of a wave start with a compact, coherent bundle of primary rays.
+void partitionPixels(uint32_t width, uint32_t height, uint32_t part, uint32_t parts, std::vector<uint32_t>& out) {
+    out.clear();
+    const uint32_t bands = (height + 15u) / 16u;
+    for (uint32_t b = part; b < bands; b += parts) {
+        const uint32_t y0 = b * 16u, y1 = std::min(y0 + 16u, height);
+        for (uint32_t ty = y0; ty < y1; ty += 8u) {
+            for (uint32_t tx = 0; tx < width; tx += 8u) {
+                for (uint32_t y = ty; y < std::min(ty + 8u, y1); ++y) {
+                    for (uint32_t x = tx; x < std::min(tx + 8u, width); ++x) out.push_back(y * width + x);
+                }
+            }
+        }
+    }
+}
+
+struct EventTimer {
+    std::vector<hipEvent_t> events;
+    size_t used = 0;
+    ~EventTimer() {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
+    hipEvent_t next() {
+        if (used == events.size()) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreate(&e));
+            events.push_back(e);
+        }
+        return events[used++];
+    }
+};
+
+void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, uint32_t part, uint32_t parts, float* dOut,
+                 hipStream_t stream, bool count, PtrRenderStats* stats) {
+    if (settings.width == 0 || settings.height == 0) throw HipError{"render size must be non-zero"};
+    if (parts == 0 || part >= parts) throw HipError{"bad partition"};
+    HIP_CHECK(hipSetDevice(ds.device));
+
+    RenderParams rp;
+    fillRenderParams(settings, spp, rp);
+
+    if (ds.cachedW != settings.width || ds.cachedH != settings.height || ds.cachedPart != part || ds.cachedParts != parts) {
+        std::vector<uint32_t> pixels;
+        partitionPixels(settings.width, settings.height, part, parts, pixels);
+        ds.pixelOfLocal.upload(pixels.data(), pixels.size());
+        ds.cachedW = settings.width;
+        ds.cachedH = settings.height;
+        ds.cachedPart = part;
+        ds.cachedParts = parts;
+        ds.cachedLocalPixels = static_cast<uint32_t>(pixels.size());
+    }
+    const uint32_t localPixels = ds.cachedLocalPixels;
+    const uint32_t bandCount = ptr_part_band_count(settings.height, part, parts);
+    const size_t outFloats = static_cast<size_t>(bandCount) * 16u * settings.width * 3u;
+    HIP_CHECK(hipMemsetAsync(dOut, 0, outFloats * sizeof(float), stream));
+    if (localPixels == 0) {
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return;
+    }
+
+    // slots in flight: enough to keep every CU's wave slots full several times over
+    const uint64_t targetSlots = 4ull << 20;
+    uint32_t inFlight = static_cast<uint32_t>(std::max<uint64_t>(1, targetSlots / localPixels));
+    inFlight = std::min(inFlight, rp.spp);
+    rp.samplesInFlight = inFlight;
+    rp.localPixels = localPixels;
+    const uint32_t slots = localPixels * inFlight;
+
+    ds.rayOrg.ensure(slots);
+    ds.rayDir.ensure(slots);
+    ds.hit.ensure(slots);
+    ds.throughput.ensure(slots);
+    ds.accum.ensure(slots);
+    ds.state.ensure(slots);
+    ds.recBuf.ensure(static_cast<size_t>(slots) * kRecSlots * 4u);
+    ds.shadowQueue.ensure(static_cast<size_t>(slots) * kRecSlots);
+
+    PathPool pool;
+    std::memset(&pool, 0, sizeof(pool));
+    pool.rayOrg = ds.rayOrg.ptr;
+    pool.rayDir = ds.rayDir.ptr;
+    pool.hit = ds.hit.ptr;
+    pool.throughput = ds.throughput.ptr;
+    pool.accum = ds.accum.ptr;
+    pool.state = ds.state.ptr;
+    for (uint32_t k = 0; k < kRecSlots; ++k) {
+        float4* base = ds.recBuf.ptr + static_cast<size_t>(k) * 4u * slots;
+        pool.rec[k].org = base;
+        pool.rec[k].dir = base + slots;
+        pool.rec[k].a = base + 2ull * slots;
+        pool.rec[k].b = base + 3ull * slots;
+    }
+    pool.shadowQueue = ds.shadowQueue.ptr;
+    pool.shadowCount = ds.scalars.ptr;
+    pool.aliveCount = ds.scalars.ptr + 1;
+    pool.pixelOfLocal = ds.pixelOfLocal.ptr;
+    pool.counters = ds.counters.ptr;
+    pool.slots = slots;
+
+    LaunchConfig cfg{ds.traceGrid, ds.spill.ptr};
+
+    const bool timed = stats != nullptr;
+    EventTimer timer;
+    struct Span {
+        hipEvent_t a, b;
+        int kind;
+    };
+    std::vector<Span> spans;
+    auto timedLaunch = [&](int kind, auto&& fn) {
+        if (timed) {
+            const hipEvent_t a = timer.next(), b = timer.next();
+            HIP_CHECK(hipEventRecord(a, stream));
+            fn();
+            HIP_CHECK(hipEventRecord(b, stream));
+            spans.push_back({a, b, kind});
+        } else {
+            fn();
+        }
+    };
+
+    if (count) HIP_CHECK(hipMemsetAsync(ds.counters.ptr, 0, sizeof(uint64_t) * kCounterSlots, stream));
+    HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * (1 + kAliveRing), stream));
+
+    const auto wall0 = std::chrono::steady_clock::now();
+    launchGenerate(rp, pool, stream);
+    uint64_t iterations = 0;
+    // Worst case: every sample runs maxDepth bounces in sequence on its slot.
+    const uint64_t maxIterations = static_cast<uint64_t>(rp.maxDepth) * ((rp.spp + inFlight - 1) / inFlight) + 4;
+    const uint32_t checkEvery = 4;
+    while (rp.maxDepth > 0) {
+        const uint32_t ring = static_cast<uint32_t>(iterations % kAliveRing);
+        uint32_t* aliveSlot = ds.scalars.ptr + 1 + ring;
+        HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t), stream));      // shadow queue length
+        HIP_CHECK(hipMemsetAsync(aliveSlot, 0, sizeof(uint32_t), stream));
+        timedLaunch(0, [&] { launchExtend(ds.view, pool, cfg, count, stream); });
+        timedLaunch(1, [&] { launchShade(rp, ds.view, pool, aliveSlot, count, stream); });
+        timedLaunch(2, [&] { launchConnect(rp, ds.view, pool, cfg, count, stream); });
+        ++iterations;
+        if (iterations % checkEvery == 0 || iterations >= maxIterations) {
+            HIP_CHECK(hipMemcpyAsync(ds.pinnedAlive, aliveSlot, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (ds.pinnedAlive[0] == 0u) break;
+            if (iterations >= maxIterations) throw HipError{"wavefront loop did not terminate"};
+        }
+    }
+    launchResolve(rp, pool, parts, dOut, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->totalSeconds = seconds;
+        stats->avgMsPerSample = seconds * 1000.0 / rp.spp;
+        stats->uploadSeconds = ds.uploadSeconds;
+        stats->samples = static_cast<uint64_t>(localPixels) * rp.spp;
+        for (const Span& s : spans) {
+            float ms = 0.0f;
+            HIP_CHECK(hipEventElapsedTime(&ms, s.a, s.b));
+            if (s.kind == 0) {
+                stats->traceKernelMs += ms;
+                ++stats->traceLaunches;
+            } else if (s.kind == 1) {
+                stats->shadeKernelMs += ms;
+            } else {
+                stats->shadowKernelMs += ms;
+            }
+        }
+        if (count) {
+            uint64_t c[kCounterSlots];
+            HIP_CHECK(hipMemcpy(c, ds.counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
+            stats->primaryRays = c[kCntPrimaryRays];
+            stats->extendRays = c[kCntExtendRays];
+            stats->shadowRays = c[kCntShadowRays];
+            stats->extendNodesVisited = c[kCntExtendNodes];
+            stats->extendLeafPrimTests = c[kCntExtendPrims];
+            stats->nodesVisited = c[kCntExtendNodes] + c[kCntShadowNodes];
+            stats->leafPrimTests = c[kCntExtendPrims] + c[kCntShadowPrims];
+            stats->shadedHits = c[kCntShadedHits];
+            stats->triangleHits = c[kCntTriangleHits];
+            stats->shadowEarlyExits = c[kCntShadowEarlyExit];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+uint32_t ptr_part_band_count(uint32_t height, uint32_t part_index, uint32_t part_count) {
+    if (part_count == 0 || part_index >= part_count) return 0;
+    const uint32_t bands = (height + 15u) / 16u;
+    return bands > part_index ? (bands - part_index + part_count - 1u) / part_count : 0u;
+}
+
+int ptr_scene_upload(const PtrSceneDesc* scene, int device, PtrDeviceScene** out_scene, char* err, size_t err_cap) {
+    if (!scene || !out_scene) {
+        setErr(err, err_cap, "ptr_scene_upload: null argument");
+        return 1;
+    }
+    if (ptr_device_count() <= device || device < 0) {
+        setErr(err, err_cap, "ptr_scene_upload: no such HIP device (the HIP path has no CPU fallback)");
+        return 2;
+    }
+    try {
+        auto ds = std::make_unique<PtrDeviceScene>();
+        ds->device = device;
+        buildScene(*scene, *ds);
+        *out_scene = ds.release();
+        return 0;
+    } catch (const HipError& e) {
+        setErr(err, err_cap, e.message);
+        return 1;
+    }
+}
+
+void ptr_scene_release(PtrDeviceScene* scene) {
+    if (!scene) return;
+    (void)hipSetDevice(scene->device);
+    delete scene;
+}
+
+int ptr_scene_info(const PtrDeviceScene* scene, uint64_t out[8]) {
+    if (!scene || !out) return 1;
+    std::memcpy(out, scene->info, sizeof(scene->info));
+    return 0;
+}
+
+int ptr_render_bands_device(PtrDeviceScene* scene, const PtrSettings* settings, uint32_t spp, uint32_t part_index,
+                            uint32_t part_count, void* d_out_rgb, void* stream, int count_traversal,
+                            PtrRenderStats* stats, char* err, size_t err_cap) {
+    if (!scene || !settings || !d_out_rgb) {
+        setErr(err, err_cap, "ptr_render_bands_device: null argument");
+        return 1;
+    }
+    try {
+        renderBands(*scene, *settings, spp, part_index, part_count, static_cast<float*>(d_out_rgb),
+                    static_cast<hipStream_t>(stream), count_traversal != 0, stats);
+        return 0;
+    } catch (const HipError& e) {
+        setErr(err, err_cap, e.message);
+        return 1;
+    }
+}
+
+int ptr_render_bands(PtrDeviceScene* scene, const PtrSettings* settings, uint32_t spp, uint32_t part_index,
+                     uint32_t part_count, float* out_rgb_bands, int count_traversal, PtrRenderStats* stats,
+                     char* err, size_t err_cap) {
+    if (!scene || !settings || !out_rgb_bands) {
+        setErr(err, err_cap, "ptr_render_bands: null argument");
+        return 1;
+    }
+    try {
+        const size_t floats = static_cast<size_t>(ptr_part_band_count(settings->height, part_index, part_count)) * 16u * settings->width * 3u;
+        HIP_CHECK(hipSetDevice(scene->device));
+        scene->outBands.ensure(floats);
+        renderBands(*scene, *settings, spp, part_index, part_count, scene->outBands.ptr, nullptr, count_traversal != 0, stats);
+        HIP_CHECK(hipMemcpy(out_rgb_bands, scene->outBands.ptr, floats * sizeof(float), hipMemcpyDeviceToHost));
+        return 0;
+    } catch (const HipError& e) {
+        setErr(err, err_cap, e.message);
+        return 1;
+    }
+}
+
+int ptr_render(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t spp, int verbose, float* out_rgb,
+               PtrRenderStats* stats, char* err, size_t err_cap) {
+    if (!scene || !settings || !out_rgb) {
+        setErr(err, err_cap, "ptr_render: null argument");
+        return 1;
+    }
+    PtrDeviceScene* ds = nullptr;
+    int rc = ptr_scene_upload(scene, 0, &ds, err, err_cap);
+    if (rc != 0) return rc;
+    const uint32_t bands = (settings->height + 15u) / 16u;
+    std::vector<float> banded(static_cast<size_t>(bands) * 16u * settings->width * 3u);
+    PtrRenderStats local{};
+    rc = ptr_render_bands(ds, settings, spp, 0, 1, banded.data(), 0, &local, err, err_cap);
+    if (rc == 0) {
+        // with a single partition the band layout is the image itself (plus padding rows)
+        std::memcpy(out_rgb, banded.data(), static_cast<size_t>(settings->width) * settings->height * 3u * sizeof(float));
+        if (stats) *stats = local;
+        if (verbose) {
+            std::fprintf(stderr, "[ptr] BVH %llu nodes, %llu tris, %llu spheres; upload %.3f s; render %.3f s (trace %.1f ms, shade %.1f ms, connect %.1f ms)\n",
+                         static_cast<unsigned long long>(ds->info[0]), static_cast<unsigned long long>(ds->info[2]),
+                         static_cast<unsigned long long>(ds->info[3]), ds->uploadSeconds, local.totalSeconds,
+                         local.traceKernelMs, local.shadeKernelMs, local.shadowKernelMs);
+        }
+    }
+    ptr_scene_release(ds);
+    return rc;
+}
+
+int ptr_trace_rays(PtrDeviceScene* scene, const float* rays, uint64_t n, int any_hit, PtrHit* out, PtrRenderStats* stats,
+                   char* err, size_t err_cap) {
+    if (!scene || (!rays && n) || (!out && n)) {
+        setErr(err, err_cap, "ptr_trace_rays: null argument");
+        return 1;
+    }
+    try {
+        HIP_CHECK(hipSetDevice(scene->device));
+        if (n == 0) return 0;
+        scene->rayBatch.upload(reinterpret_cast<const float4*>(rays), n * 2);
+        scene->hitBatch.ensure(n);
+        HIP_CHECK(hipMemset(scene->counters.ptr, 0, sizeof(uint64_t) * kCounterSlots));
+        LaunchConfig cfg{scene->traceGrid, scene->spill.ptr};
+        launchTraceRays(scene->view, scene->rayBatch.ptr, n, any_hit != 0, scene->hitBatch.ptr, cfg, scene->counters.ptr, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(out, scene->hitBatch.ptr, n * sizeof(PtrHit), hipMemcpyDeviceToHost));
+        if (stats) {
+            std::memset(stats, 0, sizeof(*stats));
+            uint64_t c[kCounterSlots];
+            HIP_CHECK(hipMemcpy(c, scene->counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
+            stats->nodesVisited = c[kCntExtendNodes] + c[kCntShadowNodes];
+            stats->leafPrimTests = c[kCntExtendPrims] + c[kCntShadowPrims];
+            stats->extendRays = any_hit ? 0 : n;
+            stats->shadowRays = any_hit ? n : 0;
+        }
+        return 0;
+    } catch (const HipError& e) {
+        setErr(err, err_cap, e.message);
+        return 1;
+    }
+}
+
+}  // extern "C"

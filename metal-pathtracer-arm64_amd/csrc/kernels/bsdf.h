@@ -1,0 +1,808 @@
+// Material evaluation / sampling on the device: the eight material models of the reference with the
+// Embree path's semantics (half-vector GGX sampling with pdf D*cos/(4 wo.wh), specular-tail clamp, no energy
+// compensation, dielectric weights not divided by the pick probability, subsurface == Lambert, factor-only PBR).
+// Oracle twins: src/headless/EmbreeHeadlessRenderer.mm EvaluateBsdf 1315-1491, SampleBsdf 1493-1918, helpers
+// 312-885, car paint 1170-1313 (Metal counterparts: shaders/pathtrace.metal evaluate_bsdf 4950, sample_bsdf 5136).
+// Random numbers are consumed in the oracle's order so a path follows the same stream.
+#pragma once
+
+#include "device_types.h"
+#include "vec.h"
+
+namespace ptrk {
+
+struct ClampCfg {
+    float factor, floorLum, throughput, tailBase, tailRoughScale, minSpecPdf;
+    bool enabled;
+};
+
+__device__ __forceinline__ uint32_t rngHash(uint32_t x) {  // lowbias32
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ float rngNext(uint32_t& state) {
+    state = rngHash(state);
+    return static_cast<float>(state & 0x00FFFFFFu) / 16777216.0f;
+}
+
+__device__ __forceinline__ float luminance(f3 c) { return (0.2126f * c.x + 0.7152f * c.y) + 0.0722f * c.z; }
+
+// Material record view: 12 float4, fetched on demand (most branches need 2-4 of them).
+struct Mat {
+    const float4* p;
+    __device__ __forceinline__ float4 v(uint32_t slot) const { return p[slot]; }
+    __device__ __forceinline__ uint32_t type() const { return static_cast<uint32_t>(p[kMatTypeEta].x); }
+    __device__ __forceinline__ f3 baseColor() const { return vclamp(mk3(p[kMatBaseColorRoughness]), 0.0f, 1.0f); }
+    __device__ __forceinline__ float roughness01() const { return clampf(p[kMatBaseColorRoughness].w, 0.0f, 1.0f); }
+    __device__ __forceinline__ float ior() const { return p[kMatTypeEta].y; }
+};
+
+// ------------------------------------------------------------------ clamps
+__device__ __forceinline__ f3 clampFirefly(f3 throughput, f3 contribution, const ClampCfg& c) {
+    f3 combined = throughput * contribution;
+    if (!finite3(combined)) return mk3(0.0f);
+    f3 positive = vmax0(combined);
+    if (!c.enabled) return positive;
+    const float lum = luminance(positive);
+    const float maxLum = smax(luminance(vmax0(throughput)) * c.factor, c.floorLum);
+    if (lum > maxLum && lum > 0.0f) {
+        combined *= maxLum / smax(lum, 1.0e-6f);
+        positive = vmax0(combined);
+    }
+    return positive;
+}
+
+__device__ __forceinline__ float clampSpecPdf(float pdf, const ClampCfg& c) {
+    const float minPdf = smax(c.minSpecPdf, 1.0e-8f);
+    return isfinite(pdf) ? smax(pdf, minPdf) : minPdf;
+}
+
+__device__ __forceinline__ f3 clampThroughput(f3 t, const ClampCfg& c) {
+    if (!finite3(t)) return mk3(0.0f);
+    if (!c.enabled || c.throughput <= 0.0f) return t;
+    const float lum = luminance(vmax0(t));
+    if (lum > c.throughput && lum > 0.0f) return t * (c.throughput / smax(lum, 1.0e-6f));
+    return t;
+}
+
+__device__ __forceinline__ f3 clampSpecTail(f3 value, float roughness, f3 f0, const ClampCfg& c) {
+    if (!finite3(value)) return mk3(0.0f);
+    f3 positive = vmax0(value);
+    if (!c.enabled) return positive;
+    const float strength = smax(smax(f0.x, f0.y), smax(f0.z, 1.0e-3f));
+    const float limit = smax((c.tailBase + c.tailRoughScale * roughness) * strength, c.floorLum);
+    const float lum = luminance(positive);
+    if (lum > limit && lum > 0.0f) positive *= limit / smax(lum, 1.0e-6f);
+    return positive;
+}
+
+// ------------------------------------------------------------------ frames, Fresnel, GGX
+struct Frame {
+    f3 t, b, n;
+};
+
+__device__ __forceinline__ Frame makeFrame(f3 n) {
+    Frame f;
+    f.n = normalize(n);
+    const f3 up = (fabsf(f.n.z) < 0.999f) ? mk3(0.0f, 0.0f, 1.0f) : mk3(1.0f, 0.0f, 0.0f);
+    f.t = normalize(cross(up, f.n));
+    f.b = cross(f.n, f.t);
+    return f;
+}
+
+__device__ __forceinline__ f3 frameToWorld(f3 l, const Frame& f) { return (l.x * f.t + l.y * f.b) + l.z * f.n; }
+
+__device__ __forceinline__ f3 reflectDir(f3 v, f3 n) { return v - 2.0f * dot(v, n) * n; }
+
+__device__ __forceinline__ f3 cosineHemisphere(uint32_t& rng, f3 n, float& pdf) {
+    const float r1 = rngNext(rng);
+    const float r2 = rngNext(rng);
+    const float r = sqrtf(smax(r1, 0.0f));
+    const float phi = 2.0f * kPi * r2;
+    const float x = cosf(phi) * r;
+    const float y = sinf(phi) * r;
+    const float z = sqrtf(smax(1.0f - r1, 0.0f));
+    pdf = z / kPi;
+    return normalize(frameToWorld(mk3(x, y, z), makeFrame(n)));
+}
+
+__device__ __forceinline__ float schlickW(float cosTheta) {
+    const float m = clampf(1.0f - cosTheta, 0.0f, 1.0f);
+    const float m2 = m * m;
+    return m2 * m2 * m;
+}
+
+__device__ __forceinline__ f3 schlick(f3 f0, float cosTheta) { return f0 + (mk3(1.0f) - f0) * schlickW(cosTheta); }
+
+__device__ __forceinline__ float fresnelDielectric(float cosI, float etaI, float etaT, float& cosTOut) {
+    cosI = clampf(cosI, -1.0f, 1.0f);
+    const float ac = fabsf(cosI);
+    const float sinI2 = smax(0.0f, 1.0f - ac * ac);
+    const float eta = etaI / etaT;
+    const float sinT2 = eta * eta * sinI2;
+    if (sinT2 >= 1.0f) {
+        cosTOut = 0.0f;
+        return 1.0f;
+    }
+    const float cosT = sqrtf(smax(0.0f, 1.0f - sinT2));
+    cosTOut = cosT;
+    const float a = etaI * ac, b = etaT * cosT;
+    const float rs = (a - b) / (a + b);
+    const float rp = (etaT * ac - etaI * cosT) / (etaT * ac + etaI * cosT);
+    return 0.5f * (rs * rs + rp * rp);
+}
+
+__device__ __forceinline__ f3 fresnelConductor(float cosI, f3 eta, f3 k) {
+    cosI = clampf(cosI, -1.0f, 1.0f);
+    const float cos2 = cosI * cosI;
+    const float sin2 = smax(0.0f, 1.0f - cos2);
+    const f3 eta2 = eta * eta, k2 = k * k;
+    const f3 t0 = (eta2 - k2) - mk3(sin2);
+    const f3 a2b2 = vsqrt(vmax0(t0 * t0 + (4.0f * eta2) * k2));
+    const f3 a = vsqrt(vmax0(0.5f * (a2b2 + t0)));
+    const f3 term1 = a2b2 + mk3(cos2);
+    const f3 term2 = (2.0f * mk3(cosI)) * a;
+    const f3 rs = (term1 - term2) / (term1 + term2);
+    const f3 term3 = mk3(cos2) * a2b2 + mk3(sin2 * sin2);
+    const f3 term4 = term2 * mk3(sin2);
+    const f3 rp = (term3 - term4) / (term3 + term4);
+    return vclamp(0.5f * (rs * rs + rp * rp), 0.0f, 1.0f);
+}
+
+__device__ __forceinline__ float ggxLambda(float alpha, float cosTheta) {
+    const float ac = fabsf(cosTheta);
+    if (ac <= 0.0f) return 0.0f;
+    const float sinTheta = sqrtf(smax(0.0f, 1.0f - ac * ac));
+    if (sinTheta == 0.0f) return 0.0f;
+    const float a = alpha * (sinTheta / ac);
+    return (-1.0f + sqrtf(1.0f + a * a)) * 0.5f;
+}
+
+__device__ __forceinline__ float ggxG1(float alpha, float cosTheta) { return 1.0f / (1.0f + ggxLambda(alpha, cosTheta)); }
+
+__device__ __forceinline__ float ggxD(float alpha, float cosH) {
+    const float c = fabsf(cosH);
+    const float a2 = alpha * alpha;
+    const float denom = c * c * (a2 - 1.0f) + 1.0f;
+    return a2 / (kPi * denom * denom);
+}
+
+__device__ __forceinline__ float ggxPdf(float alpha, f3 n, f3 wo, f3 wi) {
+    const f3 wh = normalize(wo + wi);
+    const float cosH = dot(n, wh);
+    const float denom = 4.0f * smax(dot(wo, wh), 1.0e-6f);
+    return ggxD(alpha, smax(cosH, 0.0f)) * smax(cosH, 0.0f) / denom;
+}
+
+__device__ __forceinline__ f3 sampleGgxHalf(uint32_t& rng, float alpha, f3 n) {
+    const float u1 = rngNext(rng);
+    const float u2 = rngNext(rng);
+    const float phi = 2.0f * kPi * u1;
+    const float denom = 1.0f + (alpha * alpha - 1.0f) * u2;
+    const float cosT = sqrtf(smax((1.0f - u2) / smax(denom, 1.0e-6f), 0.0f));
+    const float sinT = sqrtf(smax(0.0f, 1.0f - cosT * cosT));
+    return normalize(frameToWorld(mk3(cosf(phi) * sinT, sinf(phi) * sinT, cosT), makeFrame(n)));
+}
+
+__device__ __forceinline__ f3 sampleGgxVndf(uint32_t& rng, float roughness, f3 n, f3 wo) {
+    const float alpha = smax(roughness * roughness, 1.0e-4f);
+    const Frame fr = makeFrame(n);
+    const f3 won = normalize(wo);
+    f3 wl = mk3(dot(won, fr.t), dot(won, fr.b), dot(won, fr.n));
+    wl.z = smax(wl.z, 1.0e-6f);
+    const f3 vh = normalize(mk3(alpha * wl.x, alpha * wl.y, wl.z));
+    const float lensq = vh.x * vh.x + vh.y * vh.y;
+    const f3 t1 = lensq > 0.0f ? mk3(-vh.y, vh.x, 0.0f) / sqrtf(lensq) : mk3(1.0f, 0.0f, 0.0f);
+    const f3 t2 = cross(vh, t1);
+    const float u1 = rngNext(rng);
+    const float u2 = rngNext(rng);
+    const float r = sqrtf(u1);
+    const float phi = 2.0f * kPi * u2;
+    const float t1r = r * cosf(phi);
+    const float t2r = r * sinf(phi);
+    const float s = 0.5f * (1.0f + vh.z);
+    const float t2a = (1.0f - s) * sqrtf(smax(0.0f, 1.0f - t1r * t1r)) + s * t2r;
+    const float t3 = sqrtf(smax(0.0f, (1.0f - t1r * t1r) - t2a * t2a));
+    const f3 nh = (t1r * t1 + t2a * t2) + t3 * vh;
+    const f3 ne = normalize(mk3(alpha * nh.x, alpha * nh.y, smax(nh.z, 0.0f)));
+    return normalize(frameToWorld(ne, fr));
+}
+
+__device__ __forceinline__ float lambertPdf(f3 n, f3 dir) {
+    const float c = smax(dot(n, normalize(dir)), 0.0f);
+    return c > 0.0f ? (c / kPi) : 0.0f;
+}
+
+__device__ __forceinline__ f3 microfacet(f3 F, float alpha, f3 n, f3 wh, float cosO, float cosI) {
+    const float D = ggxD(alpha, dot(n, wh));
+    const float G = ggxG1(alpha, cosO) * ggxG1(alpha, cosI);
+    return F * (D * G / smax(4.0f * cosO * cosI, 1.0e-6f));
+}
+
+__device__ __forceinline__ bool halfOk(f3 wh, f3 n, f3 wo, f3 wi) {
+    return dot(wh, n) > 0.0f && dot(wo, wh) > 0.0f && dot(wi, wh) > 0.0f;
+}
+
+__device__ __forceinline__ float dielectricF0(float ior) {
+    const float eta = smax(ior, 1.0f);
+    const float r = (eta - 1.0f) / (eta + 1.0f);
+    return r * r;
+}
+
+__device__ __forceinline__ float dielectricF0Clamped(float ior) {
+    const float eta = smax(ior, 1.0f);
+    const float q = (eta - 1.0f) / smax(eta + 1.0f, 1.0e-6f);
+    return clampf(q * q, 0.0f, 0.99f);
+}
+
+__device__ __forceinline__ f3 exp3(f3 v) { return mk3(expf(v.x), expf(v.y), expf(v.z)); }
+__device__ __forceinline__ f3 fract3(f3 v) { return mk3(v.x - floorf(v.x), v.y - floorf(v.y), v.z - floorf(v.z)); }
+
+// ------------------------------------------------------------------ coat helpers (plastic / car paint)
+struct Coat {
+    float roughness, thickness, sampleWeight, fresnelAvg, ior;
+    f3 tint, absorption;
+};
+
+__device__ __forceinline__ Coat loadCoat(const Mat& m) {
+    Coat c;
+    const float4 cp = m.v(kMatCoatParams);
+    c.roughness = smax(clampf(cp.x, 0.0f, 1.0f), 1.0e-3f);
+    c.thickness = smax(cp.y, 0.0f);
+    c.sampleWeight = cp.z;
+    c.fresnelAvg = clampf(cp.w, 0.0f, 1.0f);
+    c.ior = smax(m.ior(), 1.0f);
+    c.tint = vclamp(mk3(m.v(kMatCoatTint)), 0.0f, 1.0f);
+    c.absorption = vmax0(mk3(m.v(kMatCoatAbsorption)));
+    return c;
+}
+
+__device__ __forceinline__ f3 coatSpecTint(const Coat& c) {
+    if (c.thickness <= 0.0f) return c.tint;
+    if (c.absorption.x <= 1.0e-6f && c.absorption.y <= 1.0e-6f && c.absorption.z <= 1.0e-6f) return c.tint;
+    return vclamp(c.tint * exp3(-c.absorption * c.thickness), 0.0f, 1.0f);
+}
+
+__device__ __forceinline__ f3 coatDiffuseTransmission(const Coat& c, float cosI, float cosO) {
+    if (c.thickness <= 0.0f) return c.tint;
+    const float ci = smax(cosI, 1.0e-3f), co = smax(cosO, 1.0e-3f);
+    const f3 ai = exp3(-c.absorption * (c.thickness / ci));
+    const f3 ao = exp3(-c.absorption * (c.thickness / co));
+    return vclamp((c.tint * ai) * ao, 0.0f, 1.0f);
+}
+
+// Plastic = GGX coat + Fresnel/absorption attenuated Lambert base.
+__device__ __forceinline__ void plasticLobes(const Mat& m, const Coat& c, f3 n, f3 wo, f3 wi, float cosO, float cosI,
+                                             const ClampCfg& cc, f3& spec, float& specPdf, f3& diffuse) {
+    const float alpha = c.roughness * c.roughness;
+    const f3 f0 = mk3(dielectricF0(c.ior));
+    spec = mk3(0.0f);
+    specPdf = 0.0f;
+    const f3 wh = normalize(wo + wi);
+    if (halfOk(wh, n, wo, wi)) {
+        spec = microfacet(schlick(f0, dot(wi, wh)), alpha, n, wh, cosO, cosI);
+        spec = clampSpecTail(spec, c.roughness, f0, cc);
+        spec *= coatSpecTint(c);
+        const float pdf = ggxPdf(alpha, n, wo, wi);
+        if (pdf > 0.0f) specPdf = clampSpecPdf(pdf, cc);
+        spec = vmax0(spec);
+    }
+    diffuse = m.baseColor() / kPi;
+    diffuse *= coatDiffuseTransmission(c, cosI, cosO);
+    diffuse *= (mk3(1.0f) - schlick(f0, cosI)) * (mk3(1.0f) - schlick(f0, cosO));
+    diffuse *= smax(1.0f - c.fresnelAvg, 0.0f);
+    diffuse = vmax0(diffuse);
+}
+
+// ------------------------------------------------------------------ conductors
+__device__ __forceinline__ bool hasConductorIor(float4 eta, float4 k) {
+    return eta.w > 0.0f || k.w > 0.0f || eta.x > 0.0f || eta.y > 0.0f || eta.z > 0.0f || k.x > 0.0f || k.y > 0.0f || k.z > 0.0f;
+}
+
+struct Conductor {
+    bool spectral;
+    f3 eta, k, f0;
+};
+
+__device__ __forceinline__ Conductor loadMetal(const Mat& m) {
+    Conductor c;
+    const float4 e = m.v(kMatConductorEta), k = m.v(kMatConductorK);
+    c.spectral = hasConductorIor(e, k);
+    c.eta = mk3(e);
+    c.k = mk3(k);
+    c.f0 = c.spectral ? fresnelConductor(1.0f, c.eta, c.k) : m.baseColor();
+    return c;
+}
+
+__device__ __forceinline__ f3 conductorF(const Conductor& c, float cosTheta) {
+    return c.spectral ? fresnelConductor(cosTheta, c.eta, c.k) : schlick(c.f0, cosTheta);
+}
+
+// ------------------------------------------------------------------ car paint
+struct CarPaint {
+    Coat coat;
+    float baseMetallic, baseRoughness, flakeScale;
+    float flakeWeight, flakeRoughness, flakeAniso, flakeStrength;
+    bool baseConductor;
+    f3 baseEta, baseK, base;
+    float pCoat, pFlake, pBase;
+};
+
+__device__ __forceinline__ CarPaint loadCarPaint(const Mat& m) {
+    CarPaint c;
+    c.coat = loadCoat(m);
+    const float4 bp = m.v(kMatCarpaintBase), fp = m.v(kMatCarpaintFlake);
+    const float4 be = m.v(kMatCarpaintBaseEta), bk = m.v(kMatCarpaintBaseK);
+    c.baseMetallic = clampf(bp.x, 0.0f, 1.0f);
+    c.baseRoughness = clampf(bp.y, 0.0f, 1.0f);
+    c.flakeScale = smax(bp.z, 1.0e-4f);
+    c.flakeWeight = clampf(fp.x, 0.0f, 0.95f);
+    c.flakeRoughness = clampf(fp.y, 0.0f, 1.0f);
+    c.flakeAniso = clampf(fp.z, -0.99f, 0.99f);
+    c.flakeStrength = clampf(fp.w, 0.0f, 1.0f);
+    c.baseConductor = be.w > 0.0f || bk.w > 0.0f;
+    c.baseEta = vmax0(mk3(be));
+    c.baseK = vmax0(mk3(bk));
+    c.base = m.baseColor();
+    // lobe pick probabilities (coat weight is clamped to 0.95 here, 1.0 for plastic)
+    float pc = clampf(c.coat.sampleWeight, 0.0f, 0.95f);
+    float pf = c.flakeWeight;
+    float pb = smax(1.0f - (pc + pf), 0.0f);
+    float norm = (pc + pf) + pb;
+    if (norm <= 1.0e-6f) {
+        pb = 1.0f;
+        pc = 0.0f;
+        pf = 0.0f;
+        norm = 1.0f;
+    }
+    c.pCoat = pc / norm;
+    c.pFlake = pf / norm;
+    c.pBase = pb / norm;
+    return c;
+}
+
+__device__ __forceinline__ f3 carpaintBaseF0(const CarPaint& c) {
+    return c.baseConductor ? fresnelConductor(1.0f, c.baseEta, c.baseK) : c.base;
+}
+
+__device__ __forceinline__ f3 carpaintHash3(f3 p) {
+    f3 v = fract3(p * 0.3183099f + mk3(0.1f, 0.3f, 0.7f));
+    const float d = dot(v, mk3(v.y + 33.33f, v.z + 55.55f, v.x + 77.77f));
+    v += mk3(d);
+    return fract3(mk3(v.x + v.y, v.x + v.z, v.y + v.z) * 13.5453123f);
+}
+
+__device__ __forceinline__ f3 carpaintFlakeNormal(const CarPaint& c, f3 position, f3 n) {
+    const f3 rnd = carpaintHash3(position * c.flakeScale);
+    const float ax = smax(1.0f - c.flakeAniso, 1.0e-3f);
+    const float ay = smax(1.0f + c.flakeAniso, 1.0e-3f);
+    const float phi = 2.0f * kPi * rnd.x;
+    const float r = sqrtf(smax(rnd.y, 1.0e-4f));
+    const float x = r * cosf(phi) * ax;
+    const float y = r * sinf(phi) * ay;
+    const float m2 = clampf(x * x + y * y, 0.0f, 0.99f);
+    const float z = sqrtf(smax(1.0f - m2, 0.0f));
+    const Frame fr = makeFrame(n);
+    const f3 perturbed = normalize((x * fr.t + y * fr.b) + z * fr.n);
+    return normalize(n * (1.0f - c.flakeStrength) + perturbed * c.flakeStrength);
+}
+
+struct Lobe {
+    f3 value;
+    float pdf;
+};
+
+__device__ __forceinline__ Lobe carpaintCoat(const CarPaint& c, f3 n, f3 wo, f3 wi, const ClampCfg& cc) {
+    Lobe r{mk3(0.0f), 0.0f};
+    const float cosO = smax(dot(n, wo), 0.0f), cosI = smax(dot(n, wi), 0.0f);
+    if (cosI <= 0.0f || cosO <= 0.0f) return r;
+    const float alpha = c.coat.roughness * c.coat.roughness;
+    const f3 wh = normalize(wo + wi);
+    if (!halfOk(wh, n, wo, wi)) return r;
+    const f3 f0 = mk3(dielectricF0(c.coat.ior));
+    f3 spec = microfacet(schlick(f0, dot(wi, wh)), alpha, n, wh, cosO, cosI);
+    spec = clampSpecTail(spec, c.coat.roughness, f0, cc);
+    spec *= coatSpecTint(c.coat);
+    spec = vmax0(spec);
+    const float pdf = ggxPdf(alpha, n, wo, wi);
+    if (pdf > 0.0f) {
+        r.pdf = clampSpecPdf(pdf, cc);
+        r.value = spec;
+    }
+    return r;
+}
+
+__device__ __forceinline__ Lobe carpaintFlake(const CarPaint& c, f3 position, f3 n, f3 wo, f3 wi, const ClampCfg& cc) {
+    Lobe r{mk3(0.0f), 0.0f};
+    const f3 fn = carpaintFlakeNormal(c, position, n);
+    const float cosO = smax(dot(fn, wo), 0.0f), cosI = smax(dot(fn, wi), 0.0f);
+    if (cosI <= 0.0f || cosO <= 0.0f) return r;
+    const float rough = smax(c.flakeRoughness, 1.0e-3f);
+    const float alpha = rough * rough;
+    const f3 wh = normalize(wo + wi);
+    if (!halfOk(wh, fn, wo, wi)) return r;
+    const f3 f0 = carpaintBaseF0(c);
+    f3 spec = microfacet(schlick(f0, dot(wi, wh)), alpha, fn, wh, cosO, cosI);
+    spec = clampSpecTail(spec * coatSpecTint(c.coat), rough, f0, cc);
+    spec *= smax(1.0f - c.coat.fresnelAvg, 0.0f);
+    spec = vmax0(spec);
+    const float pdf = ggxPdf(alpha, fn, wo, wi);
+    if (pdf > 0.0f) {
+        r.pdf = clampSpecPdf(pdf, cc);
+        r.value = spec;
+    }
+    return r;
+}
+
+__device__ __forceinline__ Lobe carpaintBase(const CarPaint& c, f3 n, f3 wo, f3 wi, const ClampCfg& cc) {
+    Lobe r{mk3(0.0f), 0.0f};
+    const float cosO = smax(dot(n, wo), 0.0f), cosI = smax(dot(n, wi), 0.0f);
+    if (cosI <= 0.0f || cosO <= 0.0f) return r;
+    const float dw = smax(1.0f - c.baseMetallic, 0.0f);
+    const float sw = smax(c.baseMetallic, 0.0f);
+    if (dw <= 1.0e-4f && sw <= 1.0e-4f) return r;
+    f3 combined = mk3(0.0f);
+    float pdfD = 0.0f, pdfS = 0.0f;
+    if (dw > 1.0e-4f) {
+        f3 diffuse = c.base / kPi;
+        diffuse *= coatDiffuseTransmission(c.coat, cosI, cosO) * smax(1.0f - c.coat.fresnelAvg, 0.0f);
+        diffuse = vmax0(diffuse);
+        combined += dw * diffuse;
+        pdfD = lambertPdf(n, wi);
+    }
+    if (sw > 1.0e-4f) {
+        const float rough = smax(c.baseRoughness, 1.0e-3f);
+        const float alpha = rough * rough;
+        const f3 wh = normalize(wo + wi);
+        if (halfOk(wh, n, wo, wi)) {
+            const f3 f0 = c.baseConductor ? fresnelConductor(1.0f, c.baseEta, c.baseK) : c.base;
+            const f3 F = c.baseConductor ? fresnelConductor(dot(wi, wh), c.baseEta, c.baseK) : schlick(c.base, dot(wi, wh));
+            f3 spec = microfacet(F, alpha, n, wh, cosO, cosI);
+            spec = clampSpecTail((spec * coatSpecTint(c.coat)) * smax(1.0f - c.coat.fresnelAvg, 0.0f), rough, f0, cc);
+            spec = vmax0(spec);
+            combined += sw * spec;
+            const float pdf = ggxPdf(alpha, n, wo, wi);
+            if (pdf > 0.0f) pdfS = clampSpecPdf(pdf, cc);
+        }
+    }
+    r.value = vmax0(combined);
+    r.pdf = dw * pdfD + sw * pdfS;
+    return r;
+}
+
+// ------------------------------------------------------------------ PBR (factor only)
+struct Pbr {
+    f3 f0, diffuseColor;
+    float roughness, specWeight;
+};
+
+__device__ __forceinline__ Pbr loadPbr(const Mat& m) {
+    Pbr p;
+    const f3 base = m.baseColor();
+    const float metallic = clampf(m.v(kMatCoatTint).w, 0.0f, 1.0f);
+    p.roughness = m.roughness01();
+    const float df0 = dielectricF0Clamped(m.ior());
+    p.f0 = base * metallic + mk3(df0) * (1.0f - metallic);
+    p.diffuseColor = base * (1.0f - metallic);
+    p.specWeight = clampf(smax(p.f0.x, smax(p.f0.y, p.f0.z)), 0.05f, 0.95f);
+    return p;
+}
+
+// ------------------------------------------------------------------ public: delta test, eval, sample
+__device__ __forceinline__ bool materialIsDelta(const Mat& m) {
+    const uint32_t type = m.type();
+    if (type == 2u) return true;
+    if (type == 1u) return smax(m.roughness01(), 1.0e-3f) <= 1.0e-3f;
+    return false;
+}
+
+struct BsdfEvalResult {
+    f3 value;
+    float pdf;
+    bool isDelta;
+};
+
+__device__ BsdfEvalResult evalBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 wi, const ClampCfg& cc) {
+    BsdfEvalResult r{mk3(0.0f), 0.0f, false};
+    const float cosO = smax(dot(n, wo), 0.0f), cosI = smax(dot(n, wi), 0.0f);
+    if (cosI <= 0.0f || cosO <= 0.0f) return r;
+    const uint32_t type = m.type();
+    switch (type) {
+        case 7u: {  // PBR metallic-roughness
+            const Pbr p = loadPbr(m);
+            const float alpha = smax(p.roughness * p.roughness, 1.0e-4f);
+            const f3 wh = normalize(wo + wi);
+            if (!halfOk(wh, n, wo, wi)) return r;
+            f3 spec = microfacet(schlick(p.f0, dot(wi, wh)), alpha, n, wh, cosO, cosI);
+            spec = vmax0(clampSpecTail(spec, p.roughness, p.f0, cc));
+            const float pdfS = ggxPdf(alpha, n, wo, wi);
+            const float pdfSc = (pdfS > 0.0f) ? clampSpecPdf(pdfS, cc) : 0.0f;
+            const float pdf = p.specWeight * pdfSc + (1.0f - p.specWeight) * lambertPdf(n, wi);
+            if (pdf > 0.0f) {
+                r.value = vmax0(spec + p.diffuseColor / kPi);
+                r.pdf = pdf;
+            }
+            return r;
+        }
+        case 4u: {  // plastic
+            const Coat c = loadCoat(m);
+            f3 spec, diffuse;
+            float specPdf;
+            plasticLobes(m, c, n, wo, wi, cosO, cosI, cc, spec, specPdf, diffuse);
+            const float pCoat = clampf(c.sampleWeight, 0.0f, 1.0f);
+            const float pdf = pCoat * specPdf + (1.0f - pCoat) * lambertPdf(n, wi);
+            if (pdf > 0.0f) {
+                r.value = spec + diffuse;
+                r.pdf = pdf;
+            }
+            return r;
+        }
+        case 1u: {  // metal
+            const float rough = m.roughness01();
+            if (rough <= 1.0e-3f) {
+                r.isDelta = true;
+                return r;
+            }
+            const float alpha = rough * rough;
+            const f3 wh = normalize(wo + wi);
+            if (!halfOk(wh, n, wo, wi)) return r;
+            const Conductor c = loadMetal(m);
+            f3 spec = microfacet(conductorF(c, dot(wi, wh)), alpha, n, wh, cosO, cosI);
+            spec = clampSpecTail(spec, rough, c.f0, cc);
+            const float pdf = ggxPdf(alpha, n, wo, wi);
+            if (pdf > 0.0f) {
+                r.value = vmax0(spec);
+                r.pdf = clampSpecPdf(pdf, cc);
+            }
+            return r;
+        }
+        case 6u: {  // car paint: probability-weighted mixture of base, flake and coat lobes
+            const CarPaint c = loadCarPaint(m);
+            const Lobe coat = carpaintCoat(c, n, wo, wi, cc);
+            const Lobe flake = carpaintFlake(c, position, n, wo, wi, cc);
+            const Lobe base = carpaintBase(c, n, wo, wi, cc);
+            r.value = (c.pBase * base.value + c.pFlake * flake.value) + c.pCoat * coat.value;
+            r.pdf = (c.pBase * base.pdf + c.pFlake * flake.pdf) + c.pCoat * coat.pdf;
+            return r;
+        }
+        case 2u:  // dielectric
+            r.isDelta = true;
+            return r;
+        default:  // Lambert, subsurface (Lambert on this path), anything unknown
+            r.value = m.baseColor() / kPi;
+            r.pdf = lambertPdf(n, wi);
+            return r;
+    }
+}
+
+struct BsdfSampleResult {
+    f3 dir, weight;
+    float pdf;
+    bool isDelta;
+};
+
+__device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 incident, bool frontFace,
+                                       uint32_t& rng, const ClampCfg& cc) {
+    BsdfSampleResult r{mk3(0.0f), mk3(0.0f), 0.0f, false};
+    const uint32_t type = m.type();
+    switch (type) {
+        case 7u: {
+            const Pbr p = loadPbr(m);
+            f3 wi, f;
+            float pdfS = 0.0f, pdfD = 0.0f;
+            if (rngNext(rng) < p.specWeight) {
+                if (p.roughness <= 1.0e-3f) {
+                    wi = normalize(reflectDir(incident, n));
+                    if (dot(n, wi) <= 0.0f) return r;
+                    f = schlick(p.f0, smax(dot(n, wo), 0.0f));
+                    pdfS = 1.0f;
+                    r.isDelta = true;
+                } else {
+                    const float alpha = p.roughness * p.roughness;
+                    const f3 wh = sampleGgxHalf(rng, alpha, n);
+                    if (dot(wh, n) <= 0.0f) return r;
+                    wi = normalize(reflectDir(-wo, wh));
+                    const float cosI = smax(dot(n, wi), 0.0f), cosO = smax(dot(n, wo), 0.0f);
+                    if (cosI <= 0.0f || cosO <= 0.0f) return r;
+                    f = microfacet(schlick(p.f0, dot(wi, wh)), alpha, n, wh, cosO, cosI);
+                    f = clampSpecTail(f, p.roughness, p.f0, cc);
+                    pdfS = ggxPdf(alpha, n, wo, wi);
+                }
+            } else {
+                wi = cosineHemisphere(rng, n, pdfD);
+                if (pdfD <= 0.0f || smax(dot(n, wi), 0.0f) <= 0.0f) return r;
+                f = p.diffuseColor / kPi;
+            }
+            const float cosI = smax(dot(n, wi), 0.0f);
+            const float pdfSc = (pdfS > 0.0f) ? clampSpecPdf(pdfS, cc) : 0.0f;
+            const float pdf = p.specWeight * pdfSc + (1.0f - p.specWeight) * pdfD;
+            if (pdf <= 0.0f || cosI <= 0.0f) return r;
+            const f3 w = f * cosI / pdf;
+            if (!finite3(w)) return r;
+            r.dir = wi;
+            r.weight = vmax0(w);
+            r.pdf = pdf;
+            return r;
+        }
+        case 4u: {
+            const Coat c = loadCoat(m);
+            const float alpha = c.roughness * c.roughness;
+            const float pCoat = clampf(c.sampleWeight, 0.0f, 1.0f);
+            f3 wi;
+            if (rngNext(rng) < pCoat) {
+                const f3 wh = sampleGgxHalf(rng, alpha, n);
+                if (dot(wh, n) <= 0.0f) return r;
+                wi = normalize(reflectDir(-wo, wh));
+            } else {
+                float unused;
+                wi = cosineHemisphere(rng, n, unused);
+            }
+            const float cosI = smax(dot(n, wi), 0.0f), cosO = smax(dot(n, wo), 0.0f);
+            if (cosI <= 0.0f || cosO <= 0.0f) return r;
+            f3 spec, diffuse;
+            float specPdf;
+            plasticLobes(m, c, n, wo, wi, cosO, cosI, cc, spec, specPdf, diffuse);
+            const float pdf = pCoat * specPdf + (1.0f - pCoat) * lambertPdf(n, wi);
+            if (pdf <= 0.0f) return r;
+            const f3 w = (spec + diffuse) * cosI / pdf;
+            if (!finite3(w)) return r;
+            r.dir = wi;
+            r.weight = vmax0(w);
+            r.pdf = pdf;
+            return r;
+        }
+        case 1u: {
+            const float rough = m.roughness01();
+            const Conductor c = loadMetal(m);
+            if (rough <= 1.0e-3f) {
+                const f3 wi = normalize(reflectDir(incident, n));
+                if (dot(n, wi) <= 0.0f) return r;
+                r.dir = wi;
+                r.weight = conductorF(c, smax(dot(n, wo), 0.0f));
+                r.pdf = 1.0f;
+                r.isDelta = true;
+                return r;
+            }
+            const float alpha = rough * rough;
+            const f3 wh = sampleGgxHalf(rng, alpha, n);
+            if (dot(wh, n) <= 0.0f) return r;
+            const f3 wi = normalize(reflectDir(-wo, wh));
+            const float cosI = dot(n, wi), cosO = dot(n, wo);
+            if (cosI <= 0.0f || cosO <= 0.0f) return r;
+            const float woh = dot(wo, wh);
+            if (woh <= 0.0f) return r;
+            const f3 F = conductorF(c, dot(wi, wh));
+            const float D = ggxD(alpha, dot(n, wh));
+            const float G = ggxG1(alpha, cosO) * ggxG1(alpha, cosI);
+            f3 f = F * (D * G / smax(4.0f * cosO * cosI, 1.0e-6f));
+            f = clampSpecTail(f, rough, c.f0, cc);
+            const float pdf = D * smax(dot(n, wh), 0.0f) / smax(4.0f * woh, 1.0e-6f);
+            if (pdf <= 0.0f) return r;
+            const float pdfC = clampSpecPdf(pdf, cc);
+            const f3 w = f * cosI / pdfC;
+            if (!finite3(w)) return r;
+            r.dir = wi;
+            r.weight = vmax0(w);
+            r.pdf = pdfC;
+            return r;
+        }
+        case 6u: {
+            const CarPaint c = loadCarPaint(m);
+            const float pick = rngNext(rng);
+            uint32_t lobe = 0u;  // 0 base, 1 flake, 2 coat
+            if (c.pCoat > 0.0f && pick < c.pCoat) {
+                lobe = 2u;
+            } else if (c.pFlake > 0.0f && pick < c.pCoat + c.pFlake) {
+                lobe = 1u;
+            } else if (c.pBase <= 1.0e-6f) {
+                if (c.pFlake > c.pCoat && c.pFlake > 0.0f) lobe = 1u;
+                else if (c.pCoat > 0.0f) lobe = 2u;
+            }
+            f3 wi;
+            if (lobe == 2u) {
+                const f3 wh = sampleGgxVndf(rng, c.coat.roughness, n, wo);
+                if (dot(wh, n) <= 0.0f) return r;
+                wi = normalize(reflectDir(-wo, wh));
+            } else if (lobe == 1u) {
+                const float fr = smax(c.flakeRoughness, 1.0e-3f);
+                const f3 fn = carpaintFlakeNormal(c, position, n);
+                const f3 wh = sampleGgxHalf(rng, fr * fr, fn);
+                if (dot(wh, fn) <= 0.0f) return r;
+                wi = normalize(reflectDir(-wo, wh));
+            } else {
+                const float dw = smax(1.0f - c.baseMetallic, 0.0f), sw = smax(c.baseMetallic, 0.0f);
+                const float sum = dw + sw;
+                const float choose = rngNext(rng);
+                if ((sw > 0.0f) && (sum > 0.0f) && (choose < sw / smax(sum, 1.0e-6f))) {
+                    const float br = smax(c.baseRoughness, 1.0e-3f);
+                    const f3 wh = sampleGgxHalf(rng, br * br, n);
+                    if (dot(wh, n) <= 0.0f) return r;
+                    wi = normalize(reflectDir(-wo, wh));
+                } else {
+                    float unused;
+                    wi = cosineHemisphere(rng, n, unused);
+                }
+            }
+            if (!finite3(wi) || dot(n, wi) <= 0.0f) return r;
+            const Lobe coat = carpaintCoat(c, n, wo, wi, cc);
+            const Lobe flake = carpaintFlake(c, position, n, wo, wi, cc);
+            const Lobe base = carpaintBase(c, n, wo, wi, cc);
+            const float pdf = (c.pBase * base.pdf + c.pFlake * flake.pdf) + c.pCoat * coat.pdf;
+            if (pdf <= 0.0f) return r;
+            const Lobe sel = (lobe == 1u) ? flake : (lobe == 2u ? coat : base);
+            if (sel.pdf <= 0.0f || !(sel.value.x > 0.0f || sel.value.y > 0.0f || sel.value.z > 0.0f)) return r;
+            const float cosI = smax(dot(n, wi), 0.0f);
+            if (cosI <= 0.0f) return r;
+            const f3 w = sel.value * cosI / pdf;
+            if (!finite3(w)) return r;
+            r.dir = wi;
+            r.weight = vmax0(w);
+            r.pdf = pdf;
+            return r;
+        }
+        case 2u: {  // smooth dielectric: Fresnel-weighted pick between mirror reflection and refraction
+            r.isDelta = true;
+            const float refIdx = smax(m.ior(), 1.0f);
+            const float etaI = frontFace ? 1.0f : refIdx;
+            const float etaT = frontFace ? refIdx : 1.0f;
+            const float cosO = clampf(dot(-incident, n), -1.0f, 1.0f);
+            float cosT = 0.0f;
+            const float Fr = fresnelDielectric(cosO, etaI, etaT, cosT);
+            f3 dir;
+            f3 weight = mk3(Fr);
+            bool refracted = false;
+            if (!(rngNext(rng) < Fr)) {
+                const float eta = etaI / etaT;
+                const float ct = smin(-dot(incident, n), 1.0f);
+                const f3 perp = eta * (incident + ct * n);
+                const float k = 1.0f - dot(perp, perp);
+                if (!(k < 0.0f)) {
+                    const f3 out = perp + (-sqrtf(k)) * n;
+                    if (dot(out, out) > 0.0f) {
+                        refracted = true;
+                        dir = normalize(out);
+                        const float etaScale = (etaT * etaT) / (etaI * etaI);
+                        const float dirScale = etaScale * (fabsf(cosT) / smax(fabsf(cosO), 1.0e-6f));
+                        weight = mk3(smax(1.0f - Fr, 0.0f) * dirScale);
+                    }
+                }
+            }
+            if (!refracted) dir = reflectDir(incident, n);
+            r.dir = normalize(dir);
+            r.weight = weight;
+            r.pdf = 1.0f;
+            return r;
+        }
+        case 0u:
+        case 5u: {  // Lambert / subsurface
+            float pdf = 0.0f;
+            const f3 wi = cosineHemisphere(rng, n, pdf);
+            const float cosI = dot(n, wi);
+            if (pdf <= 0.0f || cosI <= 0.0f) return r;
+            const f3 w = (m.baseColor() / kPi) * cosI / pdf;
+            if (!finite3(w)) return r;
+            r.dir = wi;
+            r.weight = vmax0(w);
+            r.pdf = pdf;
+            return r;
+        }
+        default: {  // unknown type: cosine sampling with weight = albedo
+            float pdf = 0.0f;
+            const f3 wi = cosineHemisphere(rng, n, pdf);
+            if (pdf <= 0.0f) return r;
+            const f3 w = m.baseColor();
+            if (!finite3(w)) return r;
+            r.dir = wi;
+            r.weight = vmax0(w);
+            r.pdf = pdf;
+            return r;
+        }
+    }
+}
+
+}  // namespace ptrk

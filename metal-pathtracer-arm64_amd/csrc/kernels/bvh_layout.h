@@ -1,0 +1,24 @@
+// BVH reference encoding shared by the host builder (plain C++) and the device traversal.
+#pragma once
+
+#include <cstdint>
+
+namespace ptrk {
+
+// ---- BVH child reference encoding (one per child slot of a 64 B node) ----
+//   0xFFFFFFFF                 : empty slot
+//   bit31 = 1                  : leaf; bit30 = sphere leaf; bits 26..29 = primCount-1; bits 0..25 = first prim
+//   otherwise                  : index of an internal node
+constexpr uint32_t kRefEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kRefLeafBit = 0x80000000u;
+constexpr uint32_t kRefSphereBit = 0x40000000u;
+constexpr uint32_t kRefCountShift = 26u;
+constexpr uint32_t kRefOffsetMask = 0x03FFFFFFu;
+constexpr uint32_t kMaxLeafPrims = 8u;
+constexpr uint32_t kTraversalStackDepth = 48u;   // builder bounds tree depth below this
+constexpr uint32_t kLdsStackLevels = 16u;        // stack levels kept in LDS; deeper levels spill to HBM
+constexpr uint32_t kTraceBlock = 256u;           // threads per block of the traversal kernels
+constexpr uint32_t kHitMiss = 0xFFFFFFFFu;
+constexpr uint32_t kHitSphereBit = 0x80000000u;
+
+}  // namespace ptrk

@@ -1,0 +1,137 @@
+// POD views shared by the host launcher and the HIP kernels: the HBM layout of a scene and of the
+// wavefront path pool.  Everything is SoA / 16-byte vectors so one lane moves one dwordx4 per access.
+#pragma once
+
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+#include "bvh_layout.h"
+
+namespace ptrk {
+
+// Node (4 x float4 = 64 B):  n[0] = (c0.min, bits(ref0))  n[1] = (c0.max, bits(ref1))
+//                            n[2] = (c1.min, 0)           n[3] = (c1.max, 0)
+// Triangle (3 x float4 = 48 B, BVH leaf order):
+//   t[0] = (v0, bits(materialIndex))  t[1] = (v0-v1, bits(kind<<30 | geomIndex))  t[2] = (v2-v0, bits(primIndex))
+//   kind: 0 = mesh triangle (geomIndex = mesh index), 2 = rectangle half (geomIndex = rectangle index)
+// Triangle normals (3 x float4, same order): world-space vertex normals (mesh) / rectangle normal.
+// Sphere (float4 centre+radius; uint2 {sphereIndex, materialIndex}), BVH leaf order.
+struct SceneView {
+    const float4* nodes;
+    const float4* tris;
+    const float4* triNormals;
+    const float4* spheres;
+    const uint2* sphereInfo;
+    const float4* materials;       // kMaterialVec4 float4 per material
+    const float4* rects;           // 5 float4 per rectangle (PtrRect layout)
+    const float4* rectLights;      // 4 float4 per light: corner|area, edgeU|twoSided, edgeV|rectIndex, normal|0 ; +1: emission
+    const int32_t* lightIndexByRect;
+    const float4* envRgba;
+    const float2* envCond;         // (threshold, bits(alias)) per texel
+    const float2* envMarg;         // per row
+    const float* envPdf;
+    uint32_t rootRef;
+    uint32_t materialCount;
+    uint32_t rectCount;
+    uint32_t rectLightCount;
+    uint32_t envWidth;
+    uint32_t envHeight;
+    uint32_t envSampling;          // distribution present
+    uint32_t pad;
+};
+
+// Compact material record: the MaterialData fields the Embree-semantics integrator reads.
+constexpr uint32_t kMaterialVec4 = 12u;
+enum MaterialSlot : uint32_t {
+    kMatBaseColorRoughness = 0,
+    kMatTypeEta = 1,
+    kMatEmission = 2,
+    kMatConductorEta = 3,
+    kMatConductorK = 4,
+    kMatCoatParams = 5,
+    kMatCoatTint = 6,          // w = pbr metallic
+    kMatCoatAbsorption = 7,
+    kMatCarpaintBase = 8,
+    kMatCarpaintFlake = 9,
+    kMatCarpaintBaseEta = 10,
+    kMatCarpaintBaseK = 11,
+};
+
+struct CameraParams {
+    float origin[3], lowerLeft[3], horizontal[3], vertical[3], u[3], v[3];
+    float lensRadius;
+};
+
+struct RenderParams {
+    CameraParams cam;
+    uint32_t width, height;
+    uint32_t maxDepth;
+    uint32_t seedBase;
+    uint32_t spp;
+    uint32_t samplesInFlight;      // S: slots per pixel; slot (lp, j) renders samples j, j+S, ...
+    uint32_t localPixels;          // pixels owned by this partition
+    uint32_t enableRussianRoulette, enableSpecularNee, enableMnee, enableMneeSecondary;
+    uint32_t backgroundMode;
+    float backgroundColor[3];
+    float envRotation, envIntensity;
+    // FireflyClampParams
+    float clampFactor, clampFloor, throughputClamp, tailClampBase, tailClampRoughnessScale, minSpecularPdf, clampEnabled;
+    float emissionScale;
+};
+
+// One pending light-connection ray of a path slot.
+//   org = (origin, tmax)   dir = (direction, bits(kind))   a = (contribution or bsdf weight, 0)   b = (throughput, 0)
+//   kind 0: any-hit; a is the finished contribution, zeroed by the connect kernel when occluded
+//   kind 1: closest hit + rectangle-light evaluation; connect kernel replaces a by the contribution
+//           (a = bsdf weight, w = bsdf pdf; b = throughput)
+//   kind 2: MNEE second bounce (closest hit, delta scatter with a copy of the rng in org.w, then both of the above)
+struct ShadowRecordView {
+    float4* org;
+    float4* dir;
+    float4* a;
+    float4* b;
+};
+
+// Record slots per path: 0 rect-light NEE, 1 environment NEE, 2 specular-NEE environment,
+// 3 specular-NEE rectangle lights, 4 MNEE two-bounce chain.
+constexpr uint32_t kRecSlots = 5u;
+
+struct PathPool {
+    float4* rayOrg;        // xyz origin
+    float4* rayDir;        // xyz direction
+    float4* hit;           // (t, u, v, bits(primRef))
+    float4* throughput;    // xyz throughput, w lastBsdfPdf
+    float4* accum;         // xyz radiance sum over this slot's samples
+    uint4* state;          // x rng, y sample index, z flags, w pending mask (bit k = record slot k)
+    ShadowRecordView rec[kRecSlots];
+    uint32_t* shadowQueue;     // entries = slot*kRecSlots + which
+    uint32_t* shadowCount;     // [1]
+    uint32_t* aliveCount;      // [1]
+    const uint32_t* pixelOfLocal;  // local pixel -> y*width + x
+    uint64_t* counters;        // kCounterSlots
+    uint32_t slots;
+};
+
+// flags word
+constexpr uint32_t kFlagAlive = 1u << 0;
+constexpr uint32_t kFlagLastDelta = 1u << 1;
+constexpr uint32_t kFlagDepthShift = 8u;        // 12 bits
+constexpr uint32_t kFlagSpecDepthShift = 20u;   // 12 bits
+constexpr uint32_t kFlagFieldMask = 0xFFFu;
+
+enum CounterSlot : uint32_t {
+    kCntExtendRays = 0,
+    kCntExtendNodes = 1,
+    kCntExtendPrims = 2,
+    kCntShadowRays = 3,
+    kCntShadowNodes = 4,
+    kCntShadowPrims = 5,
+    kCntShadedHits = 6,
+    kCntTriangleHits = 7,
+    kCntPrimaryRays = 8,
+    kCntShadowEarlyExit = 9,
+    kCntStackOverflow = 10,
+    kCounterSlots = 16,
+};
+
+}  // namespace ptrk

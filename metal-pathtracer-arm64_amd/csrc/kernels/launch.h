@@ -1,0 +1,37 @@
+// Host-callable launchers of the wavefront kernels (defined in wavefront.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+#include "ptr_abi.h"
+
+namespace ptrk {
+
+struct LaunchConfig {
+    uint32_t traceGrid;      // blocks of kTraceBlock threads for extend / connect (grid-stride)
+    uint32_t* spill;         // traversal stack spill area: (kTraversalStackDepth-kLdsStackLevels) * traceGrid*kTraceBlock words
+};
+
+void launchGenerate(const RenderParams& rp, const PathPool& pool, hipStream_t stream);
+void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count, hipStream_t stream);
+void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, uint32_t* aliveSlot, bool count,
+                 hipStream_t stream);
+void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count,
+                   hipStream_t stream);
+// Adds outstanding light connections, reduces the slots of each pixel in fixed order and writes
+// out[((localBand*16 + row) * width + x) * 3 + c] = sum / spp.
+void launchResolve(const RenderParams& rp, const PathPool& pool, uint32_t partCount, float* dOut, hipStream_t stream);
+
+void launchTraceRays(const SceneView& sc, const float4* dRays, uint64_t n, bool anyHit, PtrHit* dOut, const LaunchConfig& cfg,
+                     uint64_t* dCounters, hipStream_t stream);
+
+// Debug / known-answer kernels (tests only): evaluate and sample a material for a batch of inputs.
+void launchDebugEvalBsdf(const float4* dMaterial, const RenderParams& rp, const float* dIn, uint64_t n, float* dOut,
+                         hipStream_t stream);
+void launchDebugSampleBsdf(const float4* dMaterial, const RenderParams& rp, const float* dIn, const uint32_t* dFront,
+                           const uint32_t* dRng, uint64_t n, float* dOut, uint32_t* dRngOut, hipStream_t stream);
+void launchDebugCameraRays(const RenderParams& rp, const uint32_t* dXys, uint64_t n, float* dOut, uint32_t* dRngOut,
+                           hipStream_t stream);
+
+}  // namespace ptrk

@@ -1,0 +1,173 @@
+// BVH traversal + primitive tests for gfx950 (closest-hit and any-hit).
+//
+// Replaces traverse_bvh_triangles_segment / trace_scene_software of the reference's Metal kernel
+// (shaders/pathtrace.metal:1971-2165, 2266-2382) with Embree-path semantics (one world-space BVH over
+// mesh triangles, rectangle halves and spheres; true closest hit; tnear = 1e-4):
+//   triangle test  = Embree Moeller-Trumbore (external/embree/kernels/geometry/triangle_intersector_moeller.h:72-115)
+//   sphere test    = Embree SPHERE_POINT   (external/embree/kernels/geometry/sphere_intersector.h:80-121)
+//
+// MI355X mapping: one lane = one ray; a 64 B node (both child boxes + child refs) is 4 dwordx4 loads per
+// lane; leaves are encoded in the parent's child reference so a leaf costs no node fetch; the traversal
+// stack lives in LDS as stack[level][lane] (lane-private column => no bank conflicts at any divergence),
+// with levels >= kLdsStackLevels spilling to a lane-interleaved HBM area so occupancy is not bounded by
+// worst-case tree depth.
+#pragma once
+
+#include "device_types.h"
+#include "vec.h"
+
+namespace ptrk {
+
+struct TraceCounters {
+    uint32_t nodes;   // internal nodes fetched + leaves visited (== "nodes popped" of a reference-layout BVH)
+    uint32_t prims;   // primitive tests
+};
+
+struct LaneStack {
+    uint32_t* lds;        // &ldsStack[threadIdx.x]; stride kTraceBlock
+    uint32_t* spill;      // &spill[globalThread]; stride spillStride
+    uint32_t spillStride;
+    uint32_t sp;
+    __device__ __forceinline__ void push(uint32_t v) {
+        if (sp < kLdsStackLevels) {
+            lds[sp * kTraceBlock] = v;
+        } else if (sp < kTraversalStackDepth) {
+            spill[static_cast<size_t>(sp - kLdsStackLevels) * spillStride] = v;
+        } else {
+            return;  // cannot happen: the builder bounds tree depth below kTraversalStackDepth
+        }
+        ++sp;
+    }
+    __device__ __forceinline__ uint32_t pop() {
+        --sp;
+        return (sp < kLdsStackLevels) ? lds[sp * kTraceBlock]
+                                      : spill[static_cast<size_t>(sp - kLdsStackLevels) * spillStride];
+    }
+};
+
+struct TraceHit {
+    float t, u, v;
+    uint32_t prim;   // kHitMiss, or leaf-order index (| kHitSphereBit for spheres)
+};
+
+// Slab test of one child box.  fminf/fmaxf drop NaNs from 0*inf, boxes are padded at build time, and the
+// final comparison carries 4 ulp of slack, so a box is never culled when a primitive inside it passes
+// the exact test.
+__device__ __forceinline__ bool slabTest(f3 lo, f3 hi, f3 org, f3 inv, float tnear, float tfar, float& entry) {
+    const float ax = (lo.x - org.x) * inv.x, bx = (hi.x - org.x) * inv.x;
+    const float ay = (lo.y - org.y) * inv.y, by = (hi.y - org.y) * inv.y;
+    const float az = (lo.z - org.z) * inv.z, bz = (hi.z - org.z) * inv.z;
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tnear));
+    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tfar));
+    entry = t0;
+    return t0 <= t1 * 1.0000004f;
+}
+
+__device__ __forceinline__ bool triangleTest(f3 v0, f3 e1, f3 e2, f3 org, f3 dir, float tnear, float tfar,
+                                             float& t, float& u, float& v) {
+    const f3 Ng = cross(e2, e1);
+    const f3 C = v0 - org;
+    const f3 R = cross(C, dir);
+    const float den = dot(Ng, dir);
+    const float absDen = fabsf(den);
+    const float sgn = signbit(den) ? -1.0f : 1.0f;
+    const float U = dot(R, e2) * sgn;
+    const float V = dot(R, e1) * sgn;
+    if (!(den != 0.0f && U >= 0.0f && V >= 0.0f && (U + V) <= absDen)) return false;
+    const float T = dot(Ng, C) * sgn;
+    if (!(absDen * tnear < T && T <= absDen * tfar)) return false;
+    const float rcpAbsDen = 1.0f / absDen;
+    t = T * rcpAbsDen;
+    u = U * rcpAbsDen;
+    v = V * rcpAbsDen;
+    return true;
+}
+
+__device__ __forceinline__ bool sphereTest(float4 s, f3 org, f3 dir, float tnear, float tfar, float& t) {
+    const float rd2 = 1.0f / dot(dir, dir);
+    const f3 c0 = mk3(s) - org;
+    const float projC0 = dot(c0, dir) * rd2;
+    const f3 perp = c0 - projC0 * dir;
+    const float l2 = dot(perp, perp);
+    const float r2 = s.w * s.w;
+    if (!(l2 <= r2)) return false;
+    const float td = sqrtf((r2 - l2) * rd2);
+    const float tFront = projC0 - td;
+    const float tBack = projC0 + td;
+    const bool validFront = (tnear <= tFront) && (tFront <= tfar);
+    const bool validBack = (tnear <= tBack) && (tBack <= tfar);
+    if (!validFront && !validBack) return false;
+    t = validFront ? tFront : tBack;
+    return true;
+}
+
+// Closest hit (ANY = false) or first hit (ANY = true).  Returns hit.prim == kHitMiss on a miss.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ TraceHit traverse(const SceneView& sc, f3 org, f3 dir, float tnear, float tfar,
+                                             LaneStack& stack, TraceCounters& cnt) {
+    TraceHit hit;
+    hit.t = tfar;
+    hit.u = 0.0f;
+    hit.v = 0.0f;
+    hit.prim = kHitMiss;
+    const f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    stack.sp = 0;
+    uint32_t cur = sc.rootRef;
+    if (cur == kRefEmpty) return hit;
+
+    while (true) {
+        if (!(cur & kRefLeafBit)) {
+            // ---- internal node: both child boxes arrive with one 64 B fetch ----
+            const float4* n = sc.nodes + static_cast<size_t>(cur) * 4u;
+            const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            if (COUNT) ++cnt.nodes;
+            const uint32_t ref0 = __float_as_uint(n0.w), ref1 = __float_as_uint(n1.w);
+            float e0, e1;
+            const bool h0 = (ref0 != kRefEmpty) && slabTest(mk3(n0), mk3(n1), org, inv, tnear, hit.t, e0);
+            const bool h1 = (ref1 != kRefEmpty) && slabTest(mk3(n2), mk3(n3), org, inv, tnear, hit.t, e1);
+            if (h0 && h1) {
+                const bool firstIs0 = e0 <= e1;
+                stack.push(firstIs0 ? ref1 : ref0);   // far child waits on the stack
+                cur = firstIs0 ? ref0 : ref1;
+                continue;
+            }
+            if (h0) { cur = ref0; continue; }
+            if (h1) { cur = ref1; continue; }
+        } else {
+            // ---- leaf: primitives are stored contiguously in leaf order ----
+            const uint32_t first = cur & kRefOffsetMask;
+            const uint32_t count = ((cur >> kRefCountShift) & 0xFu) + 1u;
+            if (COUNT) { ++cnt.nodes; cnt.prims += count; }
+            if (cur & kRefSphereBit) {
+                for (uint32_t i = 0; i < count; ++i) {
+                    float t;
+                    if (sphereTest(sc.spheres[first + i], org, dir, tnear, hit.t, t)) {
+                        hit.t = t;
+                        hit.u = 0.0f;
+                        hit.v = 0.0f;
+                        hit.prim = (first + i) | kHitSphereBit;
+                        if (ANY) return hit;
+                    }
+                }
+            } else {
+                for (uint32_t i = 0; i < count; ++i) {
+                    const float4* tp = sc.tris + static_cast<size_t>(first + i) * 3u;
+                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    float t, u, v;
+                    if (triangleTest(mk3(a), mk3(b), mk3(c), org, dir, tnear, hit.t, t, u, v)) {
+                        hit.t = t;
+                        hit.u = u;
+                        hit.v = v;
+                        hit.prim = first + i;
+                        if (ANY) return hit;
+                    }
+                }
+            }
+        }
+        if (stack.sp == 0) break;
+        cur = stack.pop();
+    }
+    return hit;
+}
+
+}  // namespace ptrk

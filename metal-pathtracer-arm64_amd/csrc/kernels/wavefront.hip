@@ -1,0 +1,981 @@
+// Wavefront path tracer kernels for MI355X (gfx950).
+//
+// One bounce = three launches over a pool of resident path slots:
+//   k_extend   closest-hit BVH traversal for every live slot                (HBM/L2 latency bound; dominant)
+//   k_shade    hit reconstruction, emission/background, light sampling, BSDF sampling, next ray or
+//              regeneration of the slot with its next sample                (ALU bound)
+//   k_connect  any-hit / light-hit rays queued by k_shade, compacted        (traversal again)
+// A slot owns pixel `lp` and the samples j, j+S, j+2S...; it accumulates into its own float4, and
+// k_resolve sums the S slots of a pixel in a fixed order — results do not depend on scheduling.
+//
+// Integrator semantics and RNG consumption order follow the reference's Embree backend
+// (src/headless/EmbreeHeadlessRenderer.mm:2573-3130); the Metal twin is
+// shaders/pathtrace.metal trace_path_software 5717-7284 / pathtraceIntegrateKernel 9698-9816.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "bsdf.h"
+#include "device_types.h"
+#include "launch.h"
+#include "traverse.h"
+#include "vec.h"
+
+namespace ptrk {
+
+namespace {
+
+constexpr float kEps = 1.0e-4f;                  // ray epsilon of the Embree path
+constexpr float kSpecNeePdfFloor = 1.0e-4f;
+constexpr float kSpecNeeInvPdfClamp = 1.0e4f;
+constexpr float kMisMin = 1.0e-4f;
+constexpr float kMisMax = 0.9999f;
+constexpr uint32_t kShadeBlock = 128u;
+
+__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+__device__ __forceinline__ ClampCfg clampCfg(const RenderParams& rp) {
+    ClampCfg c;
+    c.factor = rp.clampFactor;
+    c.floorLum = rp.clampFloor;
+    c.throughput = rp.throughputClamp;
+    c.tailBase = rp.tailClampBase;
+    c.tailRoughScale = rp.tailClampRoughnessScale;
+    c.minSpecPdf = rp.minSpecularPdf;
+    c.enabled = rp.clampEnabled >= 0.5f;
+    return c;
+}
+
+// ---------------------------------------------------------------- wave helpers
+__device__ __forceinline__ uint32_t laneId() { return __lane_id(); }
+
+__device__ __forceinline__ uint32_t waveSum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// One atomic per wave; returns this lane's slot in the queue (valid where `want`).
+__device__ __forceinline__ uint32_t waveAppend(uint32_t* counter, bool want) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return 0u;
+    const uint32_t total = static_cast<uint32_t>(__popcll(mask));
+    const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(mask))) - 1u;
+    uint32_t base = 0u;
+    if (laneId() == leader) base = atomicAdd(counter, total);
+    base = __shfl(base, static_cast<int>(leader), 64);
+    const unsigned long long below = mask & ((1ull << laneId()) - 1ull);
+    return base + static_cast<uint32_t>(__popcll(below));
+}
+
+__device__ __forceinline__ void addCounter(uint64_t* counters, uint32_t slot, uint32_t value) {
+    const uint32_t total = waveSum(value);
+    if (laneId() == 0 && total != 0u) atomicAdd(reinterpret_cast<unsigned long long*>(counters + slot), static_cast<unsigned long long>(total));
+}
+
+// ---------------------------------------------------------------- camera
+__device__ __forceinline__ void cameraRay(const RenderParams& rp, uint32_t x, uint32_t y, uint32_t& rng, f3& org, f3& dir) {
+    const CameraParams& c = rp.cam;
+    const float u = (static_cast<float>(x) + rngNext(rng)) / static_cast<float>(rp.width);
+    float v = (static_cast<float>(y) + rngNext(rng)) / static_cast<float>(rp.height);
+    v = 1.0f - v;
+    f3 d = ((ld3(c.lowerLeft) + u * ld3(c.horizontal)) + v * ld3(c.vertical)) - ld3(c.origin);
+    f3 o = ld3(c.origin);
+    if (c.lensRadius > 0.0f) {
+        // thin lens: rejection-sample the unit disk, at most 8 pairs, (0,0) if all rejected
+        float dx = 0.0f, dy = 0.0f;
+        for (int i = 0; i < 8; ++i) {
+            const float px = rngNext(rng) * 2.0f - 1.0f;
+            const float py = rngNext(rng) * 2.0f - 1.0f;
+            if (px * px + py * py <= 1.0f) {
+                dx = px;
+                dy = py;
+                break;
+            }
+        }
+        dx *= c.lensRadius;
+        dy *= c.lensRadius;
+        const f3 offset = ld3(c.u) * dx + ld3(c.v) * dy;
+        o += offset;
+        d -= offset;
+    }
+    org = o;
+    dir = normalize(d);
+}
+
+// Start sample `s` of the slot's pixel: seed, primary ray, fresh path state.
+__device__ __forceinline__ void beginSample(const RenderParams& rp, uint32_t pixel, uint32_t s, uint32_t& rng, f3& org, f3& dir) {
+    rng = rngHash(rp.seedBase ^ pixel ^ (s * 0x9e3779b9u));
+    cameraRay(rp, pixel % rp.width, pixel / rp.width, rng, org, dir);
+}
+
+// ---------------------------------------------------------------- environment
+__device__ __forceinline__ f3 skyColor(f3 direction) {
+    const f3 unit = normalize(direction);
+    const float t = 0.5f * (unit.y + 1.0f);
+    return mk3(1.0f) * (1.0f - t) + mk3(0.5f, 0.7f, 1.0f) * t;
+}
+
+__device__ __forceinline__ void envUv(f3 direction, float rotation, float& u, float& v) {
+    const f3 unit = normalize(direction);
+    const float c = cosf(rotation), s = sinf(rotation);
+    const f3 r = mk3(unit.x * c - unit.z * s, unit.y, unit.x * s + unit.z * c);
+    u = (atan2f(r.z, r.x) + kPi) / (2.0f * kPi);
+    v = 0.5f - asinf(clampf(r.y, -1.0f, 1.0f)) / kPi;
+}
+
+// Bilinear lookup on level 0 with the -0.5 texel offset, wrap in x, clamp in y.
+__device__ __forceinline__ f3 envLookup(const SceneView& sc, f3 direction, float rotation, float intensity) {
+    if (sc.envWidth == 0u || sc.envHeight == 0u) return mk3(0.0f);
+    float u, v;
+    envUv(direction, rotation, u, v);
+    const int W = static_cast<int>(sc.envWidth), H = static_cast<int>(sc.envHeight);
+    const float fx = u * static_cast<float>(sc.envWidth) - 0.5f;
+    const float fy = v * static_cast<float>(sc.envHeight) - 0.5f;
+    int x0 = static_cast<int>(floorf(fx)), y0 = static_cast<int>(floorf(fy));
+    int x1 = x0 + 1, y1 = y0 + 1;
+    const float tx = fx - static_cast<float>(x0), ty = fy - static_cast<float>(y0);
+    x0 %= W; if (x0 < 0) x0 += W;
+    x1 %= W; if (x1 < 0) x1 += W;
+    y0 = min(max(y0, 0), H - 1);
+    y1 = min(max(y1, 0), H - 1);
+    const f3 c00 = mk3(sc.envRgba[static_cast<size_t>(y0) * W + x0]);
+    const f3 c10 = mk3(sc.envRgba[static_cast<size_t>(y0) * W + x1]);
+    const f3 c01 = mk3(sc.envRgba[static_cast<size_t>(y1) * W + x0]);
+    const f3 c11 = mk3(sc.envRgba[static_cast<size_t>(y1) * W + x1]);
+    const f3 c0 = c00 * (1.0f - tx) + c10 * tx;
+    const f3 c1 = c01 * (1.0f - tx) + c11 * tx;
+    return (c0 * (1.0f - ty) + c1 * ty) * smax(intensity, 0.0f);
+}
+
+// Solid-angle pdf of the texel a direction looks up (note: offset by half a turn from the texel the
+// sampler would have drawn it from — reference quirk Q2, kept).
+__device__ __forceinline__ float envPdfOf(const SceneView& sc, f3 direction, float rotation) {
+    if (!sc.envSampling) return 0.0f;
+    float u, v;
+    envUv(direction, rotation, u, v);
+    u = clampf(u, 0.0f, 0.99999994f);
+    v = clampf(v, 0.0f, 0.99999994f);
+    const uint32_t x = min(static_cast<uint32_t>(u * static_cast<float>(sc.envWidth)), sc.envWidth - 1u);
+    const uint32_t y = min(static_cast<uint32_t>(v * static_cast<float>(sc.envHeight)), sc.envHeight - 1u);
+    const float value = sc.envPdf[static_cast<size_t>(y) * sc.envWidth + x];
+    return (isfinite(value) && value > 0.0f) ? value : 0.0f;
+}
+
+__device__ __forceinline__ void envSample(const SceneView& sc, float uM, float uC, float uJ, float rotation, f3& dir, float& pdf) {
+    uM = clampf(uM, 0.0f, 0.99999994f);
+    uC = clampf(uC, 0.0f, 0.99999994f);
+    uJ = clampf(uJ, 0.0f, 0.99999994f);
+    const float rowChoice = uM * static_cast<float>(sc.envHeight);
+    uint32_t row = min(static_cast<uint32_t>(rowChoice), sc.envHeight - 1u);
+    const float2 me = sc.envMarg[row];
+    if (rowChoice - static_cast<float>(row) >= me.x) row = min(__float_as_uint(me.y), sc.envHeight - 1u);
+    const float colChoice = uC * static_cast<float>(sc.envWidth);
+    uint32_t col = min(static_cast<uint32_t>(colChoice), sc.envWidth - 1u);
+    const size_t rowOff = static_cast<size_t>(row) * sc.envWidth;
+    const float2 ce = sc.envCond[rowOff + col];
+    if (colChoice - static_cast<float>(col) >= ce.x) col = min(__float_as_uint(ce.y), sc.envWidth - 1u);
+    const float jitterX = uC - floorf(uC);
+    const float fx = (static_cast<float>(col) + jitterX) / static_cast<float>(sc.envWidth);
+    const float fy = (static_cast<float>(row) + uJ) / static_cast<float>(sc.envHeight);
+    const float theta = fy * kPi;
+    const float phi = fx * (2.0f * kPi);
+    const float st = sinf(theta), ct = cosf(theta);
+    const f3 m = mk3(st * cosf(phi), ct, st * sinf(phi));
+    const float cr = cosf(rotation), sr = sinf(rotation);
+    dir = mk3(m.x * cr + m.z * sr, m.y, -m.x * sr + m.z * cr);
+    pdf = sc.envPdf[rowOff + col];
+}
+
+// ---------------------------------------------------------------- surface reconstruction
+struct Surface {
+    f3 position, normal, hitShadingNormal;   // HitInfo fields of the oracle
+    float t;
+    uint32_t material;
+    uint32_t primType;    // 0 mesh, 1 sphere, 2 rectangle
+    uint32_t primIndex;   // rectangle index for primType 2
+    bool frontFace, twoSided;
+};
+
+__device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 dir, float t, float u, float v, uint32_t prim) {
+    Surface s;
+    s.t = t;
+    s.position = org + t * dir;
+    s.normal = mk3(0.0f, 1.0f, 0.0f);
+    s.twoSided = false;
+    if (prim & kHitSphereBit) {
+        const uint32_t idx = prim & ~kHitSphereBit;
+        const float4 sp = sc.spheres[idx];
+        const uint2 info = sc.sphereInfo[idx];
+        const f3 n = normalize(s.position - mk3(sp));
+        s.normal = n;
+        s.hitShadingNormal = n;
+        s.frontFace = dot(dir, n) < 0.0f;
+        s.twoSided = true;
+        s.primType = 1u;
+        s.primIndex = info.x;
+        s.material = info.y;
+        return s;
+    }
+    const float4* tp = sc.tris + static_cast<size_t>(prim) * 3u;
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    const f3 ng = cross(mk3(c), mk3(b));
+    if (dot(ng, ng) > 0.0f) s.normal = normalize(ng);
+    s.frontFace = dot(dir, s.normal) < 0.0f;
+    const f3 adjusted = s.frontFace ? s.normal : -s.normal;
+    f3 shading = adjusted;
+    const uint32_t meta = __float_as_uint(b.w);
+    s.material = __float_as_uint(a.w);
+    const float4* np = sc.triNormals + static_cast<size_t>(prim) * 3u;
+    if ((meta >> 30) == 0u) {
+        s.primType = 0u;
+        s.primIndex = __float_as_uint(c.w);
+        const float w = 1.0f - u - v;
+        const f3 interp = (w * mk3(np[0]) + u * mk3(np[1])) + v * mk3(np[2]);
+        if (dot(interp, interp) > 0.0f) {
+            shading = normalize(interp);
+            if (dot(shading, adjusted) < 0.0f) shading = -shading;
+        }
+    } else {
+        s.primType = 2u;
+        s.primIndex = meta & 0x3FFFFFFFu;
+        shading = mk3(np[0]);
+        if (dot(shading, adjusted) < 0.0f) shading = -shading;
+        s.twoSided = __float_as_uint(sc.rects[static_cast<size_t>(s.primIndex) * 5u + 4u].y) != 0u;
+    }
+    s.hitShadingNormal = shading;
+    return s;
+}
+
+// Next-ray origin: pushed off the surface along the (hit record's) shading normal, to the side the
+// direction leaves on, plus half an epsilon along the direction.
+__device__ __forceinline__ f3 offsetOrigin(const Surface& s, f3 direction) {
+    f3 n = s.hitShadingNormal;
+    if (dot(n, n) <= 0.0f) n = s.normal;
+    if (dot(n, n) <= 0.0f) n = mk3(0.0f, 1.0f, 0.0f);
+    n = normalize(n);
+    const float sign = dot(direction, n) >= 0.0f ? 1.0f : -1.0f;
+    const float distance = smax(fabsf(s.t) * 1.0e-4f, kEps);
+    f3 o = s.position + n * (sign * distance);
+    o += (direction * kEps) * 0.5f;
+    return o;
+}
+
+// pdf (solid angle, incl. 1/N light pick) of hitting rectangle `rectIndex` at `position` from `origin`
+__device__ __forceinline__ float rectLightPdfForHit(const SceneView& sc, uint32_t primType, uint32_t rectIndex, f3 position, f3 origin) {
+    if (sc.rectLightCount == 0u || sc.rectCount == 0u) return 0.0f;
+    if (primType != 2u || rectIndex >= sc.rectCount) return 0.0f;
+    if (sc.lightIndexByRect[rectIndex] < 0) return 0.0f;
+    const float4* r = sc.rects + static_cast<size_t>(rectIndex) * 5u;
+    const float area = length(cross(mk3(r[1]), mk3(r[2])));
+    if (area <= 0.0f) return 0.0f;
+    const f3 toLight = position - origin;
+    const float distSq = dot(toLight, toLight);
+    if (distSq <= 0.0f) return 0.0f;
+    const float distance = sqrtf(distSq);
+    const f3 direction = toLight / distance;
+    float cosLight = dot(-direction, mk3(r[3]));
+    if (__float_as_uint(r[4].y) != 0u) {
+        cosLight = fabsf(cosLight);
+    } else if (cosLight <= 0.0f) {
+        return 0.0f;
+    }
+    if (cosLight <= 0.0f) return 0.0f;
+    const float pdfArea = 1.0f / area;
+    const float pdfDir = pdfArea * distSq / smax(cosLight, 1.0e-6f);
+    return pdfDir * (1.0f / static_cast<float>(sc.rectLightCount));
+}
+
+// Emission + pdf of a rectangle light reached by a specular-chain ray (mnee_rect_light_hit twin).
+__device__ __forceinline__ bool rectLightHit(const SceneView& sc, const Surface& s, f3 origin, float emissionScale, f3& emission, float& pdf) {
+    if (sc.rectLightCount == 0u || sc.rectCount == 0u) return false;
+    if (s.primType != 2u || s.primIndex >= sc.rectCount) return false;
+    const int32_t li = sc.lightIndexByRect[s.primIndex];
+    if (li < 0) return false;
+    const float4* L = sc.rectLights + static_cast<size_t>(li) * 5u;
+    const bool twoSided = L[1].w != 0.0f;
+    if (!s.frontFace && !twoSided) return false;
+    emission = mk3(L[4]) * emissionScale;
+    if (!(dot(emission, emission) > 0.0f)) return false;
+    pdf = rectLightPdfForHit(sc, s.primType, s.primIndex, s.position, origin);
+    return (pdf > 0.0f) && isfinite(pdf);
+}
+
+struct PendingRay {
+    f3 org, dir;
+    float tmax;
+};
+
+__device__ __forceinline__ void storeRecord(const PathPool& pool, uint32_t slot, uint32_t which, uint32_t kind, f3 org, float tmaxOrBits,
+                                            f3 dir, f3 a, float aw, f3 b) {
+    const ShadowRecordView& r = pool.rec[which];
+    r.org[slot] = mk4(org, tmaxOrBits);
+    r.dir[slot] = mk4(dir, __uint_as_float(kind));
+    r.a[slot] = mk4(a, aw);
+    if (kind != 0u) r.b[slot] = mk4(b, 0.0f);
+}
+
+}  // namespace
+
+// =====================================================================================================
+// k_generate: first sample of every slot
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_generate(RenderParams rp, PathPool pool) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= pool.slots) return;
+    const uint32_t lp = slot % rp.localPixels;
+    const uint32_t j = slot / rp.localPixels;
+    uint4 st = make_uint4(0u, j, 0u, 0u);
+    pool.accum[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (j < rp.spp && rp.maxDepth > 0u) {
+        uint32_t rng;
+        f3 o, d;
+        beginSample(rp, pool.pixelOfLocal[lp], j, rng, o, d);
+        st.x = rng;
+        st.z = kFlagAlive | kFlagLastDelta;
+        pool.rayOrg[slot] = mk4(o, 0.0f);
+        pool.rayDir[slot] = mk4(d, 0.0f);
+        pool.throughput[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    }
+    pool.state[slot] = st;
+}
+
+// =====================================================================================================
+// k_extend: closest hit for every live slot
+// =====================================================================================================
+template <bool COUNT>
+__global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride) {
+    __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
+    const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
+    LaneStack stack;
+    stack.lds = ldsStack + threadIdx.x;
+    stack.spill = spill + gtid;
+    stack.spillStride = spillStride;
+    TraceCounters cnt{0u, 0u};
+    uint32_t rays = 0u;
+    for (uint32_t slot = gtid; slot < pool.slots; slot += gridDim.x * kTraceBlock) {
+        if (!(pool.state[slot].z & kFlagAlive)) continue;
+        const f3 o = mk3(pool.rayOrg[slot]);
+        const f3 d = mk3(pool.rayDir[slot]);
+        const TraceHit h = traverse<false, COUNT>(sc, o, d, kEps, INFINITY, stack, cnt);
+        pool.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+        if (COUNT) ++rays;
+    }
+    if (COUNT) {
+        addCounter(pool.counters, kCntExtendRays, rays);
+        addCounter(pool.counters, kCntExtendNodes, cnt.nodes);
+        addCounter(pool.counters, kCntExtendPrims, cnt.prims);
+    }
+}
+
+// =====================================================================================================
+// k_shade
+// =====================================================================================================
+template <bool COUNT>
+__global__ void __launch_bounds__(kShadeBlock) k_shade(RenderParams rp, SceneView sc, PathPool pool, uint32_t* aliveSlot) {
+    const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x;
+    const bool inRange = slot < pool.slots;
+    uint4 st = inRange ? pool.state[slot] : make_uint4(0u, 0u, 0u, 0u);
+    const bool active = inRange && (st.z & kFlagAlive);
+    const bool touched = inRange && (active || st.w != 0u);   // state/accum will be rewritten
+
+    bool want[kRecSlots] = {false, false, false, false, false};
+    bool stillAlive = false;
+    uint32_t shadedHit = 0u, triHit = 0u, primary = 0u;
+
+    if (touched) {
+        const ClampCfg cc = clampCfg(rp);
+        f3 acc = mk3(pool.accum[slot]);
+        // light connections queued last bounce have been resolved by k_connect: add them in slot order
+#pragma unroll
+        for (uint32_t k = 0; k < kRecSlots; ++k) {
+            if (st.w & (1u << k)) acc += mk3(pool.rec[k].a[slot]);
+        }
+        st.w = 0u;
+
+        if (active) {
+            const uint32_t lp = slot % rp.localPixels;
+            uint32_t rng = st.x;
+            uint32_t depth = (st.z >> kFlagDepthShift) & kFlagFieldMask;
+            uint32_t specDepth = (st.z >> kFlagSpecDepthShift) & kFlagFieldMask;
+            bool lastDelta = (st.z & kFlagLastDelta) != 0u;
+            const f3 rayO = mk3(pool.rayOrg[slot]);
+            const f3 rayD = mk3(pool.rayDir[slot]);
+            const float4 hitv = pool.hit[slot];
+            const float4 thr4 = pool.throughput[slot];
+            f3 thr = mk3(thr4);
+            float lastPdf = thr4.w;
+            const uint32_t prim = __float_as_uint(hitv.w);
+            if (COUNT && depth == 0u) primary = 1u;
+
+            bool endPath = false;
+            f3 nextO = rayO, nextD = rayD;
+
+            if (prim == kHitMiss) {
+                // ---- escaped: background, MIS-weighted against environment sampling ----
+                f3 bg;
+                if (rp.backgroundMode == PTR_BG_SOLID) {
+                    bg = ld3(rp.backgroundColor);
+                } else if (rp.backgroundMode == PTR_BG_ENVIRONMENT && sc.envWidth > 0u) {
+                    bg = envLookup(sc, rayD, rp.envRotation, rp.envIntensity);
+                } else {
+                    bg = skyColor(rayD);
+                }
+                float mis = 1.0f;
+                const bool useMis = (!lastDelta) || rp.enableSpecularNee || rp.enableMnee;
+                if (useMis && sc.envSampling) {
+                    const float lightPdf = envPdfOf(sc, rayD, rp.envRotation);
+                    const float denom = lastPdf + lightPdf;
+                    if (denom > 0.0f) mis = lastPdf / denom;
+                    mis = clampf(mis, kMisMin, kMisMax);
+                }
+                acc += clampFirefly(thr, bg * mis, cc);
+                endPath = true;
+            } else if (sc.materialCount == 0u) {
+                endPath = true;
+            } else {
+                const Surface sf = reconstruct(sc, rayO, rayD, hitv.x, hitv.y, hitv.z, prim);
+                if (COUNT) {
+                    shadedHit = 1u;
+                    triHit = sf.primType == 0u ? 1u : 0u;
+                }
+                const Mat mat{sc.materials + static_cast<size_t>(min(sf.material, sc.materialCount - 1u)) * kMaterialVec4};
+                const uint32_t type = mat.type();
+                const f3 incident = normalize(rayD);
+                const f3 wo = -incident;
+                f3 n = sf.hitShadingNormal;
+                if (dot(n, n) <= 0.0f) n = sf.normal;
+                if (type == 2u) n = sf.normal;      // dielectrics shade with the geometric normal
+                n = normalize(n);
+
+                if (type == 3u) {
+                    // ---- emitter reached by a BSDF-sampled ray ----
+                    const float4 em = mat.v(kMatEmission);
+                    f3 emission = mk3(em) * rp.emissionScale;
+                    if (em.w > 0.0f && sc.envWidth > 0u && sf.frontFace) {
+                        emission *= envLookup(sc, -n, rp.envRotation, rp.envIntensity);
+                    }
+                    if ((dot(emission, emission) > 0.0f) && (sf.frontFace || sf.twoSided)) {
+                        float mis = 1.0f;
+                        const bool useMis = (!lastDelta) || rp.enableSpecularNee || rp.enableMnee;
+                        if (useMis && sc.rectLightCount > 0u) {
+                            const float lightPdf = rectLightPdfForHit(sc, sf.primType, sf.primIndex, sf.position, rayO);
+                            const float denom = lastPdf + lightPdf;
+                            if (denom > 0.0f) mis = lastPdf / denom;
+                            mis = clampf(mis, kMisMin, kMisMax);
+                        }
+                        acc += clampFirefly(thr, emission * mis, cc);
+                    }
+                    endPath = true;
+                } else {
+                    const bool surfaceDelta = materialIsDelta(mat);
+
+                    // ---- rectangle-light NEE (3 random numbers, drawn even if the sample is rejected) ----
+                    if (!surfaceDelta && sc.rectLightCount > 0u) {
+                        const uint32_t nL = sc.rectLightCount;
+                        const uint32_t sel = min(static_cast<uint32_t>(rngNext(rng) * static_cast<float>(nL)), nL - 1u);
+                        const float lu = rngNext(rng);
+                        const float lv = rngNext(rng);
+                        const float4* L = sc.rectLights + static_cast<size_t>(sel) * 5u;
+                        const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3];
+                        const f3 samplePoint = (mk3(l0) + lu * mk3(l1)) + lv * mk3(l2);
+                        const f3 toLight = samplePoint - sf.position;
+                        const float distSq = dot(toLight, toLight);
+                        if (distSq > 0.0f && l0.w > 0.0f) {
+                            const float distance = sqrtf(distSq);
+                            const f3 ldir = toLight / distance;
+                            float cosLight = dot(-ldir, mk3(l3));
+                            if (l1.w != 0.0f) cosLight = fabsf(cosLight);
+                            if (cosLight > 0.0f) {
+                                const float pdfArea = 1.0f / l0.w;
+                                const float pdfDir = pdfArea * distSq / smax(cosLight, 1.0e-6f);
+                                const float pdf = pdfDir * (1.0f / static_cast<float>(nL));
+                                const f3 emission = mk3(L[4]) * rp.emissionScale;
+                                const float nDotL = smax(dot(n, ldir), 0.0f);
+                                if (pdf > 0.0f && isfinite(pdf) && (dot(emission, emission) > 0.0f) && nDotL > 0.0f) {
+                                    const BsdfEvalResult be = evalBsdf(mat, sf.position, n, wo, ldir, cc);
+                                    if (!be.isDelta && be.pdf > 0.0f) {
+                                        const float w = pdf / (pdf + be.pdf);   // balance heuristic, unclamped
+                                        f3 contrib = (emission * be.value) * nDotL;
+                                        contrib *= w / pdf;
+                                        if (finite3(contrib)) {
+                                            const f3 clamped = clampFirefly(thr, contrib, cc);
+                                            if (clamped.x > 0.0f || clamped.y > 0.0f || clamped.z > 0.0f) {
+                                                // tfar is measured from the un-offset hit point (reference quirk Q9)
+                                                const float shadowMax = smax(distance - kEps, kEps);
+                                                storeRecord(pool, slot, 0u, 0u, offsetOrigin(sf, ldir), shadowMax, ldir, clamped, 0.0f, mk3(0.0f));
+                                                want[0] = true;
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+
+                    // ---- environment NEE (3 random numbers: marginal, conditional, jitter) ----
+                    if (!surfaceDelta && sc.envSampling) {
+                        const float uM = rngNext(rng);
+                        const float uC = rngNext(rng);
+                        const float uJ = rngNext(rng);
+                        f3 edir;
+                        float epdf;
+                        envSample(sc, uM, uC, uJ, rp.envRotation, edir, epdf);
+                        const float nDotL = smax(dot(n, edir), 0.0f);
+                        if (epdf > 0.0f && nDotL > 0.0f) {
+                            const f3 envRadiance = envLookup(sc, edir, rp.envRotation, rp.envIntensity);
+                            const BsdfEvalResult be = evalBsdf(mat, sf.position, n, wo, edir, cc);
+                            if (!be.isDelta && be.pdf > 0.0f) {
+                                const float w = epdf / (epdf + be.pdf);
+                                f3 contrib = (envRadiance * be.value) * nDotL;
+                                contrib *= w / epdf;
+                                if (finite3(contrib)) {
+                                    const f3 clamped = clampFirefly(thr, contrib, cc);
+                                    if (clamped.x > 0.0f || clamped.y > 0.0f || clamped.z > 0.0f) {
+                                        storeRecord(pool, slot, 1u, 0u, offsetOrigin(sf, edir), INFINITY, edir, clamped, 0.0f, mk3(0.0f));
+                                        want[1] = true;
+                                    }
+                                }
+                            }
+                        }
+                    }
+
+                    // ---- continue the path ----
+                    const BsdfSampleResult bs = sampleBsdf(mat, sf.position, n, wo, incident, sf.frontFace, rng, cc);
+                    if (bs.pdf <= 0.0f || dot(bs.dir, bs.dir) <= 0.0f || !finite3(bs.weight)) {
+                        endPath = true;
+                    } else {
+                        const uint32_t nextSpecDepth = bs.isDelta ? (specDepth + 1u) : 0u;
+                        specDepth = nextSpecDepth;
+                        const bool dirValid = finite3(bs.dir);
+                        const bool mneeEligible = rp.enableMnee && bs.isDelta && dirValid && type == 2u && nextSpecDepth == 1u;
+                        const bool specNeeEligible = rp.enableSpecularNee && bs.isDelta && dirValid && !mneeEligible;
+
+                        if (specNeeEligible || mneeEligible) {
+                            // light reached straight along the specular direction
+                            const f3 sdir = normalize(bs.dir);
+                            const f3 sorg = offsetOrigin(sf, sdir);
+                            if (sc.envSampling) {
+                                const float envPdf = smax(envPdfOf(sc, sdir, rp.envRotation), kSpecNeePdfFloor);
+                                const float invEnvPdf = smin(1.0f / envPdf, kSpecNeeInvPdfClamp);
+                                const float bsdfPdf = smax(bs.pdf, kSpecNeePdfFloor);
+                                const float denom = envPdf + bsdfPdf;
+                                float mis = denom > 0.0f ? (envPdf / denom) : 0.0f;
+                                mis = clampf(mis, kMisMin, kMisMax);
+                                const f3 envColor = envLookup(sc, sdir, rp.envRotation, rp.envIntensity);
+                                const f3 contrib = (bs.weight * envColor) * (mis * invEnvPdf);
+                                if (finite3(contrib)) {
+                                    const f3 clamped = clampFirefly(thr, contrib, cc);
+                                    if (clamped.x > 0.0f || clamped.y > 0.0f || clamped.z > 0.0f) {
+                                        storeRecord(pool, slot, 2u, 0u, sorg, INFINITY, sdir, clamped, 0.0f, mk3(0.0f));
+                                        want[2] = true;
+                                    }
+                                }
+                            }
+                            if (sc.rectLightCount > 0u) {
+                                storeRecord(pool, slot, 3u, 1u, sorg, INFINITY, sdir, bs.weight, bs.pdf, thr);
+                                want[3] = true;
+                            }
+                        }
+                        if (mneeEligible && rp.enableMneeSecondary) {
+                            const f3 sdir = normalize(bs.dir);
+                            storeRecord(pool, slot, 4u, 2u, offsetOrigin(sf, sdir), __uint_as_float(rng), sdir, bs.weight, bs.pdf, thr);
+                            want[4] = true;
+                        }
+
+                        thr *= bs.weight;
+                        thr = clampThroughput(thr, cc);
+                        const float maxComp = smax(smax(thr.x, thr.y), thr.z);
+                        if (!finite3(thr) || maxComp <= 0.0f) {
+                            endPath = true;
+                        } else {
+                            lastPdf = bs.pdf > 0.0f ? bs.pdf : lastPdf;
+                            lastDelta = bs.isDelta;
+                            nextO = offsetOrigin(sf, bs.dir);
+                            nextD = bs.dir;
+                            if (rp.enableRussianRoulette && depth >= 5u) {
+                                const float p = clampf(maxComp, 0.05f, 0.95f);
+                                if (rngNext(rng) > p) {
+                                    endPath = true;
+                                } else {
+                                    thr /= p;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+
+            ++depth;
+            if (depth >= rp.maxDepth) endPath = true;
+
+            if (endPath) {
+                // this slot's next sample of the same pixel
+                const uint32_t s = st.y + rp.samplesInFlight;
+                st.y = s;
+                if (s < rp.spp) {
+                    beginSample(rp, pool.pixelOfLocal[lp], s, rng, nextO, nextD);
+                    thr = mk3(1.0f);
+                    lastPdf = 1.0f;
+                    lastDelta = true;
+                    depth = 0u;
+                    specDepth = 0u;
+                    stillAlive = true;
+                }
+            } else {
+                stillAlive = true;
+            }
+
+            st.x = rng;
+            st.z = (stillAlive ? kFlagAlive : 0u) | (lastDelta ? kFlagLastDelta : 0u) | (depth << kFlagDepthShift) |
+                   (specDepth << kFlagSpecDepthShift);
+            if (stillAlive) {
+                pool.rayOrg[slot] = mk4(nextO, 0.0f);
+                pool.rayDir[slot] = mk4(nextD, 0.0f);
+                pool.throughput[slot] = mk4(thr, lastPdf);
+            }
+        }
+        pool.accum[slot] = mk4(acc, 0.0f);
+    }
+
+    // ---- enqueue this bounce's light connections (one atomic per wave and record slot) ----
+    uint32_t pendingMask = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < kRecSlots; ++k) {
+        const uint32_t idx = waveAppend(pool.shadowCount, want[k]);
+        if (want[k]) {
+            pool.shadowQueue[idx] = slot * kRecSlots + k;
+            pendingMask |= 1u << k;
+        }
+    }
+    if (touched) {
+        st.w = pendingMask;
+        pool.state[slot] = st;
+    }
+    const uint32_t aliveInWave = static_cast<uint32_t>(__popcll(__ballot(stillAlive)));
+    if (laneId() == 0 && aliveInWave != 0u) atomicAdd(aliveSlot, aliveInWave);
+    if (COUNT) {
+        addCounter(pool.counters, kCntShadedHits, shadedHit);
+        addCounter(pool.counters, kCntTriangleHits, triHit);
+        addCounter(pool.counters, kCntPrimaryRays, primary);
+    }
+}
+
+// =====================================================================================================
+// k_connect: resolve queued light connections
+// =====================================================================================================
+namespace {
+
+template <bool COUNT>
+__device__ __forceinline__ f3 alongRect(const RenderParams& rp, const SceneView& sc, const ClampCfg& cc, f3 org, f3 dir, f3 weight,
+                                        float bsdfPdfIn, f3 thr, LaneStack& stack, TraceCounters& cnt) {
+    const TraceHit h = traverse<false, COUNT>(sc, org, dir, kEps, INFINITY, stack, cnt);
+    if (h.prim == kHitMiss) return mk3(0.0f);
+    const Surface ls = reconstruct(sc, org, dir, h.t, h.u, h.v, h.prim);
+    f3 emission;
+    float pdf;
+    if (!rectLightHit(sc, ls, org, rp.emissionScale, emission, pdf)) return mk3(0.0f);
+    const float lightPdf = smax(pdf, kSpecNeePdfFloor);
+    const float invLightPdf = smin(1.0f / lightPdf, kSpecNeeInvPdfClamp);
+    const float bsdfPdf = smax(bsdfPdfIn, kSpecNeePdfFloor);
+    const float denom = lightPdf + bsdfPdf;
+    float mis = denom > 0.0f ? (lightPdf / denom) : 0.0f;
+    mis = clampf(mis, kMisMin, kMisMax);
+    const f3 contrib = (weight * emission) * (mis * invLightPdf);
+    return finite3(contrib) ? clampFirefly(thr, contrib, cc) : mk3(0.0f);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ f3 alongEnv(const RenderParams& rp, const SceneView& sc, const ClampCfg& cc, f3 org, f3 dir, f3 weight,
+                                       float bsdfPdfIn, f3 thr, LaneStack& stack, TraceCounters& cnt) {
+    const TraceHit h = traverse<true, COUNT>(sc, org, dir, kEps, INFINITY, stack, cnt);
+    if (h.prim != kHitMiss) return mk3(0.0f);
+    const float envPdf = smax(envPdfOf(sc, dir, rp.envRotation), kSpecNeePdfFloor);
+    const float invEnvPdf = smin(1.0f / envPdf, kSpecNeeInvPdfClamp);
+    const float bsdfPdf = smax(bsdfPdfIn, kSpecNeePdfFloor);
+    const float denom = envPdf + bsdfPdf;
+    float mis = denom > 0.0f ? (envPdf / denom) : 0.0f;
+    mis = clampf(mis, kMisMin, kMisMax);
+    const f3 envColor = envLookup(sc, dir, rp.envRotation, rp.envIntensity);
+    const f3 contrib = (weight * envColor) * (mis * invEnvPdf);
+    return finite3(contrib) ? clampFirefly(thr, contrib, cc) : mk3(0.0f);
+}
+
+}  // namespace
+
+template <bool COUNT>
+__global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride) {
+    __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
+    const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
+    LaneStack stack;
+    stack.lds = ldsStack + threadIdx.x;
+    stack.spill = spill + gtid;
+    stack.spillStride = spillStride;
+    TraceCounters cnt{0u, 0u}, cntClosest{0u, 0u};
+    uint32_t rays = 0u, raysClosest = 0u, early = 0u;
+    const uint32_t total = *pool.shadowCount;
+    const ClampCfg cc = clampCfg(rp);
+    for (uint32_t q = gtid; q < total; q += gridDim.x * kTraceBlock) {
+        const uint32_t entry = pool.shadowQueue[q];
+        const uint32_t slot = entry / kRecSlots, which = entry % kRecSlots;
+        const ShadowRecordView& r = pool.rec[which];
+        const float4 o4 = r.org[slot], d4 = r.dir[slot];
+        const f3 org = mk3(o4), dir = mk3(d4);
+        const uint32_t kind = __float_as_uint(d4.w);
+        if (kind == 0u) {
+            const TraceHit h = traverse<true, COUNT>(sc, org, dir, kEps, o4.w, stack, cnt);
+            if (COUNT) { ++rays; early += (h.prim != kHitMiss) ? 1u : 0u; }
+            if (h.prim != kHitMiss) r.a[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        } else if (kind == 1u) {
+            const float4 a4 = r.a[slot];
+            const f3 thr = mk3(r.b[slot]);
+            if (COUNT) ++raysClosest;
+            const f3 c = alongRect<COUNT>(rp, sc, cc, org, dir, mk3(a4), a4.w, thr, stack, cntClosest);
+            r.a[slot] = mk4(c, 0.0f);
+        } else {
+            // MNEE second bounce: follow the refracted ray to the next delta surface, scatter with a copy of
+            // the rng, then look for the environment / a rectangle light along the second specular direction
+            const float4 a4 = r.a[slot];
+            const f3 thr = mk3(r.b[slot]);
+            f3 result = mk3(0.0f);
+            if (COUNT) ++raysClosest;
+            const TraceHit h = traverse<false, COUNT>(sc, org, dir, kEps, INFINITY, stack, cntClosest);
+            if (h.prim != kHitMiss && sc.materialCount > 0u) {
+                const Surface cs = reconstruct(sc, org, dir, h.t, h.u, h.v, h.prim);
+                f3 tmpE;
+                float tmpP;
+                const bool isLight = sc.rectLightCount > 0u && rectLightHit(sc, cs, org, rp.emissionScale, tmpE, tmpP);
+                if (!isLight) {
+                    const Mat cm{sc.materials + static_cast<size_t>(min(cs.material, sc.materialCount - 1u)) * kMaterialVec4};
+                    if (materialIsDelta(cm)) {
+                        f3 cn = cs.normal;
+                        if (dot(cn, cn) <= 0.0f) cn = mk3(0.0f, 1.0f, 0.0f);
+                        cn = normalize(cn);
+                        const f3 cin = normalize(dir);
+                        uint32_t chainRng = __float_as_uint(o4.w);
+                        const BsdfSampleResult s2 = sampleBsdf(cm, cs.position, cn, -cin, cin, cs.frontFace, chainRng, cc);
+                        if (s2.pdf > 0.0f && s2.isDelta && dot(s2.dir, s2.dir) > 0.0f && finite3(s2.weight)) {
+                            const f3 d2 = normalize(s2.dir);
+                            const f3 o2 = offsetOrigin(cs, d2);
+                            const f3 w2 = mk3(a4) * s2.weight;
+                            const float pdf2 = a4.w * s2.pdf;
+                            if (sc.envSampling) {
+                                if (COUNT) ++rays;
+                                result += alongEnv<COUNT>(rp, sc, cc, o2, d2, w2, pdf2, thr, stack, cnt);
+                            }
+                            if (sc.rectLightCount > 0u) {
+                                if (COUNT) ++raysClosest;
+                                result += alongRect<COUNT>(rp, sc, cc, o2, d2, w2, pdf2, thr, stack, cntClosest);
+                            }
+                        }
+                    }
+                }
+            }
+            r.a[slot] = mk4(result, 0.0f);
+        }
+    }
+    if (COUNT) {
+        addCounter(pool.counters, kCntShadowRays, rays);
+        addCounter(pool.counters, kCntShadowNodes, cnt.nodes);
+        addCounter(pool.counters, kCntShadowPrims, cnt.prims);
+        addCounter(pool.counters, kCntShadowEarlyExit, early);
+        addCounter(pool.counters, kCntExtendRays, raysClosest);
+        addCounter(pool.counters, kCntExtendNodes, cntClosest.nodes);
+        addCounter(pool.counters, kCntExtendPrims, cntClosest.prims);
+    }
+}
+
+// =====================================================================================================
+// k_resolve: fixed-order per-pixel reduction
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_resolve(RenderParams rp, PathPool pool, uint32_t partCount, float* out) {
+    const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lp >= rp.localPixels) return;
+    f3 sum = mk3(0.0f);
+    for (uint32_t j = 0; j < rp.samplesInFlight; ++j) {
+        const uint32_t slot = j * rp.localPixels + lp;
+        f3 acc = mk3(pool.accum[slot]);
+        const uint32_t pending = pool.state[slot].w;
+        for (uint32_t k = 0; k < kRecSlots; ++k) {
+            if (pending & (1u << k)) acc += mk3(pool.rec[k].a[slot]);
+        }
+        sum += acc;
+    }
+    const f3 avg = sum / static_cast<float>(rp.spp);
+    const uint32_t pixel = pool.pixelOfLocal[lp];
+    const uint32_t x = pixel % rp.width, y = pixel / rp.width;
+    const uint32_t localBand = (y / 16u) / partCount;
+    float* o = out + (static_cast<size_t>(localBand * 16u + (y % 16u)) * rp.width + x) * 3u;
+    o[0] = avg.x;
+    o[1] = avg.y;
+    o[2] = avg.z;
+}
+
+// =====================================================================================================
+// k_trace_rays: ray-batch queries for ptr_trace_rays (parity tests against the oracle ray caster)
+// =====================================================================================================
+template <bool ANY>
+__global__ void __launch_bounds__(kTraceBlock) k_trace_rays(SceneView sc, const float4* rays, uint64_t n, PtrHit* out, uint32_t* spill,
+                                                             uint32_t spillStride, uint64_t* counters) {
+    __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
+    const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
+    LaneStack stack;
+    stack.lds = ldsStack + threadIdx.x;
+    stack.spill = spill + gtid;
+    stack.spillStride = spillStride;
+    TraceCounters cnt{0u, 0u};
+    for (uint64_t i = gtid; i < n; i += static_cast<uint64_t>(gridDim.x) * kTraceBlock) {
+        const float4 a = rays[i * 2u], b = rays[i * 2u + 1u];
+        const f3 org = mk3(a), dir = mk3(b);
+        const TraceHit h = traverse<ANY, true>(sc, org, dir, a.w, b.w, stack, cnt);
+        PtrHit r;
+        r.t = -1.0f;
+        r.u = 0.0f;
+        r.v = 0.0f;
+        r.primType = 0u;
+        r.geomIndex = 0u;
+        r.primIndex = 0u;
+        r.ng[0] = r.ng[1] = r.ng[2] = 0.0f;
+        r.pad = 0u;
+        if (h.prim != kHitMiss) {
+            r.t = ANY ? 0.0f : h.t;
+            if (!ANY) {
+                r.u = h.u;
+                r.v = h.v;
+                if (h.prim & kHitSphereBit) {
+                    r.primType = 1u;
+                    r.primIndex = sc.sphereInfo[h.prim & ~kHitSphereBit].x;
+                } else {
+                    const float4* tp = sc.tris + static_cast<size_t>(h.prim) * 3u;
+                    const float4 t1 = tp[1], t2 = tp[2];
+                    const uint32_t meta = __float_as_uint(t1.w);
+                    const f3 ng = cross(mk3(t2), mk3(t1));
+                    r.ng[0] = ng.x;
+                    r.ng[1] = ng.y;
+                    r.ng[2] = ng.z;
+                    if ((meta >> 30) == 0u) {
+                        r.primType = 0u;
+                        r.geomIndex = meta & 0x3FFFFFFFu;
+                        r.primIndex = __float_as_uint(t2.w);
+                    } else {
+                        r.primType = 2u;
+                        r.primIndex = meta & 0x3FFFFFFFu;
+                    }
+                }
+            }
+        }
+        out[i] = r;
+    }
+    if (counters) {
+        addCounter(counters, ANY ? kCntShadowNodes : kCntExtendNodes, cnt.nodes);
+        addCounter(counters, ANY ? kCntShadowPrims : kCntExtendPrims, cnt.prims);
+    }
+}
+
+// =====================================================================================================
+// debug kernels (known-answer tests of device functions)
+// =====================================================================================================
+__global__ void k_debug_eval(const float4* material, RenderParams rp, const float* in, uint64_t n, float* out) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = in + i * 12u;
+    const Mat m{material};
+    const BsdfEvalResult e = evalBsdf(m, ld3(p), ld3(p + 3), ld3(p + 6), ld3(p + 9), clampCfg(rp));
+    float* o = out + i * 5u;
+    o[0] = e.value.x; o[1] = e.value.y; o[2] = e.value.z; o[3] = e.pdf; o[4] = e.isDelta ? 1.0f : 0.0f;
+}
+
+__global__ void k_debug_sample(const float4* material, RenderParams rp, const float* in, const uint32_t* front, const uint32_t* rngIn,
+                               uint64_t n, float* out, uint32_t* rngOut) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = in + i * 9u;
+    const Mat m{material};
+    uint32_t rng = rngIn[i];
+    const f3 wo = ld3(p + 6);
+    const BsdfSampleResult s = sampleBsdf(m, ld3(p), ld3(p + 3), wo, -wo, front[i] != 0u, rng, clampCfg(rp));
+    float* o = out + i * 8u;
+    o[0] = s.dir.x; o[1] = s.dir.y; o[2] = s.dir.z;
+    o[3] = s.weight.x; o[4] = s.weight.y; o[5] = s.weight.z;
+    o[6] = s.pdf; o[7] = s.isDelta ? 1.0f : 0.0f;
+    rngOut[i] = rng;
+}
+
+__global__ void k_debug_camera(RenderParams rp, const uint32_t* xys, uint64_t n, float* out, uint32_t* rngOut) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t x = xys[i * 3u], y = xys[i * 3u + 1u], s = xys[i * 3u + 2u];
+    uint32_t rng;
+    f3 o, d;
+    beginSample(rp, y * rp.width + x, s, rng, o, d);
+    float* q = out + i * 6u;
+    q[0] = o.x; q[1] = o.y; q[2] = o.z; q[3] = d.x; q[4] = d.y; q[5] = d.z;
+    rngOut[i] = rng;
+}
+
+// =====================================================================================================
+// launchers
+// =====================================================================================================
+static inline uint32_t ceilDiv(uint64_t a, uint32_t b) { return static_cast<uint32_t>((a + b - 1) / b); }
+
+void launchGenerate(const RenderParams& rp, const PathPool& pool, hipStream_t stream) {
+    hipLaunchKernelGGL(k_generate, dim3(ceilDiv(pool.slots, 256)), dim3(256), 0, stream, rp, pool);
+}
+
+void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count, hipStream_t stream) {
+    const uint32_t stride = cfg.traceGrid * kTraceBlock;
+    const uint32_t grid = std::min(cfg.traceGrid, ceilDiv(pool.slots, kTraceBlock));
+    if (count) {
+        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride);
+    } else {
+        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride);
+    }
+}
+
+void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, uint32_t* aliveSlot, bool count, hipStream_t stream) {
+    const uint32_t grid = ceilDiv(pool.slots, kShadeBlock);
+    if (count) {
+        hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, aliveSlot);
+    } else {
+        hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, aliveSlot);
+    }
+}
+
+void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count, hipStream_t stream) {
+    const uint32_t stride = cfg.traceGrid * kTraceBlock;
+    if (count) {
+        hipLaunchKernelGGL(k_connect<true>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride);
+    } else {
+        hipLaunchKernelGGL(k_connect<false>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride);
+    }
+}
+
+void launchResolve(const RenderParams& rp, const PathPool& pool, uint32_t partCount, float* dOut, hipStream_t stream) {
+    hipLaunchKernelGGL(k_resolve, dim3(ceilDiv(rp.localPixels, 256)), dim3(256), 0, stream, rp, pool, partCount, dOut);
+}
+
+void launchTraceRays(const SceneView& sc, const float4* dRays, uint64_t n, bool anyHit, PtrHit* dOut, const LaunchConfig& cfg,
+                     uint64_t* dCounters, hipStream_t stream) {
+    const uint32_t stride = cfg.traceGrid * kTraceBlock;
+    const uint32_t grid = std::min(cfg.traceGrid, std::max(1u, ceilDiv(n, kTraceBlock)));
+    if (anyHit) {
+        hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, dRays, n, dOut, cfg.spill, stride, dCounters);
+    } else {
+        hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, dRays, n, dOut, cfg.spill, stride, dCounters);
+    }
+}
+
+void launchDebugEvalBsdf(const float4* dMaterial, const RenderParams& rp, const float* dIn, uint64_t n, float* dOut, hipStream_t stream) {
+    hipLaunchKernelGGL(k_debug_eval, dim3(std::max(1u, ceilDiv(n, 128))), dim3(128), 0, stream, dMaterial, rp, dIn, n, dOut);
+}
+
+void launchDebugSampleBsdf(const float4* dMaterial, const RenderParams& rp, const float* dIn, const uint32_t* dFront, const uint32_t* dRng,
+                           uint64_t n, float* dOut, uint32_t* dRngOut, hipStream_t stream) {
+    hipLaunchKernelGGL(k_debug_sample, dim3(std::max(1u, ceilDiv(n, 128))), dim3(128), 0, stream, dMaterial, rp, dIn, dFront, dRng, n, dOut, dRngOut);
+}
+
+void launchDebugCameraRays(const RenderParams& rp, const uint32_t* dXys, uint64_t n, float* dOut, uint32_t* dRngOut, hipStream_t stream) {
+    hipLaunchKernelGGL(k_debug_camera, dim3(std::max(1u, ceilDiv(n, 128))), dim3(128), 0, stream, rp, dXys, n, dOut, dRngOut);
+}
+
+}  // namespace ptrk

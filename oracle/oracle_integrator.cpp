@@ -1,0 +1,1595 @@
+// TEST INFRASTRUCTURE — not part of the product.  See oracle/README.md and oracle_integrator.h.
+// "E:" citations = /root/reference/src/headless/EmbreeHeadlessRenderer.mm line numbers.
+#include "oracle_integrator.h"
+
+#include <atomic>
+#include <limits>
+#include <thread>
+
+namespace oracle {
+namespace {
+
+constexpr float kEpsilon = 1.0e-4f;                 // E:31
+constexpr float kSpecularNeePdfFloor = 1.0e-4f;     // E:32
+constexpr float kSpecularNeeInvPdfClamp = 1.0e4f;   // E:33
+constexpr float kMisWeightClampMin = 1.0e-4f;       // E:34
+constexpr float kMisWeightClampMax = 0.9999f;       // E:35
+constexpr float kInf = std::numeric_limits<float>::infinity();
+
+inline uint32_t matType(const PtrMaterial& m) { return static_cast<uint32_t>(m.typeEta[0]); }
+inline float degToRad(float d) { return d * (kPi / 180.0f); }
+inline float luminance(V3 c) { return (0.2126f * c.x + 0.7152f * c.y) + 0.0722f * c.z; }  // E:377-379
+
+// ---------------------------------------------------------------------------------------------
+// background / environment                                                           E:234-310
+// ---------------------------------------------------------------------------------------------
+V3 skyColor(V3 direction) {
+    const V3 unit = normalize(direction);
+    const float t = 0.5f * (unit.y + 1.0f);
+    return V3(1.0f, 1.0f, 1.0f) * (1.0f - t) + V3(0.5f, 0.7f, 1.0f) * t;
+}
+
+V3 rotateIntoMap(V3 unit, float rotation) {
+    const float c = std::cos(rotation), s = std::sin(rotation);
+    return {unit.x * c - unit.z * s, unit.y, unit.x * s + unit.z * c};
+}
+
+V3 evaluateBackground(const PtrSettings& s, const EnvMap* env, V3 direction) {  // E:293-310
+    if (s.backgroundMode == PTR_BG_SOLID) return V3(s.backgroundColor);
+    if (s.backgroundMode == PTR_BG_ENVIRONMENT && env) {
+        return sampleEnvironment(*env, direction, s.environmentRotation, s.environmentIntensity);
+    }
+    return skyColor(direction);
+}
+
+// ---------------------------------------------------------------------------------------------
+// small BSDF helpers                                                                 E:312-375
+// ---------------------------------------------------------------------------------------------
+V3 reflect(V3 v, V3 n) { return v - 2.0f * dot(v, n) * n; }
+
+bool refract(V3 v, V3 n, float eta, V3& out) {
+    const float cosTheta = std::min(-dot(v, n), 1.0f);
+    const V3 perp = eta * (v + cosTheta * n);
+    const float k = 1.0f - dot(perp, perp);
+    if (k < 0.0f) return false;
+    out = perp + (-std::sqrt(k)) * n;
+    return true;
+}
+
+struct Onb {
+    V3 tangent, bitangent, normal;
+};
+
+Onb buildOnb(V3 n) {  // E:341-350
+    Onb o;
+    o.normal = normalize(n);
+    const V3 up = (std::fabs(o.normal.z) < 0.999f) ? V3(0.0f, 0.0f, 1.0f) : V3(1.0f, 0.0f, 0.0f);
+    o.tangent = normalize(cross(up, o.normal));
+    o.bitangent = cross(o.normal, o.tangent);
+    return o;
+}
+
+V3 onbToWorld(V3 l, const Onb& o) { return (l.x * o.tangent + l.y * o.bitangent) + l.z * o.normal; }
+V3 onbToLocal(V3 v, const Onb& o) { return {dot(v, o.tangent), dot(v, o.bitangent), dot(v, o.normal)}; }
+
+V3 sampleCosineHemisphere(Rng& rng, V3 n, float& outPdf) {  // E:352-365
+    const float r1 = rng.nextFloat();
+    const float r2 = rng.nextFloat();
+    const float r = std::sqrt(std::max(r1, 0.0f));
+    const float phi = 2.0f * kPi * r2;
+    const float x = std::cos(phi) * r;
+    const float y = std::sin(phi) * r;
+    const float z = std::sqrt(std::max(1.0f - r1, 0.0f));
+    const V3 dir = onbToWorld(V3(x, y, z), buildOnb(n));
+    outPdf = z / kPi;
+    return normalize(dir);
+}
+
+float schlickWeight(float cosTheta) {
+    const float m = clampf(1.0f - cosTheta, 0.0f, 1.0f);
+    const float m2 = m * m;
+    return m2 * m2 * m;
+}
+
+V3 schlickFresnel(V3 f0, float cosTheta) { return f0 + (V3(1.0f, 1.0f, 1.0f) - f0) * schlickWeight(cosTheta); }
+
+// ---------------------------------------------------------------------------------------------
+// clamps                                                                              E:406-479
+// ---------------------------------------------------------------------------------------------
+V3 clampFireflyContribution(V3 throughput, V3 contribution, const ClampParams& p) {
+    V3 combined = throughput * contribution;
+    if (!finite3(combined)) return V3();
+    V3 positive = vmax(combined, V3());
+    if (p.enabled < 0.5f) return positive;
+    const float lum = luminance(positive);
+    const float throughputLum = luminance(vmax(throughput, V3()));
+    const float maxLum = std::max(throughputLum * p.clampFactor, p.clampFloor);
+    if (lum > maxLum && lum > 0.0f) {
+        const float scale = maxLum / std::max(lum, 1.0e-6f);
+        combined *= scale;
+        positive = vmax(combined, V3());
+    }
+    return positive;
+}
+
+float clampSpecularPdf(float pdf, const ClampParams& p) {
+    const float minPdf = std::max(p.minSpecularPdf, 1.0e-8f);
+    if (!std::isfinite(pdf)) return minPdf;
+    return std::max(pdf, minPdf);
+}
+
+V3 clampPathThroughput(V3 throughput, const ClampParams& p) {
+    if (!finite3(throughput)) return V3();
+    if (p.enabled < 0.5f || p.throughputClamp <= 0.0f) return throughput;
+    const float lum = luminance(vmax(throughput, V3()));
+    if (lum > p.throughputClamp && lum > 0.0f) {
+        return throughput * (p.throughputClamp / std::max(lum, 1.0e-6f));
+    }
+    return throughput;
+}
+
+V3 clampSpecularTail(V3 value, float roughness, V3 f0, const ClampParams& p) {
+    if (!finite3(value)) return V3();
+    V3 positive = vmax(value, V3());
+    if (p.enabled < 0.5f) return positive;
+    const float strength = std::max(std::max(f0.x, f0.y), std::max(f0.z, 1.0e-3f));
+    float limit = (p.specularTailClampBase + p.specularTailClampRoughnessScale * roughness) * strength;
+    limit = std::max(limit, p.clampFloor);
+    const float lum = luminance(positive);
+    if (lum > limit && lum > 0.0f) positive *= limit / std::max(lum, 1.0e-6f);
+    return positive;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fresnel / GGX                                                                       E:481-632
+// ---------------------------------------------------------------------------------------------
+float fresnelDielectricExact(float cosThetaI, float etaI, float etaT, float& outCosThetaT) {
+    cosThetaI = clampf(cosThetaI, -1.0f, 1.0f);
+    const float absCosI = std::fabs(cosThetaI);
+    const float sinI2 = std::max(0.0f, 1.0f - absCosI * absCosI);
+    const float eta = etaI / etaT;
+    const float sinT2 = eta * eta * sinI2;
+    if (sinT2 >= 1.0f) {
+        outCosThetaT = 0.0f;
+        return 1.0f;
+    }
+    const float cosT = std::sqrt(std::max(0.0f, 1.0f - sinT2));
+    outCosThetaT = cosT;
+    const float etaICosI = etaI * absCosI;
+    const float etaTCosT = etaT * cosT;
+    const float rs = (etaICosI - etaTCosT) / (etaICosI + etaTCosT);
+    const float rp = (etaT * absCosI - etaI * cosT) / (etaT * absCosI + etaI * cosT);
+    return 0.5f * (rs * rs + rp * rp);
+}
+
+float dielectricF0FromIor(float ior) {  // E:509-515 (clamped variant, PBR)
+    const float eta = std::max(ior, 1.0f);
+    const float num = eta - 1.0f;
+    const float den = std::max(eta + 1.0f, 1.0e-6f);
+    const float f0 = (num / den) * (num / den);
+    return clampf(f0, 0.0f, 0.99f);
+}
+
+float dielectricF0(float ior) {  // E:667-671 (plastic / coat)
+    const float eta = std::max(ior, 1.0f);
+    const float r = (eta - 1.0f) / (eta + 1.0f);
+    return r * r;
+}
+
+V3 fresnelConductor(float cosThetaI, V3 eta, V3 k) {
+    cosThetaI = clampf(cosThetaI, -1.0f, 1.0f);
+    const float cos2 = cosThetaI * cosThetaI;
+    const float sin2 = std::max(0.0f, 1.0f - cos2);
+    const V3 eta2 = eta * eta;
+    const V3 k2 = k * k;
+    const V3 t0 = (eta2 - k2) - splat(sin2);
+    const V3 a2plusb2 = vsqrt(vmax(t0 * t0 + (4.0f * eta2) * k2, V3()));
+    const V3 a = vsqrt(vmax(0.5f * (a2plusb2 + t0), V3()));
+    const V3 term1 = a2plusb2 + splat(cos2);
+    const V3 term2 = (2.0f * splat(cosThetaI)) * a;
+    const V3 rs = (term1 - term2) / (term1 + term2);
+    const V3 term3 = splat(cos2) * a2plusb2 + splat(sin2 * sin2);
+    const V3 term4 = term2 * splat(sin2);
+    const V3 rp = (term3 - term4) / (term3 + term4);
+    return vclamp(0.5f * (rs * rs + rp * rp), 0.0f, 1.0f);
+}
+
+float ggxLambda(float alpha, float cosTheta) {
+    const float absCos = std::fabs(cosTheta);
+    if (absCos <= 0.0f) return 0.0f;
+    const float sinTheta = std::sqrt(std::max(0.0f, 1.0f - absCos * absCos));
+    if (sinTheta == 0.0f) return 0.0f;
+    const float a = alpha * (sinTheta / absCos);
+    return (-1.0f + std::sqrt(1.0f + a * a)) * 0.5f;
+}
+
+float ggxG1(float alpha, float cosTheta) { return 1.0f / (1.0f + ggxLambda(alpha, cosTheta)); }
+
+float ggxDistribution(float alpha, float cosThetaH) {
+    const float c = std::fabs(cosThetaH);
+    const float a2 = alpha * alpha;
+    const float denom = c * c * (a2 - 1.0f) + 1.0f;
+    return a2 / (kPi * denom * denom);
+}
+
+float ggxPdf(float alpha, V3 normal, V3 wo, V3 wi) {  // half-vector pdf, no G1 (E:570-577)
+    const V3 wh = normalize(wo + wi);
+    const float cosThetaH = dot(normal, wh);
+    const float denom = 4.0f * std::max(dot(wo, wh), 1.0e-6f);
+    const float d = ggxDistribution(alpha, std::max(cosThetaH, 0.0f));
+    return d * std::max(cosThetaH, 0.0f) / denom;
+}
+
+V3 sampleGgxHalfVector(Rng& rng, float alpha, V3 n) {  // E:579-590
+    const float u1 = rng.nextFloat();
+    const float u2 = rng.nextFloat();
+    const float phi = 2.0f * kPi * u1;
+    const float denom = 1.0f + (alpha * alpha - 1.0f) * u2;
+    const float cosTheta = std::sqrt(std::max((1.0f - u2) / std::max(denom, 1.0e-6f), 0.0f));
+    const float sinTheta = std::sqrt(std::max(0.0f, 1.0f - cosTheta * cosTheta));
+    const V3 local(std::cos(phi) * sinTheta, std::sin(phi) * sinTheta, cosTheta);
+    return normalize(onbToWorld(local, buildOnb(n)));
+}
+
+V3 sampleGgxVndf(Rng& rng, float roughness, V3 normal, V3 wo) {  // E:602-632
+    const float alpha = std::max(roughness * roughness, 1.0e-4f);
+    const Onb onb = buildOnb(normal);
+    V3 woLocal = onbToLocal(normalize(wo), onb);
+    woLocal.z = std::max(woLocal.z, 1.0e-6f);
+    const V3 vh = normalize(V3(alpha * woLocal.x, alpha * woLocal.y, woLocal.z));
+    const float lensq = vh.x * vh.x + vh.y * vh.y;
+    const V3 t1 = lensq > 0.0f ? V3(-vh.y, vh.x, 0.0f) / std::sqrt(lensq) : V3(1.0f, 0.0f, 0.0f);
+    const V3 t2 = cross(vh, t1);
+    const float u1 = rng.nextFloat();
+    const float u2 = rng.nextFloat();
+    const float r = std::sqrt(u1);
+    const float phi = 2.0f * kPi * u2;
+    const float t1r = r * std::cos(phi);
+    const float t2r = r * std::sin(phi);
+    const float s = 0.5f * (1.0f + vh.z);
+    const float t2Adj = (1.0f - s) * std::sqrt(std::max(0.0f, 1.0f - t1r * t1r)) + s * t2r;
+    const float t3 = std::sqrt(std::max(0.0f, (1.0f - t1r * t1r) - t2Adj * t2Adj));
+    const V3 nh = (t1r * t1 + t2Adj * t2) + t3 * vh;
+    const V3 ne = normalize(V3(alpha * nh.x, alpha * nh.y, std::max(nh.z, 0.0f)));
+    return normalize(onbToWorld(ne, onb));
+}
+
+// ---------------------------------------------------------------------------------------------
+// material accessors                                                                  E:656-872
+// ---------------------------------------------------------------------------------------------
+V3 baseColor(const PtrMaterial& m) { return vclamp(V3(m.baseColorRoughness), 0.0f, 1.0f); }
+float materialRoughness(const PtrMaterial& m) { return std::max(clampf(m.baseColorRoughness[3], 0.0f, 1.0f), 1.0e-3f); }
+float coatIor(const PtrMaterial& m) { return std::max(m.typeEta[1], 1.0f); }  // PlasticCoatIor reads typeEta.y
+float coatRoughness(const PtrMaterial& m) { return std::max(clampf(m.coatParams[0], 0.0f, 1.0f), 1.0e-3f); }
+float coatThickness(const PtrMaterial& m) { return std::max(m.coatParams[1], 0.0f); }
+float coatSampleWeight(const PtrMaterial& m) { return clampf(m.coatParams[2], 0.0f, 1.0f); }
+float coatFresnelAverage(const PtrMaterial& m) { return clampf(m.coatParams[3], 0.0f, 1.0f); }
+V3 coatTint(const PtrMaterial& m) { return vclamp(V3(m.coatTint), 0.0f, 1.0f); }
+V3 coatAbsorption(const PtrMaterial& m) { return vmax(V3(m.coatAbsorption), V3()); }
+V3 exp3(V3 v) { return {std::exp(v.x), std::exp(v.y), std::exp(v.z)}; }
+V3 fract3(V3 v) { return {v.x - std::floor(v.x), v.y - std::floor(v.y), v.z - std::floor(v.z)}; }
+
+V3 plasticSpecularTint(const PtrMaterial& m) {  // E:707-719
+    const V3 tint = coatTint(m);
+    const float thickness = coatThickness(m);
+    if (thickness <= 0.0f) return tint;
+    const V3 a = coatAbsorption(m);
+    if (a.x <= 1.0e-6f && a.y <= 1.0e-6f && a.z <= 1.0e-6f) return tint;
+    return vclamp(tint * exp3(-a * thickness), 0.0f, 1.0f);
+}
+
+V3 plasticDiffuseTransmission(const PtrMaterial& m, float cosThetaI, float cosThetaO) {  // E:721-735
+    const V3 tint = coatTint(m);
+    const float thickness = coatThickness(m);
+    if (thickness <= 0.0f) return tint;
+    const V3 a = coatAbsorption(m);
+    const float ci = std::max(cosThetaI, 1.0e-3f), co = std::max(cosThetaO, 1.0e-3f);
+    const V3 attenI = exp3(-a * (thickness / ci));
+    const V3 attenO = exp3(-a * (thickness / co));
+    return vclamp((tint * attenI) * attenO, 0.0f, 1.0f);
+}
+
+float cpBaseMetallic(const PtrMaterial& m) { return clampf(m.carpaintBaseParams[0], 0.0f, 1.0f); }
+float cpBaseRoughness(const PtrMaterial& m) { return clampf(m.carpaintBaseParams[1], 0.0f, 1.0f); }
+float cpFlakeScale(const PtrMaterial& m) { return std::max(m.carpaintBaseParams[2], 1.0e-4f); }
+float cpFlakeSampleWeight(const PtrMaterial& m) { return clampf(m.carpaintFlakeParams[0], 0.0f, 0.95f); }
+float cpFlakeRoughness(const PtrMaterial& m) { return clampf(m.carpaintFlakeParams[1], 0.0f, 1.0f); }
+float cpFlakeAnisotropy(const PtrMaterial& m) { return clampf(m.carpaintFlakeParams[2], -0.99f, 0.99f); }
+float cpFlakeNormalStrength(const PtrMaterial& m) { return clampf(m.carpaintFlakeParams[3], 0.0f, 1.0f); }
+float cpCoatSampleWeight(const PtrMaterial& m) { return clampf(m.coatParams[2], 0.0f, 0.95f); }
+bool cpHasBaseConductor(const PtrMaterial& m) { return m.carpaintBaseEta[3] > 0.0f || m.carpaintBaseK[3] > 0.0f; }
+V3 cpBaseEta(const PtrMaterial& m) { return vmax(V3(m.carpaintBaseEta), V3()); }
+V3 cpBaseK(const PtrMaterial& m) { return vmax(V3(m.carpaintBaseK), V3()); }
+V3 cpBaseF0(const PtrMaterial& m) {
+    return cpHasBaseConductor(m) ? fresnelConductor(1.0f, cpBaseEta(m), cpBaseK(m)) : baseColor(m);
+}
+
+V3 carpaintHash3(V3 p) {  // E:794-805
+    V3 value = fract3(p * 0.3183099f + V3(0.1f, 0.3f, 0.7f));
+    const float d = dot(value, V3(value.y + 33.33f, value.z + 55.55f, value.x + 77.77f));
+    value += splat(d);
+    const V3 mixed(value.x + value.y, value.x + value.z, value.y + value.z);
+    return fract3(mixed * 13.5453123f);
+}
+
+V3 carpaintFlakeNormal(const PtrMaterial& m, V3 position, V3 normal) {  // E:807-827
+    const V3 rnd = carpaintHash3(position * cpFlakeScale(m));
+    const float anis = cpFlakeAnisotropy(m);
+    const float ax = std::max(1.0f - anis, 1.0e-3f);
+    const float ay = std::max(1.0f + anis, 1.0e-3f);
+    const float phi = 2.0f * kPi * rnd.x;
+    const float r = std::sqrt(std::max(rnd.y, 1.0e-4f));
+    const float x = r * std::cos(phi) * ax;
+    const float y = r * std::sin(phi) * ay;
+    const float m2 = clampf(x * x + y * y, 0.0f, 0.99f);
+    const float z = std::sqrt(std::max(1.0f - m2, 0.0f));
+    const Onb onb = buildOnb(normal);
+    const V3 perturbed = normalize((x * onb.tangent + y * onb.bitangent) + z * onb.normal);
+    const float strength = cpFlakeNormalStrength(m);
+    return normalize(normal * (1.0f - strength) + perturbed * strength);
+}
+
+bool hasConductorIor(const PtrMaterial& m) {  // E:829-834
+    return m.conductorEta[3] > 0.0f || m.conductorK[3] > 0.0f || m.conductorEta[0] > 0.0f || m.conductorEta[1] > 0.0f ||
+           m.conductorEta[2] > 0.0f || m.conductorK[0] > 0.0f || m.conductorK[1] > 0.0f || m.conductorK[2] > 0.0f;
+}
+
+V3 conductorF0(const PtrMaterial& m) {
+    return hasConductorIor(m) ? fresnelConductor(1.0f, V3(m.conductorEta), V3(m.conductorK)) : baseColor(m);
+}
+
+bool materialIsDelta(const PtrMaterial& m) {  // E:849-861
+    const uint32_t type = matType(m);
+    if (type == PTR_MAT_DIELECTRIC) return true;
+    if (type == PTR_MAT_METAL) return materialRoughness(m) <= 1.0e-3f;
+    return false;
+}
+
+float pbrSpecularWeight(V3 f0) { return clampf(std::max(f0.x, std::max(f0.y, f0.z)), 0.05f, 0.95f); }
+
+float lambertPdf(V3 normal, V3 direction) {
+    const float c = std::max(dot(normal, normalize(direction)), 0.0f);
+    return c > 0.0f ? (c / kPi) : 0.0f;
+}
+
+// Microfacet specular term F*D*G/(4 cosO cosI) shared by every glossy branch.
+V3 specTerm(V3 F, float alpha, V3 normal, V3 wh, float cosThetaO, float cosThetaI) {
+    const float D = ggxDistribution(alpha, dot(normal, wh));
+    const float G = ggxG1(alpha, cosThetaO) * ggxG1(alpha, cosThetaI);
+    const float denom = 4.0f * cosThetaO * cosThetaI;
+    return F * (D * G / std::max(denom, 1.0e-6f));
+}
+
+bool halfVectorUsable(V3 wh, V3 n, V3 wo, V3 wi) { return dot(wh, n) > 0.0f && dot(wo, wh) > 0.0f && dot(wi, wh) > 0.0f; }
+
+// ---------------------------------------------------------------------------------------------
+// car paint lobes                                                                     E:1170-1313
+// ---------------------------------------------------------------------------------------------
+struct LobeResult {
+    V3 value;
+    float pdf = 0.0f;
+};
+
+LobeResult carpaintEvalCoat(const PtrMaterial& m, V3 normal, V3 wo, V3 wi, const ClampParams& cp) {
+    LobeResult r;
+    const float cosO = std::max(dot(normal, wo), 0.0f), cosI = std::max(dot(normal, wi), 0.0f);
+    if (cosI <= 0.0f || cosO <= 0.0f) return r;
+    const float roughness = coatRoughness(m);
+    const float alpha = roughness * roughness;
+    const V3 wh = normalize(wo + wi);
+    if (!halfVectorUsable(wh, normal, wo, wi)) return r;
+    const V3 f0 = splat(dielectricF0(coatIor(m)));
+    V3 spec = specTerm(schlickFresnel(f0, dot(wi, wh)), alpha, normal, wh, cosO, cosI);
+    spec = clampSpecularTail(spec, roughness, f0, cp);
+    spec *= plasticSpecularTint(m);
+    spec = vmax(spec, V3());
+    const float pdf = ggxPdf(alpha, normal, wo, wi);
+    if (pdf > 0.0f) {
+        r.pdf = clampSpecularPdf(pdf, cp);
+        r.value = spec;
+    }
+    return r;
+}
+
+LobeResult carpaintEvalFlake(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 wi, const ClampParams& cp) {
+    LobeResult r;
+    const V3 fn = carpaintFlakeNormal(m, position, normal);
+    const float cosO = std::max(dot(fn, wo), 0.0f), cosI = std::max(dot(fn, wi), 0.0f);
+    if (cosI <= 0.0f || cosO <= 0.0f) return r;
+    const float roughness = std::max(cpFlakeRoughness(m), 1.0e-3f);
+    const float alpha = roughness * roughness;
+    const V3 wh = normalize(wo + wi);
+    if (!halfVectorUsable(wh, fn, wo, wi)) return r;
+    const V3 f0 = cpBaseF0(m);
+    V3 spec = specTerm(schlickFresnel(f0, dot(wi, wh)), alpha, fn, wh, cosO, cosI);
+    spec = clampSpecularTail(spec * plasticSpecularTint(m), roughness, f0, cp);
+    spec *= std::max(1.0f - coatFresnelAverage(m), 0.0f);
+    spec = vmax(spec, V3());
+    const float pdf = ggxPdf(alpha, fn, wo, wi);
+    if (pdf > 0.0f) {
+        r.pdf = clampSpecularPdf(pdf, cp);
+        r.value = spec;
+    }
+    return r;
+}
+
+LobeResult carpaintEvalBase(const PtrMaterial& m, V3 normal, V3 wo, V3 wi, const ClampParams& cp) {
+    LobeResult r;
+    const float cosO = std::max(dot(normal, wo), 0.0f), cosI = std::max(dot(normal, wi), 0.0f);
+    if (cosI <= 0.0f || cosO <= 0.0f) return r;
+    const float metallic = cpBaseMetallic(m);
+    const float diffuseWeight = std::max(1.0f - metallic, 0.0f);
+    const float specWeight = std::max(metallic, 0.0f);
+    if (diffuseWeight <= 1.0e-4f && specWeight <= 1.0e-4f) return r;
+    const float coatAvg = coatFresnelAverage(m);
+    const V3 base = baseColor(m);
+    V3 combined;
+    float pdfDiffuse = 0.0f, pdfSpec = 0.0f;
+    if (diffuseWeight > 1.0e-4f) {
+        V3 diffuse = base / kPi;
+        diffuse *= plasticDiffuseTransmission(m, cosI, cosO) * std::max(1.0f - coatAvg, 0.0f);
+        diffuse = vmax(diffuse, V3());
+        combined += diffuseWeight * diffuse;
+        pdfDiffuse = lambertPdf(normal, wi);
+    }
+    if (specWeight > 1.0e-4f) {
+        const float roughness = std::max(cpBaseRoughness(m), 1.0e-3f);
+        const float alpha = roughness * roughness;
+        const V3 wh = normalize(wo + wi);
+        if (halfVectorUsable(wh, normal, wo, wi)) {
+            const bool conductor = cpHasBaseConductor(m);
+            const V3 eta = cpBaseEta(m), k = cpBaseK(m);
+            const V3 f0 = conductor ? fresnelConductor(1.0f, eta, k) : base;
+            const V3 F = conductor ? fresnelConductor(dot(wi, wh), eta, k) : schlickFresnel(base, dot(wi, wh));
+            V3 spec = specTerm(F, alpha, normal, wh, cosO, cosI);
+            spec = clampSpecularTail((spec * plasticSpecularTint(m)) * std::max(1.0f - coatAvg, 0.0f), roughness, f0, cp);
+            spec = vmax(spec, V3());
+            combined += specWeight * spec;
+            const float pdf = ggxPdf(alpha, normal, wo, wi);
+            if (pdf > 0.0f) pdfSpec = clampSpecularPdf(pdf, cp);
+        }
+    }
+    r.value = vmax(combined, V3());
+    r.pdf = diffuseWeight * pdfDiffuse + specWeight * pdfSpec;
+    return r;
+}
+
+void carpaintLobeWeights(const PtrMaterial& m, float& pCoat, float& pFlake, float& pBase) {  // E:1459-1471 / 1747-1759
+    pCoat = cpCoatSampleWeight(m);
+    pFlake = cpFlakeSampleWeight(m);
+    pBase = std::max(1.0f - (pCoat + pFlake), 0.0f);
+    float norm = (pCoat + pFlake) + pBase;
+    if (norm <= 1.0e-6f) {
+        pBase = 1.0f;
+        pCoat = 0.0f;
+        pFlake = 0.0f;
+        norm = 1.0f;
+    }
+    pCoat /= norm;
+    pFlake /= norm;
+    pBase /= norm;
+}
+
+// Plastic: coat specular + attenuated diffuse, shared by eval and sample (E:1374-1421, 1626-1657).
+void plasticLobes(const PtrMaterial& m, V3 normal, V3 wo, V3 wi, float cosO, float cosI, const ClampParams& cp,
+                  V3& specular, float& specularPdf, V3& diffuse) {
+    const V3 albedo = baseColor(m);
+    const float cr = coatRoughness(m);
+    const float alpha = cr * cr;
+    const V3 f0 = splat(dielectricF0(coatIor(m)));
+    const V3 specTint = plasticSpecularTint(m);
+    specular = V3();
+    specularPdf = 0.0f;
+    const V3 wh = normalize(wo + wi);
+    if (halfVectorUsable(wh, normal, wo, wi)) {
+        specular = specTerm(schlickFresnel(f0, dot(wi, wh)), alpha, normal, wh, cosO, cosI);
+        specular = clampSpecularTail(specular, cr, f0, cp);
+        specular *= specTint;
+        const float pdf = ggxPdf(alpha, normal, wo, wi);
+        if (pdf > 0.0f) specularPdf = clampSpecularPdf(pdf, cp);
+        specular = vmax(specular, V3());
+    }
+    diffuse = albedo / kPi;
+    const V3 tint = plasticDiffuseTransmission(m, cosI, cosO);
+    const V3 Fi = schlickFresnel(f0, cosI);
+    const V3 Fo = schlickFresnel(f0, cosO);
+    diffuse *= tint;
+    diffuse *= (V3(1.0f, 1.0f, 1.0f) - Fi) * (V3(1.0f, 1.0f, 1.0f) - Fo);
+    diffuse *= std::max(1.0f - coatFresnelAverage(m), 0.0f);
+    diffuse = vmax(diffuse, V3());
+}
+
+V3 metalFresnel(const PtrMaterial& m, V3 f0, float cosTheta) {
+    return hasConductorIor(m) ? fresnelConductor(cosTheta, V3(m.conductorEta), V3(m.conductorK)) : schlickFresnel(f0, cosTheta);
+}
+
+// ---------------------------------------------------------------------------------------------
+// lights                                                                              E:917-1168
+// ---------------------------------------------------------------------------------------------
+struct RectLight {  // RectLightInfo E:109-119
+    uint32_t rectIndex = 0;
+    V3 corner, edgeU, edgeV, normal, baseEmission;
+    bool twoSided = false, emissionUsesEnv = false;
+    float area = 0.0f;
+};
+
+struct RectLightSample {
+    V3 direction, emission;
+    float distance = 0.0f, pdf = 0.0f;
+};
+
+V3 offsetRayOrigin(const HitInfo& hit, V3 direction) {  // E:917-931
+    V3 normal = hit.shadingNormal;
+    if (dot(normal, normal) <= 0.0f) normal = hit.normal;
+    if (dot(normal, normal) <= 0.0f) normal = V3(0.0f, 1.0f, 0.0f);
+    normal = normalize(normal);
+    const float sign = dot(direction, normal) >= 0.0f ? 1.0f : -1.0f;
+    const float distance = std::max(std::fabs(hit.t) * 1.0e-4f, kEpsilon);
+    V3 origin = hit.position + normal * (sign * distance);
+    origin += (direction * kEpsilon) * 0.5f;
+    return origin;
+}
+
+bool sampleRectLight(const std::vector<RectLight>& lights, const EnvMap* env, const PtrSettings& s, const HitInfo& hit,
+                     Rng& rng, RectLightSample& out) {  // E:987-1055
+    out = RectLightSample{};
+    if (lights.empty()) return false;
+    const uint32_t selected = std::min(static_cast<uint32_t>(rng.nextFloat() * lights.size()),
+                                       static_cast<uint32_t>(lights.size() - 1u));
+    const RectLight& light = lights[selected];
+    const float u = rng.nextFloat();
+    const float v = rng.nextFloat();
+    const V3 samplePoint = (light.corner + u * light.edgeU) + v * light.edgeV;
+    const V3 toLight = samplePoint - hit.position;
+    const float distSq = dot(toLight, toLight);
+    if (distSq <= 0.0f) return false;
+    const float distance = std::sqrt(distSq);
+    const V3 direction = toLight / distance;
+    if (light.area <= 0.0f) return false;
+    float cosLight = dot(-direction, light.normal);
+    if (light.twoSided) {
+        cosLight = std::fabs(cosLight);
+    } else if (cosLight <= 0.0f) {
+        return false;
+    }
+    if (cosLight <= 0.0f) return false;
+    const float pdfArea = 1.0f / light.area;
+    const float pdfDir = pdfArea * distSq / std::max(cosLight, 1.0e-6f);
+    const float selectionPdf = 1.0f / static_cast<float>(lights.size());
+    const float pdf = pdfDir * selectionPdf;
+    if (!(pdf > 0.0f) || !std::isfinite(pdf)) return false;
+    V3 emission = light.baseEmission;
+    if (light.emissionUsesEnv && env && env->width > 0 && env->height > 0 && env->rgba) {
+        emission *= sampleEnvironment(*env, -light.normal, s.environmentRotation, s.environmentIntensity);
+    }
+    if (!(dot(emission, emission) > 0.0f)) return false;
+    out.direction = direction;
+    out.distance = distance;
+    out.pdf = pdf;
+    out.emission = emission;
+    return true;
+}
+
+float rectLightPdfForHit(const std::vector<int32_t>& lightIndexByRect, const PtrRect* rects, uint32_t rectCount,
+                         uint32_t lightCount, const HitInfo& lightHit, V3 origin) {  // E:1057-1111
+    if (lightCount == 0 || !rects || rectCount == 0) return 0.0f;
+    if (lightHit.primitiveType != GeomType::Rectangles) return 0.0f;
+    const uint32_t rectIndex = lightHit.primitiveIndex;
+    if (rectIndex >= rectCount) return 0.0f;
+    if (lightIndexByRect.empty() || rectIndex >= lightIndexByRect.size() || lightIndexByRect[rectIndex] < 0) return 0.0f;
+    const PtrRect& rect = rects[rectIndex];
+    const float area = length(cross(V3(rect.edgeU), V3(rect.edgeV)));
+    if (area <= 0.0f) return 0.0f;
+    const V3 toLight = lightHit.position - origin;
+    const float distSq = dot(toLight, toLight);
+    if (distSq <= 0.0f) return 0.0f;
+    const float distance = std::sqrt(distSq);
+    const V3 direction = toLight / distance;
+    float cosLight = dot(-direction, V3(rect.normalAndPlane));
+    if (rect.materialTwoSided[1] != 0u) {
+        cosLight = std::fabs(cosLight);
+    } else if (cosLight <= 0.0f) {
+        return 0.0f;
+    }
+    if (cosLight <= 0.0f) return 0.0f;
+    const float pdfArea = 1.0f / area;
+    const float pdfDir = pdfArea * distSq / std::max(cosLight, 1.0e-6f);
+    return pdfDir * (1.0f / static_cast<float>(lightCount));
+}
+
+struct RectLightHit {
+    V3 emission;
+    float pdf = 0.0f;
+};
+
+bool rectLightHitInfo(const std::vector<int32_t>& lightIndexByRect, const std::vector<RectLight>& lights,
+                      const PtrRect* rects, uint32_t rectCount, const EnvMap* env, const PtrSettings& s,
+                      const HitInfo& hit, V3 origin, RectLightHit& out) {  // E:1113-1168
+    out = RectLightHit{};
+    if (lights.empty() || !rects || rectCount == 0) return false;
+    if (hit.primitiveType != GeomType::Rectangles) return false;
+    const uint32_t rectIndex = hit.primitiveIndex;
+    if (rectIndex >= rectCount || rectIndex >= lightIndexByRect.size()) return false;
+    const int32_t li = lightIndexByRect[rectIndex];
+    if (li < 0) return false;
+    const RectLight& light = lights[static_cast<size_t>(li)];
+    if (!hit.frontFace && !light.twoSided) return false;
+    V3 emission = light.baseEmission;
+    if (light.emissionUsesEnv && env && env->width > 0 && env->height > 0 && env->rgba) {
+        emission *= sampleEnvironment(*env, -hit.shadingNormal, s.environmentRotation, s.environmentIntensity);
+    }
+    if (!(dot(emission, emission) > 0.0f)) return false;
+    const float pdf = rectLightPdfForHit(lightIndexByRect, rects, rectCount, static_cast<uint32_t>(lights.size()), hit, origin);
+    if (!(pdf > 0.0f) || !std::isfinite(pdf)) return false;
+    out.emission = emission;
+    out.pdf = pdf;
+    return true;
+}
+
+}  // namespace
+
+// =============================================================================================
+// public pieces
+// =============================================================================================
+
+Camera buildCamera(const PtrSettings& s) {  // E:150-198
+    Camera c;
+    const uint32_t width = s.width, height = s.height;
+    const float aspect = width > 0 ? static_cast<float>(width) / static_cast<float>(height) : 1.0f;
+    const float vfov = clampf(s.cameraVerticalFov, 1.0f, 179.0f);
+    const float defocusAngle = std::max(s.cameraDefocusAngle, 0.0f);
+    const float theta = degToRad(vfov);
+    const float h = std::tan(theta * 0.5f);
+    const float viewportHeight = 2.0f * h;
+    const float viewportWidth = aspect * viewportHeight;
+    const float distance = std::max(s.cameraDistance, 0.1f);
+    const float cosPitch = std::cos(s.cameraPitch), sinPitch = std::sin(s.cameraPitch);
+    const float cosYaw = std::cos(s.cameraYaw), sinYaw = std::sin(s.cameraYaw);
+    const V3 offset(distance * cosPitch * cosYaw, distance * sinPitch, distance * cosPitch * sinYaw);
+    const V3 lookAt(s.cameraTarget);
+    const V3 lookFrom = lookAt + offset;
+    const V3 w = normalize(lookFrom - lookAt);
+    const V3 u = normalize(cross(V3(0.0f, 1.0f, 0.0f), w));
+    const V3 v = cross(w, u);
+    float focusDist = s.cameraFocusDistance;
+    if (focusDist <= 0.0f) focusDist = distance;
+    c.horizontal = (focusDist * viewportWidth) * u;
+    c.vertical = (focusDist * viewportHeight) * v;
+    c.lowerLeft = ((lookFrom - 0.5f * c.horizontal) - 0.5f * c.vertical) - focusDist * w;
+    c.origin = lookFrom;
+    c.u = u;
+    c.v = v;
+    c.lensRadius = focusDist * std::tan(degToRad(defocusAngle * 0.5f));
+    return c;
+}
+
+Ray generateCameraRay(const Camera& cam, uint32_t width, uint32_t height, uint32_t x, uint32_t y, Rng& rng) {  // E:200-232
+    const float u = (static_cast<float>(x) + rng.nextFloat()) / static_cast<float>(width);
+    float v = (static_cast<float>(y) + rng.nextFloat()) / static_cast<float>(height);
+    v = 1.0f - v;
+    V3 direction = ((cam.lowerLeft + u * cam.horizontal) + v * cam.vertical) - cam.origin;
+    V3 origin = cam.origin;
+    if (cam.lensRadius > 0.0f) {
+        V3 disk;  // SampleInUnitDisk: up to 8 rejection pairs, else (0,0,0)
+        for (int i = 0; i < 8; ++i) {
+            const float dx = rng.nextFloat() * 2.0f - 1.0f;
+            const float dy = rng.nextFloat() * 2.0f - 1.0f;
+            if (dx * dx + dy * dy <= 1.0f) {
+                disk = V3(dx, dy, 0.0f);
+                break;
+            }
+        }
+        disk = disk * cam.lensRadius;
+        const V3 offset = cam.u * disk.x + cam.v * disk.y;
+        origin += offset;
+        direction -= offset;
+    }
+    return Ray{origin, normalize(direction)};
+}
+
+ClampParams makeClampParams(const PtrSettings& s) {  // E:381-391
+    ClampParams p;
+    p.clampFactor = std::max(s.fireflyClampFactor, 0.0f);
+    p.clampFloor = std::max(s.fireflyClampFloor, 0.0f);
+    p.throughputClamp = std::max(s.throughputClamp, 0.0f);
+    p.specularTailClampBase = std::max(s.specularTailClampBase, 0.0f);
+    p.specularTailClampRoughnessScale = std::max(s.specularTailClampRoughnessScale, 0.0f);
+    p.minSpecularPdf = std::max(s.minSpecularPdf, 1.0e-8f);
+    p.enabled = s.fireflyClampEnabled ? 1.0f : 0.0f;
+    return p;
+}
+
+V3 sampleEnvironment(const EnvMap& env, V3 direction, float rotation, float intensity) {  // E:241-291
+    if (env.width == 0 || env.height == 0 || !env.rgba) return V3();
+    const V3 rotated = rotateIntoMap(normalize(direction), rotation);
+    const float u = (std::atan2(rotated.z, rotated.x) + kPi) / (2.0f * kPi);
+    const float v = 0.5f - std::asin(clampf(rotated.y, -1.0f, 1.0f)) / kPi;
+    const float fx = u * static_cast<float>(env.width) - 0.5f;
+    const float fy = v * static_cast<float>(env.height) - 0.5f;
+    int x0 = static_cast<int>(std::floor(fx));
+    int y0 = static_cast<int>(std::floor(fy));
+    int x1 = x0 + 1, y1 = y0 + 1;
+    const float tx = fx - static_cast<float>(x0);
+    const float ty = fy - static_cast<float>(y0);
+    auto wrap = [](int value, int max) {
+        const int m = value % max;
+        return m < 0 ? m + max : m;
+    };
+    const int W = static_cast<int>(env.width), H = static_cast<int>(env.height);
+    x0 = wrap(x0, W);
+    x1 = wrap(x1, W);
+    y0 = std::min(std::max(y0, 0), H - 1);
+    y1 = std::min(std::max(y1, 0), H - 1);
+    auto fetch = [&](int px, int py) { return V3(env.rgba + (static_cast<size_t>(py) * env.width + static_cast<size_t>(px)) * 4u); };
+    const V3 c00 = fetch(x0, y0), c10 = fetch(x1, y0), c01 = fetch(x0, y1), c11 = fetch(x1, y1);
+    const V3 c0 = c00 * (1.0f - tx) + c10 * tx;
+    const V3 c1 = c01 * (1.0f - tx) + c11 * tx;
+    const V3 color = c0 * (1.0f - ty) + c1 * ty;
+    return color * std::max(intensity, 0.0f);
+}
+
+float environmentPdf(const EnvMap& env, float rotation, V3 direction) {  // E:887-915
+    if (!env.hasDistribution || env.width == 0 || env.height == 0 || env.dist.texelPdf.empty()) return 0.0f;
+    const V3 rotated = rotateIntoMap(normalize(direction), rotation);
+    float u = (std::atan2(rotated.z, rotated.x) + kPi) / (2.0f * kPi);
+    float v = 0.5f - std::asin(clampf(rotated.y, -1.0f, 1.0f)) / kPi;
+    u = clampf(u, 0.0f, 0.99999994f);
+    v = clampf(v, 0.0f, 0.99999994f);
+    const uint32_t width = std::max(env.dist.width, 1u), height = std::max(env.dist.height, 1u);
+    const uint32_t x = std::min(static_cast<uint32_t>(u * static_cast<float>(width)), width - 1u);
+    const uint32_t y = std::min(static_cast<uint32_t>(v * static_cast<float>(height)), height - 1u);
+    const size_t index = static_cast<size_t>(y) * width + x;
+    if (index >= env.dist.texelPdf.size()) return 0.0f;
+    const float value = env.dist.texelPdf[index];
+    return (std::isfinite(value) && value > 0.0f) ? value : 0.0f;
+}
+
+BsdfEval evaluateBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 wi, const ClampParams& cp) {  // E:1315-1491
+    BsdfEval r;
+    const float cosO = std::max(dot(normal, wo), 0.0f);
+    const float cosI = std::max(dot(normal, wi), 0.0f);
+    if (cosI <= 0.0f || cosO <= 0.0f) return r;
+    const uint32_t type = matType(m);
+
+    if (type == PTR_MAT_LAMBERTIAN || type == PTR_MAT_SUBSURFACE) {
+        r.value = baseColor(m) / kPi;
+        r.pdf = lambertPdf(normal, wi);
+        return r;
+    }
+    if (type == PTR_MAT_PBR) {
+        const V3 base = baseColor(m);
+        const float metallic = clampf(m.pbrParams[0], 0.0f, 1.0f);
+        const float roughness = clampf(m.baseColorRoughness[3], 0.0f, 1.0f);
+        const float df0 = dielectricF0FromIor(m.typeEta[1]);
+        const V3 f0 = base * metallic + splat(df0) * (1.0f - metallic);
+        const V3 diffuseColor = base * (1.0f - metallic);
+        const float alpha = std::max(roughness * roughness, 1.0e-4f);
+        const V3 wh = normalize(wo + wi);
+        if (!halfVectorUsable(wh, normal, wo, wi)) return r;
+        V3 spec = specTerm(schlickFresnel(f0, dot(wi, wh)), alpha, normal, wh, cosO, cosI);
+        spec = clampSpecularTail(spec, roughness, f0, cp);
+        spec = vmax(spec, V3());
+        const V3 diffuse = diffuseColor / kPi;
+        const float pdfDiffuse = lambertPdf(normal, wi);
+        const float pdfSpec = ggxPdf(alpha, normal, wo, wi);
+        const float specPdfClamped = (pdfSpec > 0.0f) ? clampSpecularPdf(pdfSpec, cp) : 0.0f;
+        const float specWeight = pbrSpecularWeight(f0);
+        const float pdf = specWeight * specPdfClamped + (1.0f - specWeight) * pdfDiffuse;
+        if (pdf > 0.0f) {
+            r.value = vmax(spec + diffuse, V3());
+            r.pdf = pdf;
+        }
+        return r;
+    }
+    if (type == PTR_MAT_PLASTIC) {
+        V3 specular, diffuse;
+        float specularPdf;
+        plasticLobes(m, normal, wo, wi, cosO, cosI, cp, specular, specularPdf, diffuse);
+        const float pdfDiffuse = lambertPdf(normal, wi);
+        const float pCoat = coatSampleWeight(m);
+        const float pdf = pCoat * specularPdf + (1.0f - pCoat) * pdfDiffuse;
+        if (pdf > 0.0f) {
+            r.value = specular + diffuse;
+            r.pdf = pdf;
+        }
+        return r;
+    }
+    if (type == PTR_MAT_METAL) {
+        const float roughness = clampf(m.baseColorRoughness[3], 0.0f, 1.0f);
+        if (roughness <= 1.0e-3f) {
+            r.isDelta = true;
+            return r;
+        }
+        const float alpha = roughness * roughness;
+        const V3 wh = normalize(wo + wi);
+        if (!halfVectorUsable(wh, normal, wo, wi)) return r;
+        const V3 f0 = conductorF0(m);
+        V3 spec = specTerm(metalFresnel(m, f0, dot(wi, wh)), alpha, normal, wh, cosO, cosI);
+        spec = clampSpecularTail(spec, roughness, f0, cp);
+        const float pdf = ggxPdf(alpha, normal, wo, wi);
+        if (pdf > 0.0f) {
+            r.value = vmax(spec, V3());
+            r.pdf = clampSpecularPdf(pdf, cp);
+        }
+        return r;
+    }
+    if (type == PTR_MAT_CARPAINT) {
+        float pCoat, pFlake, pBase;
+        carpaintLobeWeights(m, pCoat, pFlake, pBase);
+        const LobeResult coat = carpaintEvalCoat(m, normal, wo, wi, cp);
+        const LobeResult flake = carpaintEvalFlake(m, position, normal, wo, wi, cp);
+        const LobeResult base = carpaintEvalBase(m, normal, wo, wi, cp);
+        r.value = (pBase * base.value + pFlake * flake.value) + pCoat * coat.value;
+        r.pdf = (pBase * base.pdf + pFlake * flake.pdf) + pCoat * coat.pdf;
+        return r;
+    }
+    if (type == PTR_MAT_DIELECTRIC) {
+        r.isDelta = true;
+        return r;
+    }
+    r.value = baseColor(m) / kPi;
+    r.pdf = lambertPdf(normal, wi);
+    return r;
+}
+
+BsdfSample sampleBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 incidentDir, bool frontFace, Rng& rng,
+                      const ClampParams& cp) {  // E:1493-1918
+    BsdfSample r;
+    const uint32_t type = matType(m);
+
+    if (type == PTR_MAT_LAMBERTIAN || type == PTR_MAT_SUBSURFACE) {
+        float pdf = 0.0f;
+        const V3 wi = sampleCosineHemisphere(rng, normal, pdf);
+        const float cosI = dot(normal, wi);
+        if (pdf <= 0.0f || cosI <= 0.0f) return r;
+        const V3 f = baseColor(m) / kPi;
+        const V3 weight = f * cosI / pdf;
+        if (!finite3(weight)) return r;
+        r.direction = wi;
+        r.weight = vmax(weight, V3());
+        r.pdf = pdf;
+        return r;
+    }
+
+    if (type == PTR_MAT_PBR) {
+        const V3 base = baseColor(m);
+        const float metallic = clampf(m.pbrParams[0], 0.0f, 1.0f);
+        const float roughness = clampf(m.baseColorRoughness[3], 0.0f, 1.0f);
+        const float df0 = dielectricF0FromIor(m.typeEta[1]);
+        const V3 f0 = base * metallic + splat(df0) * (1.0f - metallic);
+        const V3 diffuseColor = base * (1.0f - metallic);
+        const float specWeight = pbrSpecularWeight(f0);
+        const float diffuseWeight = 1.0f - specWeight;
+        V3 wi, f;
+        float pdfSpec = 0.0f, pdfDiffuse = 0.0f;
+        if (rng.nextFloat() < specWeight) {
+            if (roughness <= 1.0e-3f) {
+                wi = normalize(reflect(incidentDir, normal));
+                if (dot(normal, wi) <= 0.0f) return r;
+                f = schlickFresnel(f0, std::max(dot(normal, wo), 0.0f));
+                pdfSpec = 1.0f;
+                r.isDelta = true;
+            } else {
+                const float alpha = roughness * roughness;
+                const V3 wh = sampleGgxHalfVector(rng, alpha, normal);
+                if (dot(wh, normal) <= 0.0f) return r;
+                wi = normalize(reflect(-wo, wh));
+                const float cosI = std::max(dot(normal, wi), 0.0f);
+                const float cosO = std::max(dot(normal, wo), 0.0f);
+                if (cosI <= 0.0f || cosO <= 0.0f) return r;
+                f = specTerm(schlickFresnel(f0, dot(wi, wh)), alpha, normal, wh, cosO, cosI);
+                f = clampSpecularTail(f, roughness, f0, cp);
+                pdfSpec = ggxPdf(alpha, normal, wo, wi);
+            }
+        } else {
+            float pdf = 0.0f;
+            wi = sampleCosineHemisphere(rng, normal, pdf);
+            pdfDiffuse = pdf;
+            if (pdfDiffuse <= 0.0f || std::max(dot(normal, wi), 0.0f) <= 0.0f) return r;
+            f = diffuseColor / kPi;
+        }
+        const float cosI = std::max(dot(normal, wi), 0.0f);
+        const float specPdfClamped = (pdfSpec > 0.0f) ? clampSpecularPdf(pdfSpec, cp) : 0.0f;
+        const float pdf = specWeight * specPdfClamped + diffuseWeight * pdfDiffuse;
+        if (pdf <= 0.0f || cosI <= 0.0f) return r;
+        const V3 weight = f * cosI / pdf;
+        if (!finite3(weight)) return r;
+        r.direction = wi;
+        r.weight = vmax(weight, V3());
+        r.pdf = pdf;
+        return r;
+    }
+
+    if (type == PTR_MAT_PLASTIC) {
+        const float cr = coatRoughness(m);
+        const float alpha = cr * cr;
+        const float pCoat = coatSampleWeight(m);
+        V3 wi;
+        if (rng.nextFloat() < pCoat) {
+            const V3 wh = sampleGgxHalfVector(rng, alpha, normal);
+            if (dot(wh, normal) <= 0.0f) return r;
+            wi = normalize(reflect(-wo, wh));
+        } else {
+            float pdf = 0.0f;
+            wi = sampleCosineHemisphere(rng, normal, pdf);
+        }
+        const float cosI = std::max(dot(normal, wi), 0.0f);
+        const float cosO = std::max(dot(normal, wo), 0.0f);
+        if (cosI <= 0.0f || cosO <= 0.0f) return r;
+        V3 specular, diffuse;
+        float specularPdf;
+        plasticLobes(m, normal, wo, wi, cosO, cosI, cp, specular, specularPdf, diffuse);
+        const float pdfDiffuse = lambertPdf(normal, wi);
+        const float pdf = pCoat * specularPdf + (1.0f - pCoat) * pdfDiffuse;
+        if (pdf <= 0.0f) return r;
+        const V3 weight = (specular + diffuse) * cosI / pdf;
+        if (!finite3(weight)) return r;
+        r.direction = wi;
+        r.weight = vmax(weight, V3());
+        r.pdf = pdf;
+        return r;
+    }
+
+    if (type == PTR_MAT_METAL) {
+        const float roughness = clampf(m.baseColorRoughness[3], 0.0f, 1.0f);
+        const V3 f0 = conductorF0(m);
+        if (roughness <= 1.0e-3f) {
+            const V3 wi = normalize(reflect(incidentDir, normal));
+            if (dot(normal, wi) <= 0.0f) return r;
+            r.direction = wi;
+            r.weight = metalFresnel(m, f0, std::max(dot(normal, wo), 0.0f));
+            r.pdf = 1.0f;
+            r.isDelta = true;
+            return r;
+        }
+        const float alpha = roughness * roughness;
+        const V3 wh = sampleGgxHalfVector(rng, alpha, normal);
+        if (dot(wh, normal) <= 0.0f) return r;
+        const V3 wi = normalize(reflect(-wo, wh));
+        const float cosI = dot(normal, wi);
+        const float cosO = dot(normal, wo);
+        if (cosI <= 0.0f || cosO <= 0.0f) return r;
+        const float dotWoWh = dot(wo, wh);
+        if (dotWoWh <= 0.0f) return r;
+        const V3 F = metalFresnel(m, f0, dot(wi, wh));
+        const float D = ggxDistribution(alpha, dot(normal, wh));
+        const float G = ggxG1(alpha, cosO) * ggxG1(alpha, cosI);
+        const float denom = 4.0f * cosO * cosI;
+        V3 f = F * (D * G / std::max(denom, 1.0e-6f));
+        f = clampSpecularTail(f, roughness, f0, cp);
+        const float pdf = D * std::max(dot(normal, wh), 0.0f) / std::max(4.0f * dotWoWh, 1.0e-6f);
+        if (pdf <= 0.0f) return r;
+        const float clampedPdf = clampSpecularPdf(pdf, cp);
+        const V3 weight = f * cosI / clampedPdf;
+        if (!finite3(weight)) return r;
+        r.direction = wi;
+        r.weight = vmax(weight, V3());
+        r.pdf = clampedPdf;
+        return r;
+    }
+
+    if (type == PTR_MAT_CARPAINT) {
+        float pCoat, pFlake, pBase;
+        carpaintLobeWeights(m, pCoat, pFlake, pBase);
+        const float pick = rng.nextFloat();
+        uint32_t lobe = 0u;  // 0 base, 1 flake, 2 coat
+        if (pCoat > 0.0f && pick < pCoat) {
+            lobe = 2u;
+        } else if (pFlake > 0.0f && pick < pCoat + pFlake) {
+            lobe = 1u;
+        } else if (pBase <= 1.0e-6f) {
+            if (pFlake > pCoat && pFlake > 0.0f) {
+                lobe = 1u;
+            } else if (pCoat > 0.0f) {
+                lobe = 2u;
+            }
+        }
+        V3 wi;
+        if (lobe == 2u) {
+            const V3 wh = sampleGgxVndf(rng, coatRoughness(m), normal, wo);
+            if (dot(wh, normal) <= 0.0f) return r;
+            wi = normalize(reflect(-wo, wh));
+        } else if (lobe == 1u) {
+            const float fr = std::max(cpFlakeRoughness(m), 1.0e-3f);
+            const V3 fn = carpaintFlakeNormal(m, position, normal);
+            const V3 wh = sampleGgxHalfVector(rng, fr * fr, fn);
+            if (dot(wh, fn) <= 0.0f) return r;
+            wi = normalize(reflect(-wo, wh));
+        } else {
+            const float metallic = cpBaseMetallic(m);
+            const float diffuseWeight = std::max(1.0f - metallic, 0.0f);
+            const float specWeight = std::max(metallic, 0.0f);
+            const float weightSum = diffuseWeight + specWeight;
+            const float choose = rng.nextFloat();
+            const bool sampleSpec = (specWeight > 0.0f) && (weightSum > 0.0f) && (choose < specWeight / std::max(weightSum, 1.0e-6f));
+            if (sampleSpec) {
+                const float br = std::max(cpBaseRoughness(m), 1.0e-3f);
+                const V3 wh = sampleGgxHalfVector(rng, br * br, normal);
+                if (dot(wh, normal) <= 0.0f) return r;
+                wi = normalize(reflect(-wo, wh));
+            } else {
+                float pdf = 0.0f;
+                wi = sampleCosineHemisphere(rng, normal, pdf);
+            }
+        }
+        if (!finite3(wi) || dot(normal, wi) <= 0.0f) return r;
+        const LobeResult coat = carpaintEvalCoat(m, normal, wo, wi, cp);
+        const LobeResult flake = carpaintEvalFlake(m, position, normal, wo, wi, cp);
+        const LobeResult base = carpaintEvalBase(m, normal, wo, wi, cp);
+        const float combinedPdf = (pBase * base.pdf + pFlake * flake.pdf) + pCoat * coat.pdf;
+        if (combinedPdf <= 0.0f) return r;
+        const LobeResult& sel = (lobe == 1u) ? flake : (lobe == 2u ? coat : base);
+        if (sel.pdf <= 0.0f || !(sel.value.x > 0.0f || sel.value.y > 0.0f || sel.value.z > 0.0f)) return r;
+        const float cosI = std::max(dot(normal, wi), 0.0f);
+        if (cosI <= 0.0f) return r;
+        const V3 weight = sel.value * cosI / combinedPdf;
+        if (!finite3(weight)) return r;
+        r.direction = wi;
+        r.weight = vmax(weight, V3());
+        r.pdf = combinedPdf;
+        return r;
+    }
+
+    if (type == PTR_MAT_DIELECTRIC) {
+        r.isDelta = true;
+        const float refIdx = std::max(m.typeEta[1], 1.0f);
+        float etaI = 1.0f, etaT = refIdx;
+        const float cosO = clampf(dot(-incidentDir, normal), -1.0f, 1.0f);
+        if (!frontFace) {
+            etaI = refIdx;
+            etaT = 1.0f;
+        }
+        const float relativeEta = etaI / etaT;
+        float cosT = 0.0f;
+        const float Fr = fresnelDielectricExact(cosO, etaI, etaT, cosT);
+        V3 direction, weight;
+        V3 refracted;
+        if (rng.nextFloat() < Fr) {
+            direction = reflect(incidentDir, normal);
+            weight = splat(Fr);
+        } else if (!refract(incidentDir, normal, relativeEta, refracted) || dot(refracted, refracted) <= 0.0f) {
+            direction = reflect(incidentDir, normal);
+            weight = splat(Fr);
+        } else {
+            // note: weight is NOT divided by the selection probability (reference quirk, Appendix A row 8)
+            direction = normalize(refracted);
+            const float etaScale = (etaT * etaT) / (etaI * etaI);
+            const float directionScale = etaScale * (std::fabs(cosT) / std::max(std::fabs(cosO), 1.0e-6f));
+            weight = splat(std::max(1.0f - Fr, 0.0f) * directionScale);
+        }
+        r.direction = normalize(direction);
+        r.weight = weight;
+        r.pdf = 1.0f;
+        return r;
+    }
+
+    float pdf = 0.0f;
+    const V3 wi = sampleCosineHemisphere(rng, normal, pdf);
+    if (pdf <= 0.0f) return r;
+    const V3 weight = baseColor(m);
+    if (!finite3(weight)) return r;
+    r.direction = wi;
+    r.weight = vmax(weight, V3());
+    r.pdf = pdf;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// EnvImportanceSampler.mm
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+void buildAliasTable(const std::vector<float>& probabilities, std::vector<uint32_t>& alias, std::vector<float>& threshold) {  // :16-66
+    const size_t count = probabilities.size();
+    alias.assign(count, 0u);
+    threshold.assign(count, 0.0f);
+    if (count == 0) return;
+    std::vector<float> scaled(count);
+    std::vector<size_t> small, large;
+    for (size_t i = 0; i < count; ++i) {
+        scaled[i] = probabilities[i] * static_cast<float>(count);
+        (scaled[i] < 1.0f ? small : large).push_back(i);
+    }
+    while (!small.empty() && !large.empty()) {
+        const size_t s = small.back();
+        small.pop_back();
+        const size_t l = large.back();
+        threshold[s] = clampf(scaled[s], 0.0f, 1.0f);
+        alias[s] = static_cast<uint32_t>(l);
+        scaled[l] = (scaled[l] + scaled[s]) - 1.0f;
+        if (scaled[l] < 1.0f - 1e-7f) {
+            large.pop_back();
+            small.push_back(l);
+        }
+    }
+    for (const std::vector<size_t>* rest : {&small, &large}) {
+        for (size_t i : *rest) {
+            threshold[i] = 1.0f;
+            alias[i] = static_cast<uint32_t>(i);
+        }
+    }
+}
+
+}  // namespace
+
+bool buildEnvDistribution(const float* rgba, uint32_t width, uint32_t height, EnvDistribution& out) {  // :70-171
+    out = EnvDistribution{};
+    if (!rgba || width == 0 || height == 0) return false;
+    const size_t texels = static_cast<size_t>(width) * height;
+    const float dTheta = kPi / static_cast<float>(height);
+    const float dPhi = (2.0f * kPi) / static_cast<float>(width);
+    std::vector<float> weights(texels, 0.0f), rowWeights(height, 0.0f);
+    float totalWeight = 0.0f;
+    for (uint32_t y = 0; y < height; ++y) {
+        const float sinTheta = std::sin((static_cast<float>(y) + 0.5f) * dTheta);
+        const float cell = std::max(sinTheta, 0.0f) * dTheta * dPhi;
+        for (uint32_t x = 0; x < width; ++x) {
+            const size_t i = static_cast<size_t>(y) * width + x;
+            const float* px = rgba + i * 4u;
+            const float lum = (0.2126f * px[0] + 0.7152f * px[1]) + 0.0722f * px[2];
+            const float w = std::max(lum, 0.0f) * cell;
+            weights[i] = w;
+            rowWeights[y] += w;
+            totalWeight += w;
+        }
+    }
+    if (totalWeight <= 0.0f) return false;
+    out.width = width;
+    out.height = height;
+    out.aliasCount = static_cast<uint32_t>(texels);
+    out.totalWeight = totalWeight;
+    std::vector<float> marginal(height);
+    for (uint32_t y = 0; y < height; ++y) marginal[y] = rowWeights[y] > 0.0f ? (rowWeights[y] / totalWeight) : 0.0f;
+    buildAliasTable(marginal, out.marginalAlias, out.marginalThreshold);
+    out.conditionalAlias.assign(texels, 0u);
+    out.conditionalThreshold.assign(texels, 0.0f);
+    std::vector<float> cond(width);
+    std::vector<uint32_t> aliasRow;
+    std::vector<float> thresholdRow;
+    for (uint32_t y = 0; y < height; ++y) {
+        const size_t off = static_cast<size_t>(y) * width;
+        if (rowWeights[y] > 0.0f) {
+            const float inv = 1.0f / rowWeights[y];
+            for (uint32_t x = 0; x < width; ++x) cond[x] = weights[off + x] * inv;
+        } else {
+            std::fill(cond.begin(), cond.end(), 1.0f / static_cast<float>(width));
+        }
+        buildAliasTable(cond, aliasRow, thresholdRow);
+        for (uint32_t x = 0; x < width; ++x) {
+            out.conditionalAlias[off + x] = aliasRow[x];
+            out.conditionalThreshold[off + x] = thresholdRow[x];
+        }
+    }
+    out.texelPdf.assign(texels, 0.0f);
+    for (uint32_t y = 0; y < height; ++y) {
+        const float sinTheta = std::sin((static_cast<float>(y) + 0.5f) * dTheta);
+        const float cell = std::max(sinTheta, 0.0f) * dTheta * dPhi;
+        for (uint32_t x = 0; x < width; ++x) {
+            const size_t i = static_cast<size_t>(y) * width + x;
+            const float probability = weights[i] / totalWeight;
+            out.texelPdf[i] = (cell > 0.0f) ? (probability / cell) : 0.0f;
+        }
+    }
+    return true;
+}
+
+EnvSample sampleEnvironmentCpu(const EnvDistribution& dist, float uMarginal, float uConditional, float uJitter,
+                               float rotation, float intensity, const float* rgba) {  // :173-236
+    EnvSample s;
+    if (!rgba || dist.width == 0 || dist.height == 0 || dist.aliasCount == 0) return s;
+    uMarginal = clampf(uMarginal, 0.0f, 0.99999994f);
+    uConditional = clampf(uConditional, 0.0f, 0.99999994f);
+    uJitter = clampf(uJitter, 0.0f, 0.99999994f);
+    const float rowChoice = uMarginal * static_cast<float>(dist.height);
+    uint32_t row = std::min(static_cast<uint32_t>(rowChoice), dist.height - 1u);
+    const float rowFrac = rowChoice - static_cast<float>(row);
+    if (rowFrac >= dist.marginalThreshold[row]) row = std::min(dist.marginalAlias[row], dist.height - 1u);
+    const float colChoice = uConditional * static_cast<float>(dist.width);
+    uint32_t col = std::min(static_cast<uint32_t>(colChoice), dist.width - 1u);
+    const float colFrac = colChoice - static_cast<float>(col);
+    const size_t rowOffset = static_cast<size_t>(row) * dist.width;
+    if (colFrac >= dist.conditionalThreshold[rowOffset + col]) col = std::min(dist.conditionalAlias[rowOffset + col], dist.width - 1u);
+    const float jitterX = uConditional - std::floor(uConditional);
+    const float fx = (static_cast<float>(col) + jitterX) / static_cast<float>(dist.width);
+    const float fy = (static_cast<float>(row) + uJitter) / static_cast<float>(dist.height);
+    const float theta = fy * kPi;
+    const float phi = fx * (2.0f * kPi);
+    const float sinTheta = std::sin(theta), cosTheta = std::cos(theta);
+    const V3 mapDir(sinTheta * std::cos(phi), cosTheta, sinTheta * std::sin(phi));
+    const float cosRot = std::cos(rotation), sinRot = std::sin(rotation);
+    s.direction = V3(mapDir.x * cosRot + mapDir.z * sinRot, mapDir.y, -mapDir.x * sinRot + mapDir.z * cosRot);
+    const size_t texel = rowOffset + col;
+    s.pdf = texel < dist.texelPdf.size() ? dist.texelPdf[texel] : 0.0f;
+    s.radiance = V3(rgba + texel * 4u) * intensity;
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scene queries                                                                       E:2302-2433
+// ---------------------------------------------------------------------------------------------
+bool intersectScene(const Scene& scene, const Ray& ray, HitInfo& out, Counters* counters) {
+    RayHit rh;
+    if (!scene.intersect(ray.origin, ray.direction, kEpsilon, kInf, rh, false, counters)) return false;
+    const Geom& g = scene.geoms[rh.geom];
+    out.t = rh.t;
+    out.position = ray.origin + out.t * ray.direction;
+    if (dot(rh.ng, rh.ng) > 0.0f) out.normal = normalize(rh.ng);
+    out.frontFace = dot(ray.direction, out.normal) < 0.0f;
+    V3 adjusted = out.frontFace ? out.normal : -out.normal;
+    V3 shading = adjusted;
+    uint32_t material = g.materialIndex;
+    out.primitiveType = g.type;
+    out.primitiveIndex = rh.primId;
+    out.twoSided = false;
+    if (g.type == GeomType::Mesh && !g.indices.empty() && !g.normals.empty()) {
+        const uint32_t base = rh.primId * 3u;
+        if (base + 2u < g.indices.size()) {
+            const float u = rh.u, v = rh.v, w = 1.0f - u - v;
+            const V3 interp = (w * g.normals[g.indices[base]] + u * g.normals[g.indices[base + 1u]]) + v * g.normals[g.indices[base + 2u]];
+            if (dot(interp, interp) > 0.0f) {
+                shading = normalize(interp);
+                if (dot(shading, adjusted) < 0.0f) shading = -shading;
+            }
+        }
+    } else if (g.type == GeomType::Rectangles && !g.normals.empty()) {
+        const uint32_t index = rh.primId * 3u;
+        if (index < g.indices.size()) {
+            shading = g.normals[g.indices[index]];
+            if (dot(shading, adjusted) < 0.0f) shading = -shading;
+        }
+        uint32_t rectIndex = rh.primId;
+        if (rh.primId < g.triToRect.size()) rectIndex = g.triToRect[rh.primId];
+        out.primitiveIndex = rectIndex;
+        if (scene.rects && rectIndex < scene.rectCount) out.twoSided = scene.rects[rectIndex].materialTwoSided[1] != 0u;
+        if (!g.primMaterial.empty()) material = g.primMaterial[rh.primId];
+    } else if (g.type == GeomType::Spheres) {
+        if (rh.primId < scene.spheres.size()) {
+            const V3 center(scene.spheres[rh.primId].centerRadius);
+            const V3 normal = normalize(out.position - center);
+            shading = normal;
+            out.normal = normal;
+            out.frontFace = dot(ray.direction, normal) < 0.0f;
+            out.twoSided = true;
+            if (!g.primMaterial.empty()) material = g.primMaterial[rh.primId];
+        }
+    }
+    out.shadingNormal = shading;
+    out.materialIndex = material;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// render loop                                                                         E:2443-3214
+// ---------------------------------------------------------------------------------------------
+void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& settings, uint32_t spp, uint32_t threads,
+            uint32_t yBegin, uint32_t yEnd, float* outRgb, RenderCounters* outCounters) {
+    const uint32_t width = settings.width, height = settings.height;
+    const PtrMaterial* materials = desc.materials;
+    const uint32_t materialCount = desc.materialCount;
+    const PtrRect* rectangles = desc.rects;
+    const uint32_t rectangleCount = desc.rectCount;
+    const float emissionScale = (settings.emissionScale > 0.0f && std::isfinite(settings.emissionScale)) ? settings.emissionScale : 1.0f;
+
+    EnvMap envMap;
+    EnvMap* env = nullptr;
+    if (desc.envRgba && desc.envWidth > 0 && desc.envHeight > 0) {
+        envMap.rgba = desc.envRgba;
+        envMap.width = desc.envWidth;
+        envMap.height = desc.envHeight;
+        envMap.hasDistribution = buildEnvDistribution(desc.envRgba, desc.envWidth, desc.envHeight, envMap.dist);
+        env = &envMap;
+    }
+
+    // rectangle lights: DiffuseLight rectangles with non-zero emission (E:2484-2522)
+    std::vector<RectLight> rectLights;
+    std::vector<int32_t> lightIndexByRect;
+    if (rectangles && rectangleCount > 0 && materials && materialCount > 0) {
+        lightIndexByRect.assign(rectangleCount, -1);
+        for (uint32_t i = 0; i < rectangleCount; ++i) {
+            const PtrRect& rect = rectangles[i];
+            const PtrMaterial& mat = materials[std::min(rect.materialTwoSided[0], materialCount - 1u)];
+            if (matType(mat) != PTR_MAT_DIFFUSE_LIGHT) continue;
+            const V3 baseEmission = V3(mat.emission) * emissionScale;
+            if (!(dot(baseEmission, baseEmission) > 0.0f)) continue;
+            RectLight li;
+            li.rectIndex = i;
+            li.corner = V3(rect.corner);
+            li.edgeU = V3(rect.edgeU);
+            li.edgeV = V3(rect.edgeV);
+            li.normal = normalize(V3(rect.normalAndPlane));
+            li.twoSided = rect.materialTwoSided[1] != 0u;
+            li.baseEmission = baseEmission;
+            li.emissionUsesEnv = false;  // emitEnv is disabled for NEE on this path (E:2515-2516)
+            li.area = length(cross(li.edgeU, li.edgeV));
+            lightIndexByRect[i] = static_cast<int32_t>(rectLights.size());
+            rectLights.push_back(li);
+        }
+    }
+    const uint32_t rectLightCount = static_cast<uint32_t>(rectLights.size());
+    const bool envMapAvailable = env && env->width > 0 && env->height > 0 && env->rgba;
+    const bool envSampling = env && env->hasDistribution && envMapAvailable;
+    const ClampParams cp = makeClampParams(settings);
+    const Camera camera = buildCamera(settings);
+    const uint32_t targetSamples = std::max<uint32_t>(1u, spp);
+    const uint32_t seedBase = settings.seed != 0 ? settings.seed : 0x9e3779b9u;
+
+    std::atomic<uint64_t> cExtend{0}, cShadow{0}, cNodes{0}, cPrims{0}, cShaded{0}, cTri{0};
+    const bool counting = outCounters != nullptr;
+
+    auto renderPixel = [&](uint32_t x, uint32_t y, RenderCounters& rc) -> V3 {
+        V3 pixelRadiance;
+        const uint32_t pixelIndex = y * width + x;
+        Counters tc;
+        Counters* tcp = counting ? &tc : nullptr;
+        auto trace = [&](const Ray& r, HitInfo& h) {
+            if (counting) ++rc.extendRays;
+            return intersectScene(scene, r, h, tcp);
+        };
+        auto occluded = [&](V3 o, V3 d, float tMax) {
+            if (counting) ++rc.shadowRays;
+            return scene.occluded(o, d, kEpsilon, tMax, false, tcp);
+        };
+
+        for (uint32_t s = 0; s < targetSamples; ++s) {
+            Rng rng;
+            rng.state = Rng::hash(seedBase ^ pixelIndex ^ (s * 0x9e3779b9u));
+            Ray ray = generateCameraRay(camera, width, height, x, y, rng);
+            V3 throughput(1.0f, 1.0f, 1.0f), radiance;
+            float lastBsdfPdf = 1.0f;
+            bool lastScatterWasDelta = true;
+            uint32_t specularDepth = 0;
+
+            for (uint32_t depth = 0; depth < settings.maxDepth; ++depth) {
+                HitInfo hit;
+                if (!trace(ray, hit)) {
+                    const V3 background = evaluateBackground(settings, env, ray.direction);
+                    float misWeight = 1.0f;
+                    const bool useSpecularMis = (!lastScatterWasDelta) || settings.enableSpecularNee || settings.enableMnee;
+                    if (useSpecularMis && envSampling) {
+                        const float lightPdf = environmentPdf(*env, settings.environmentRotation, ray.direction);
+                        const float denom = lastBsdfPdf + lightPdf;
+                        if (denom > 0.0f) misWeight = lastBsdfPdf / denom;
+                        misWeight = clampf(misWeight, kMisWeightClampMin, kMisWeightClampMax);
+                    }
+                    radiance += clampFireflyContribution(throughput, background * misWeight, cp);
+                    break;
+                }
+                if (!materials || materialCount == 0) break;
+                if (counting) {
+                    ++rc.shadedHits;
+                    if (hit.primitiveType == GeomType::Mesh) ++rc.triangleHits;
+                }
+
+                const PtrMaterial& material = materials[std::min(hit.materialIndex, materialCount - 1)];
+                const uint32_t type = matType(material);
+                const V3 incidentDir = normalize(ray.direction);
+                const V3 wo = -incidentDir;
+                V3 shadingNormal = hit.shadingNormal;
+                if (dot(shadingNormal, shadingNormal) <= 0.0f) shadingNormal = hit.normal;
+                if (type == PTR_MAT_DIELECTRIC) shadingNormal = hit.normal;  // dielectrics shade with the geometric normal
+                shadingNormal = normalize(shadingNormal);
+
+                if (type == PTR_MAT_DIFFUSE_LIGHT) {  // E:2660-2706
+                    V3 emission = V3(material.emission) * emissionScale;
+                    if (material.emission[3] > 0.0f && envMapAvailable && hit.frontFace) {
+                        emission *= sampleEnvironment(*env, -shadingNormal, settings.environmentRotation, settings.environmentIntensity);
+                    }
+                    if ((dot(emission, emission) > 0.0f) && (hit.frontFace || hit.twoSided)) {
+                        float misWeight = 1.0f;
+                        const bool useSpecularMis = (!lastScatterWasDelta) || settings.enableSpecularNee || settings.enableMnee;
+                        if (useSpecularMis && rectLightCount > 0) {
+                            const float lightPdf = rectLightPdfForHit(lightIndexByRect, rectangles, rectangleCount, rectLightCount, hit, ray.origin);
+                            const float denom = lastBsdfPdf + lightPdf;
+                            if (denom > 0.0f) misWeight = lastBsdfPdf / denom;
+                            misWeight = clampf(misWeight, kMisWeightClampMin, kMisWeightClampMax);
+                        }
+                        radiance += clampFireflyContribution(throughput, emission * misWeight, cp);
+                    }
+                    break;
+                }
+
+                const bool surfaceIsDelta = materialIsDelta(material);
+
+                if (!surfaceIsDelta && rectLightCount > 0) {  // rect-light NEE, E:2710-2772
+                    RectLightSample ls;
+                    if (sampleRectLight(rectLights, env, settings, hit, rng, ls)) {
+                        const float nDotL = std::max(dot(shadingNormal, ls.direction), 0.0f);
+                        if (ls.pdf > 0.0f && nDotL > 0.0f) {
+                            const float shadowMax = std::max(ls.distance - kEpsilon, kEpsilon);
+                            if (!occluded(offsetRayOrigin(hit, ls.direction), ls.direction, shadowMax)) {
+                                const BsdfEval be = evaluateBsdf(material, hit.position, shadingNormal, wo, ls.direction, cp);
+                                if (!be.isDelta && be.pdf > 0.0f) {
+                                    const float weight = ls.pdf / (ls.pdf + be.pdf);  // unclamped balance heuristic
+                                    V3 contribution = (ls.emission * be.value) * nDotL;
+                                    contribution *= weight / ls.pdf;
+                                    if (finite3(contribution)) radiance += clampFireflyContribution(throughput, contribution, cp);
+                                }
+                            }
+                        }
+                    }
+                }
+
+                if (!surfaceIsDelta && envSampling) {  // environment NEE, E:2774-2811
+                    // draw into named locals: argument evaluation order is unspecified (quirk Q10);
+                    // the reference binary (Apple clang) evaluates left to right
+                    const float uMarginal = rng.nextFloat();
+                    const float uConditional = rng.nextFloat();
+                    const float uJitter = rng.nextFloat();
+                    const EnvSample es = sampleEnvironmentCpu(env->dist, uMarginal, uConditional, uJitter,
+                                                              settings.environmentRotation, settings.environmentIntensity, env->rgba);
+                    const float nDotL = std::max(dot(shadingNormal, es.direction), 0.0f);
+                    if (es.pdf > 0.0f && nDotL > 0.0f) {
+                        if (!occluded(offsetRayOrigin(hit, es.direction), es.direction, kInf)) {
+                            const V3 envRadiance = sampleEnvironment(*env, es.direction, settings.environmentRotation, settings.environmentIntensity);
+                            const BsdfEval be = evaluateBsdf(material, hit.position, shadingNormal, wo, es.direction, cp);
+                            if (!be.isDelta && be.pdf > 0.0f) {
+                                const float weight = es.pdf / (es.pdf + be.pdf);
+                                V3 contribution = (envRadiance * be.value) * nDotL;
+                                contribution *= weight / es.pdf;
+                                if (finite3(contribution)) radiance += clampFireflyContribution(throughput, contribution, cp);
+                            }
+                        }
+                    }
+                }
+
+                const BsdfSample bs = sampleBsdf(material, hit.position, shadingNormal, wo, incidentDir, hit.frontFace, rng, cp);
+                if (bs.pdf <= 0.0f || dot(bs.direction, bs.direction) <= 0.0f || !finite3(bs.weight)) break;
+
+                const uint32_t nextSpecularDepth = bs.isDelta ? (specularDepth + 1u) : 0u;
+                specularDepth = nextSpecularDepth;
+
+                const bool specDirectionValid = (dot(bs.direction, bs.direction) > 0.0f) && finite3(bs.direction);
+                const bool mneeEligible = settings.enableMnee && bs.isDelta && specDirectionValid &&
+                                          type == PTR_MAT_DIELECTRIC && nextSpecularDepth == 1u;
+                const bool specNeeEligible = settings.enableSpecularNee && bs.isDelta && specDirectionValid && !mneeEligible;
+
+                // Extra "NEE along the specular direction" rays.  The specular-NEE (E:2856-2917) and MNEE
+                // (E:2919-2980) blocks are the same computation behind different gates.
+                auto envAlong = [&](V3 origin, V3 dir, V3 weight, float bsdfPdfFloorInput) {
+                    if (occluded(origin, dir, kInf)) return;
+                    const float envPdf = std::max(environmentPdf(*env, settings.environmentRotation, dir), kSpecularNeePdfFloor);
+                    const float invEnvPdf = std::min(1.0f / envPdf, kSpecularNeeInvPdfClamp);
+                    const float bsdfPdf = std::max(bsdfPdfFloorInput, kSpecularNeePdfFloor);
+                    const float denom = envPdf + bsdfPdf;
+                    float misWeight = denom > 0.0f ? (envPdf / denom) : 0.0f;
+                    misWeight = clampf(misWeight, kMisWeightClampMin, kMisWeightClampMax);
+                    const V3 envColor = sampleEnvironment(*env, dir, settings.environmentRotation, settings.environmentIntensity);
+                    const V3 c = (weight * envColor) * (misWeight * invEnvPdf);
+                    if (finite3(c)) radiance += clampFireflyContribution(throughput, c, cp);
+                };
+                auto rectAlong = [&](V3 origin, V3 dir, V3 weight, float bsdfPdfFloorInput) {
+                    HitInfo lightHit;
+                    if (!trace(Ray{origin, dir}, lightHit)) return;
+                    RectLightHit rh;
+                    if (!rectLightHitInfo(lightIndexByRect, rectLights, rectangles, rectangleCount, env, settings, lightHit, origin, rh)) return;
+                    const float lightPdf = std::max(rh.pdf, kSpecularNeePdfFloor);
+                    const float invLightPdf = std::min(1.0f / lightPdf, kSpecularNeeInvPdfClamp);
+                    const float bsdfPdf = std::max(bsdfPdfFloorInput, kSpecularNeePdfFloor);
+                    const float denom = lightPdf + bsdfPdf;
+                    float misWeight = denom > 0.0f ? (lightPdf / denom) : 0.0f;
+                    misWeight = clampf(misWeight, kMisWeightClampMin, kMisWeightClampMax);
+                    const V3 c = (weight * rh.emission) * (misWeight * invLightPdf);
+                    if (finite3(c)) radiance += clampFireflyContribution(throughput, c, cp);
+                };
+
+                if (specNeeEligible || mneeEligible) {
+                    const V3 dir = normalize(bs.direction);
+                    const V3 origin = offsetRayOrigin(hit, dir);
+                    if (envSampling) envAlong(origin, dir, bs.weight, bs.pdf);
+                    if (rectLightCount > 0) rectAlong(origin, dir, bs.weight, bs.pdf);
+                }
+
+                if (mneeEligible && settings.enableMneeSecondary) {  // two-bounce specular chain, E:2982-3096
+                    const V3 chainDir = normalize(bs.direction);
+                    const Ray chainRay{offsetRayOrigin(hit, chainDir), chainDir};
+                    HitInfo chainHit;
+                    if (trace(chainRay, chainHit)) {
+                        bool chainHitIsLight = false;
+                        if (rectLightCount > 0) {
+                            RectLightHit tmp;
+                            chainHitIsLight = rectLightHitInfo(lightIndexByRect, rectLights, rectangles, rectangleCount, env, settings,
+                                                               chainHit, chainRay.origin, tmp);
+                        }
+                        if (!chainHitIsLight) {
+                            const PtrMaterial& chainMaterial = materials[std::min(chainHit.materialIndex, materialCount - 1)];
+                            if (materialIsDelta(chainMaterial)) {
+                                V3 chainNormal = chainHit.normal;
+                                if (dot(chainNormal, chainNormal) <= 0.0f) chainNormal = V3(0.0f, 1.0f, 0.0f);
+                                chainNormal = normalize(chainNormal);
+                                const V3 chainIncident = normalize(chainRay.direction);
+                                Rng chainRng = rng;  // copy: the main stream does not advance
+                                const BsdfSample cs = sampleBsdf(chainMaterial, chainHit.position, chainNormal, -chainIncident,
+                                                                 chainIncident, chainHit.frontFace, chainRng, cp);
+                                if (cs.pdf > 0.0f && cs.isDelta && dot(cs.direction, cs.direction) > 0.0f && finite3(cs.weight)) {
+                                    const V3 secondDir = normalize(cs.direction);
+                                    const V3 secondOrigin = offsetRayOrigin(chainHit, secondDir);
+                                    const V3 combinedWeight = bs.weight * cs.weight;
+                                    const float chainPdf = bs.pdf * cs.pdf;
+                                    if (envSampling) envAlong(secondOrigin, secondDir, combinedWeight, chainPdf);
+                                    if (rectLightCount > 0) rectAlong(secondOrigin, secondDir, combinedWeight, chainPdf);
+                                }
+                            }
+                        }
+                    }
+                }
+
+                throughput *= bs.weight;
+                throughput = clampPathThroughput(throughput, cp);
+                if (!finite3(throughput)) break;
+                const float maxComp = std::max(std::max(throughput.x, throughput.y), throughput.z);
+                if (maxComp <= 0.0f) break;
+
+                lastBsdfPdf = bs.pdf > 0.0f ? bs.pdf : lastBsdfPdf;
+                lastScatterWasDelta = bs.isDelta;
+                ray.origin = offsetRayOrigin(hit, bs.direction);
+                ray.direction = bs.direction;
+
+                if (settings.enableRussianRoulette && depth >= 5) {
+                    const float rrProb = clampf(maxComp, 0.05f, 0.95f);
+                    if (rng.nextFloat() > rrProb) break;
+                    throughput /= rrProb;
+                }
+            }
+            pixelRadiance += radiance;
+        }
+        if (counting) {
+            rc.nodes += tc.nodes;
+            rc.prims += tc.prims;
+        }
+        return pixelRadiance / static_cast<float>(targetSamples);
+    };
+
+    // 16x16 tiles pulled from an atomic counter by a std::thread pool (E:2538-2571, 3159-3187)
+    constexpr uint32_t kTile = 16u;
+    yEnd = std::min(yEnd, height);
+    const uint32_t tilesX = (width + kTile - 1u) / kTile;
+    const uint32_t tileY0 = yBegin / kTile, tileY1 = (yEnd + kTile - 1u) / kTile;
+    const uint32_t totalTiles = tilesX * (tileY1 > tileY0 ? tileY1 - tileY0 : 0u);
+    std::atomic<uint32_t> nextTile{0};
+    auto worker = [&]() {
+        RenderCounters rc;
+        while (true) {
+            const uint32_t tile = nextTile.fetch_add(1, std::memory_order_relaxed);
+            if (tile >= totalTiles) break;
+            const uint32_t ty = tileY0 + tile / tilesX, tx = tile % tilesX;
+            const uint32_t x0 = tx * kTile, x1 = std::min(x0 + kTile, width);
+            const uint32_t y0 = std::max(ty * kTile, yBegin), y1 = std::min(ty * kTile + kTile, yEnd);
+            for (uint32_t y = y0; y < y1; ++y) {
+                for (uint32_t x = x0; x < x1; ++x) {
+                    const V3 avg = renderPixel(x, y, rc);
+                    float* px = outRgb + (static_cast<size_t>(y) * width + x) * 3u;
+                    px[0] = avg.x;
+                    px[1] = avg.y;
+                    px[2] = avg.z;
+                }
+            }
+        }
+        if (counting) {
+            cExtend += rc.extendRays;
+            cShadow += rc.shadowRays;
+            cNodes += rc.nodes;
+            cPrims += rc.prims;
+            cShaded += rc.shadedHits;
+            cTri += rc.triangleHits;
+        }
+    };
+    uint32_t workerCount = threads;
+    if (workerCount == 0) workerCount = std::max(1u, std::thread::hardware_concurrency());
+    if (workerCount == 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (uint32_t i = 0; i < workerCount; ++i) pool.emplace_back(worker);
+        for (auto& t : pool) t.join();
+    }
+    if (outCounters) {
+        outCounters->extendRays = cExtend;
+        outCounters->shadowRays = cShadow;
+        outCounters->nodes = cNodes;
+        outCounters->prims = cPrims;
+        outCounters->shadedHits = cShaded;
+        outCounters->triangleHits = cTri;
+    }
+}
+
+}  // namespace oracle
