@@ -1,0 +1,30 @@
+/*
+ * ptr_debug.h — test-only entry points of libptr_hip.so: run single device functions of the integrator on a
+ * batch of inputs so the parity tests can compare them with the oracle function by function
+ * (SURVEY.md section 8(c) "fixtures": Rng::Hash, BuildCamera/GenerateCameraRay, EvaluateBsdf, SampleBsdf).
+ * Reference twins: src/headless/EmbreeHeadlessRenderer.mm 52-68, 150-232, 1315-1491, 1493-1918.
+ */
+#ifndef PTR_DEBUG_H
+#define PTR_DEBUG_H
+
+#include "ptr_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* in: n*12 floats {position, normal, wo, wi}; out: n*5 floats {value rgb, pdf, isDelta} */
+int ptr_debug_eval_bsdf(const PtrMaterial* material, const PtrSettings* settings, const float* in, uint64_t n,
+                        float* out, char* err, size_t err_cap);
+/* in: n*9 floats {position, normal, wo} (incident = -wo); out: n*8 floats {direction, weight, pdf, isDelta} */
+int ptr_debug_sample_bsdf(const PtrMaterial* material, const PtrSettings* settings, const float* in,
+                          const uint32_t* front_face, const uint32_t* rng_states, uint64_t n, float* out,
+                          uint32_t* out_states, char* err, size_t err_cap);
+/* xys: n*3 {x, y, sample}; out: n*6 floats {origin, direction}; out_states: rng state after ray generation */
+int ptr_debug_camera_rays(const PtrSettings* settings, const uint32_t* xys, uint64_t n, float* out,
+                          uint32_t* out_states, char* err, size_t err_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTR_DEBUG_H */

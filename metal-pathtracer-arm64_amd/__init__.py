@@ -191,6 +191,8 @@ ABI_SYMBOLS = (
     "ptr_host_scene_load", "ptr_host_scene_free", "ptr_host_scene_desc", "ptr_host_write_image",
     "ptr_host_read_pfm", "ptr_version",
 )
+# include/ptr_debug.h (test-only device-function probes)
+DEBUG_SYMBOLS = ("ptr_debug_eval_bsdf", "ptr_debug_sample_bsdf", "ptr_debug_camera_rays")
 
 _lib: Optional[C.CDLL] = None
 
@@ -230,6 +232,10 @@ def load_library() -> C.CDLL:
                                          C.c_float, cp, sz]
     lib.ptr_host_read_pfm.argtypes = [cp, C.POINTER(C.c_float), u32, C.POINTER(u32), C.POINTER(u32)]
     lib.ptr_version.restype = cp
+    fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    lib.ptr_debug_eval_bsdf.argtypes = [C.POINTER(PtrMaterial), C.POINTER(PtrSettings), fp, u64, fp, cp, sz]
+    lib.ptr_debug_sample_bsdf.argtypes = [C.POINTER(PtrMaterial), C.POINTER(PtrSettings), fp, up, up, u64, fp, up, cp, sz]
+    lib.ptr_debug_camera_rays.argtypes = [C.POINTER(PtrSettings), up, u64, fp, up, cp, sz]
     _lib = lib
     return lib
 
@@ -411,3 +417,43 @@ def read_pfm(path: str) -> np.ndarray:
     if lib.ptr_host_read_pfm(os.fsencode(path), _fptr(out), out.size, C.byref(w), C.byref(h)) != 0:
         raise PtrError(f"cannot read PFM data: {path}")
     return out
+
+
+# ----------------------------------------------------------------------------- device-function probes (tests)
+
+
+def _uptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def debug_eval_bsdf(material: PtrMaterial, settings: PtrSettings, inputs: np.ndarray) -> np.ndarray:
+    inputs = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, 12)
+    out = np.zeros((inputs.shape[0], 5), dtype=np.float32)
+    err = _err_buf()
+    _check(load_library().ptr_debug_eval_bsdf(C.byref(material), C.byref(settings), _fptr(inputs), inputs.shape[0],
+                                             _fptr(out), err, len(err)), err)
+    return out
+
+
+def debug_sample_bsdf(material: PtrMaterial, settings: PtrSettings, inputs: np.ndarray, front: np.ndarray,
+                      states: np.ndarray):
+    inputs = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, 9)
+    front = np.ascontiguousarray(front, dtype=np.uint32)
+    states = np.ascontiguousarray(states, dtype=np.uint32)
+    out = np.zeros((inputs.shape[0], 8), dtype=np.float32)
+    out_states = np.zeros(inputs.shape[0], dtype=np.uint32)
+    err = _err_buf()
+    _check(load_library().ptr_debug_sample_bsdf(C.byref(material), C.byref(settings), _fptr(inputs), _uptr(front),
+                                               _uptr(states), inputs.shape[0], _fptr(out), _uptr(out_states), err,
+                                               len(err)), err)
+    return out, out_states
+
+
+def debug_camera_rays(settings: PtrSettings, xys: np.ndarray):
+    xys = np.ascontiguousarray(xys, dtype=np.uint32).reshape(-1, 3)
+    out = np.zeros((xys.shape[0], 6), dtype=np.float32)
+    states = np.zeros(xys.shape[0], dtype=np.uint32)
+    err = _err_buf()
+    _check(load_library().ptr_debug_camera_rays(C.byref(settings), _uptr(xys), xys.shape[0], _fptr(out), _uptr(states),
+                                               err, len(err)), err)
+    return out, states

@@ -21,6 +21,7 @@
 #include "bvh_builder.h"
 #include "env_importance_sampler.h"
 #include "ptr_abi.h"
+#include "ptr_debug.h"
 #include "vecmath.h"
 
 using namespace ptrk;
@@ -176,6 +177,18 @@ namespace {
 
 constexpr uint32_t kAliveRing = 16;   // scalars[0] = shadow count, scalars[1..16] = alive counters
 
+// 576 B MaterialData -> the 12 float4 the integrator reads (kernels/device_types.h MaterialSlot).
+void compactMaterial(const PtrMaterial& m, std::vector<float>& out) {
+    const float* rows[kMaterialVec4] = {m.baseColorRoughness, m.typeEta,        m.emission,           m.conductorEta,
+                                        m.conductorK,         m.coatParams,     m.coatTint,           m.coatAbsorption,
+                                        m.carpaintBaseParams, m.carpaintFlakeParams, m.carpaintBaseEta, m.carpaintBaseK};
+    for (uint32_t r = 0; r < kMaterialVec4; ++r) {
+        float v[4] = {rows[r][0], rows[r][1], rows[r][2], rows[r][3]};
+        if (r == kMatCoatTint) v[3] = m.pbrParams[0];   // PBR metallic rides in the free w lane
+        out.insert(out.end(), v, v + 4);
+    }
+}
+
 void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<HostTri> tris;
@@ -283,17 +296,7 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     // compact materials
     std::vector<float> mats;
     mats.reserve(static_cast<size_t>(desc.materialCount) * kMaterialVec4 * 4);
-    for (uint32_t i = 0; i < desc.materialCount; ++i) {
-        const PtrMaterial& m = desc.materials[i];
-        const float* rows[kMaterialVec4] = {m.baseColorRoughness, m.typeEta,        m.emission,           m.conductorEta,
-                                            m.conductorK,         m.coatParams,     m.coatTint,           m.coatAbsorption,
-                                            m.carpaintBaseParams, m.carpaintFlakeParams, m.carpaintBaseEta, m.carpaintBaseK};
-        for (uint32_t r = 0; r < kMaterialVec4; ++r) {
-            float v[4] = {rows[r][0], rows[r][1], rows[r][2], rows[r][3]};
-            if (r == kMatCoatTint) v[3] = m.pbrParams[0];   // PBR metallic rides in the free w lane
-            mats.insert(mats.end(), v, v + 4);
-        }
-    }
+    for (uint32_t i = 0; i < desc.materialCount; ++i) compactMaterial(desc.materials[i], mats);
 
     // rectangle lights: DiffuseLight rectangles with non-zero emission (:2484-2522)
     std::vector<float> lights;
@@ -773,6 +776,84 @@ int ptr_trace_rays(PtrDeviceScene* scene, const float* rays, uint64_t n, int any
             stats->extendRays = any_hit ? 0 : n;
             stats->shadowRays = any_hit ? n : 0;
         }
+        return 0;
+    } catch (const HipError& e) {
+        setErr(err, err_cap, e.message);
+        return 1;
+    }
+}
+
+// ---- test-only entry points (include/ptr_debug.h) ----
+
+int ptr_debug_eval_bsdf(const PtrMaterial* material, const PtrSettings* settings, const float* in, uint64_t n, float* out,
+                        char* err, size_t err_cap) {
+    try {
+        if (ptr_device_count() < 1) throw HipError{"no HIP device (the HIP path has no CPU fallback)"};
+        HIP_CHECK(hipSetDevice(0));
+        std::vector<float> m;
+        compactMaterial(*material, m);
+        RenderParams rp;
+        fillRenderParams(*settings, 1, rp);
+        DeviceBuffer<float4> dm;
+        DeviceBuffer<float> din, dout;
+        dm.upload(reinterpret_cast<const float4*>(m.data()), kMaterialVec4);
+        din.upload(in, n * 12);
+        dout.ensure(n * 5);
+        launchDebugEvalBsdf(dm.ptr, rp, din.ptr, n, dout.ptr, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(out, dout.ptr, n * 5 * sizeof(float), hipMemcpyDeviceToHost));
+        return 0;
+    } catch (const HipError& e) {
+        setErr(err, err_cap, e.message);
+        return 1;
+    }
+}
+
+int ptr_debug_sample_bsdf(const PtrMaterial* material, const PtrSettings* settings, const float* in, const uint32_t* front_face,
+                          const uint32_t* rng_states, uint64_t n, float* out, uint32_t* out_states, char* err, size_t err_cap) {
+    try {
+        if (ptr_device_count() < 1) throw HipError{"no HIP device (the HIP path has no CPU fallback)"};
+        HIP_CHECK(hipSetDevice(0));
+        std::vector<float> m;
+        compactMaterial(*material, m);
+        RenderParams rp;
+        fillRenderParams(*settings, 1, rp);
+        DeviceBuffer<float4> dm;
+        DeviceBuffer<float> din, dout;
+        DeviceBuffer<uint32_t> dfront, drng, drngOut;
+        dm.upload(reinterpret_cast<const float4*>(m.data()), kMaterialVec4);
+        din.upload(in, n * 9);
+        dfront.upload(front_face, n);
+        drng.upload(rng_states, n);
+        dout.ensure(n * 8);
+        drngOut.ensure(n);
+        launchDebugSampleBsdf(dm.ptr, rp, din.ptr, dfront.ptr, drng.ptr, n, dout.ptr, drngOut.ptr, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(out, dout.ptr, n * 8 * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(out_states, drngOut.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        return 0;
+    } catch (const HipError& e) {
+        setErr(err, err_cap, e.message);
+        return 1;
+    }
+}
+
+int ptr_debug_camera_rays(const PtrSettings* settings, const uint32_t* xys, uint64_t n, float* out, uint32_t* out_states,
+                          char* err, size_t err_cap) {
+    try {
+        if (ptr_device_count() < 1) throw HipError{"no HIP device (the HIP path has no CPU fallback)"};
+        HIP_CHECK(hipSetDevice(0));
+        RenderParams rp;
+        fillRenderParams(*settings, 1, rp);
+        DeviceBuffer<uint32_t> dxy, drng;
+        DeviceBuffer<float> dout;
+        dxy.upload(xys, n * 3);
+        dout.ensure(n * 6);
+        drng.ensure(n);
+        launchDebugCameraRays(rp, dxy.ptr, n, dout.ptr, drng.ptr, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(out, dout.ptr, n * 6 * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(out_states, drng.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
         return 0;
     } catch (const HipError& e) {
         setErr(err, err_cap, e.message);

@@ -1,0 +1,297 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle on the same seeded inputs.
+
+Tolerances (floating-point path; north star: "within the repo's own RMSE threshold on linear PFM"; the reference
+publishes no number, so SURVEY.md section 8(d) defines them):
+  * ray queries:   t within max(1e-3, 1e-4*t) and same primitive except ties — the reference's own HWRT/SWRT
+                   parity thresholds (shaders/pathtrace.metal:6813-6837).  In practice t is bit-identical.
+  * device functions (camera, BSDF eval/sample): relative 2e-4 (libm vs ocml sin/cos/exp differ in the last ulps),
+                   RNG state after sampling identical (same number of draws).
+  * images:        deterministic-stream check at low spp (fraction of pixels within 1e-3 relative), and
+                   RMSE(build, oracle) <= 1.25 * N with N = RMSE(oracle seed 1337, oracle seed 1338), mean ratio 0.5 %.
+"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pt = importlib.import_module("metal-pathtracer-arm64_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SCENES = os.path.join(ROOT, "scenes")
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.abs(a - b) / (np.abs(b) + 1e-2)
+
+
+def _rmse(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def _random_rays(n, lo, hi, seed, finite_fraction=0.3):
+    rng = np.random.default_rng(seed)
+    org = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tmax = np.where(rng.random(n) < finite_fraction, rng.uniform(0.1 * (hi - lo), hi - lo, n), np.inf).astype(np.float32)
+    return np.concatenate([org, np.full((n, 1), 1e-4, np.float32), d, tmax[:, None]], axis=1).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def cornell_small():
+    host = pt.HostScene.load(os.path.join(GOLDEN, "cornell_small_mesh.scene"), SCENES)
+    return host, pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
+
+
+@pytest.fixture(scope="module")
+def materials_scene():
+    host = pt.HostScene.load(os.path.join(GOLDEN, "materials.scene"))
+    return host, pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
+
+
+# --------------------------------------------------------------------------- ray level
+@pytest.mark.parametrize("any_hit", [False, True])
+def test_ray_queries_match_oracle(cornell_small, any_hit):
+    host, dev, osc = cornell_small
+    rays = _random_rays(50000, 5.0, 550.0, 11)
+    g, stats = dev.trace_rays(rays, any_hit=any_hit)
+    o = osc.trace_rays(rays, any_hit=any_hit)
+    assert np.array_equal(g["t"] >= 0, o["t"] >= 0)
+    if not any_hit:
+        hit = o["t"] >= 0
+        assert hit.mean() > 0.5
+        tol = np.maximum(1e-3, 1e-4 * o["t"][hit])
+        assert (np.abs(g["t"][hit] - o["t"][hit]) <= tol).all()
+        assert np.array_equal(g["t"], o["t"])                       # in fact bit-identical
+        same = (g["primType"][hit] == o["primType"][hit]) & (g["primIndex"][hit] == o["primIndex"][hit]) & \
+               (g["geomIndex"][hit] == o["geomIndex"][hit])
+        assert same.mean() > 0.999                                  # ties on shared edges may pick the other triangle
+        assert np.allclose(g["u"][hit][same], o["u"][hit][same], atol=1e-6)
+        tri = same & (o["primType"][hit] != 1)                      # spheres: the integrator recomputes the normal
+        assert np.allclose(g["ng"][hit][tri], o["ng"][hit][tri], rtol=1e-6, atol=1e-6)
+    assert stats.nodesVisited > 0 and stats.leafPrimTests > 0
+
+
+def test_ray_queries_spheres_and_empty_and_degenerate(materials_scene):
+    host, dev, osc = materials_scene
+    rays = _random_rays(20000, -6.0, 6.0, 5)
+    rays[:, 1] = np.abs(rays[:, 1]) + 0.05
+    g, _ = dev.trace_rays(rays)
+    o = osc.trace_rays(rays)
+    assert np.array_equal(g["t"], o["t"]) and np.array_equal(g["primType"], o["primType"]) and np.array_equal(g["primIndex"], o["primIndex"])
+    assert (o["primType"][o["t"] >= 0] == 1).any() and (o["primType"][o["t"] >= 0] == 2).any()
+    # empty batch and axis-aligned directions (zero components -> infinite reciprocals)
+    e, _ = dev.trace_rays(np.zeros((0, 8), np.float32))
+    assert e.shape == (0,)
+    axis = np.array([[0, 5, 0, 1e-4, 0, -1, 0, np.inf], [-3.6, 0.6, 5, 1e-4, 0, 0, -1, np.inf], [50, 0.6, 0, 1e-4, -1, 0, 0, np.inf]], np.float32)
+    ga, _ = dev.trace_rays(axis)
+    oa = osc.trace_rays(axis)
+    assert np.array_equal(ga["t"], oa["t"]) and (ga["t"] > 0).all()
+
+
+def test_large_mesh_bvh_depth_and_parity():
+    host = pt.HostScene.load(os.path.join(SCENES, "cornell_mesh.scene"), SCENES)
+    dev = pt.DeviceScene(host.desc, 0, keepalive=host)
+    info = dev.info()
+    assert info["triangles"] == 70688 + 12 and info["max_depth"] < 48 and info["max_leaf"] <= 4 and info["rect_lights"] == 1
+    osc = ol.OracleScene(host)
+    rays = _random_rays(30000, 5.0, 550.0, 3, finite_fraction=0.0)
+    g, stats = dev.trace_rays(rays)
+    o = osc.trace_rays(rays)
+    assert np.array_equal(g["t"], o["t"])
+    assert 5 < stats.nodesVisited / len(rays) < 200
+
+
+# --------------------------------------------------------------------------- device functions
+def test_camera_rays_match_oracle():
+    host = pt.HostScene.load(os.path.join(SCENES, "cornell.scene"))
+    for defocus in (0.0, 2.5):
+        s = host.settings_for(width=320, height=200, cameraDefocusAngle=defocus, cameraFocusDistance=900.0)
+        rng = np.random.default_rng(0)
+        xys = np.stack([rng.integers(0, 320, 4096), rng.integers(0, 200, 4096), rng.integers(0, 64, 4096)], axis=1).astype(np.uint32)
+        g, gs = pt.debug_camera_rays(s, xys)
+        o, os_ = ol.camera_rays(s, xys)
+        assert np.array_equal(gs, os_)                              # same number of draws (lens rejection loop included)
+        assert np.array_equal(g[:, :3], o[:, :3]) or np.allclose(g[:, :3], o[:, :3], rtol=1e-6, atol=1e-4)
+        assert np.allclose(g[:, 3:], o[:, 3:], atol=2e-6)
+
+
+def _bsdf_inputs(n, seed):
+    rng = np.random.default_rng(seed)
+
+    def hemi(k, zmin):
+        v = rng.normal(size=(k, 3))
+        v[:, 2] = np.abs(v[:, 2]) + zmin
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+    normal = np.tile(np.array([0, 0, 1], np.float32), (n, 1))
+    pos = rng.uniform(-2, 2, size=(n, 3)).astype(np.float32)
+    states = rng.integers(1, 2**32 - 1, size=n, dtype=np.uint64).astype(np.uint32)
+    return pos, normal, hemi(n, 0.05), hemi(n, 0.05), states
+
+
+def _all_materials(host):
+    mats = [(int(host.desc.materials[i].typeEta[0]), host.desc.materials[i]) for i in range(host.desc.materialCount)]
+    pbr = []
+    for metallic, rough in ((0.0, 0.6), (1.0, 0.3), (0.5, 0.0)):
+        m = pt.PtrMaterial.from_buffer_copy(bytes(host.desc.materials[0]))
+        m.typeEta[0] = 7.0
+        m.typeEta[1] = 1.5
+        m.baseColorRoughness[3] = rough
+        m.pbrParams[0] = metallic
+        pbr.append((7, m))
+    return mats + pbr
+
+
+def test_eval_bsdf_matches_oracle(materials_scene):
+    host, _, _ = materials_scene
+    s = host.settings_for(width=16, height=16)
+    pos, normal, wo, wi, _ = _bsdf_inputs(4096, 21)
+    inp = np.concatenate([pos, normal, wo, wi], axis=1)
+    for mtype, mat in _all_materials(host):
+        g = pt.debug_eval_bsdf(mat, s, inp)
+        o = ol.eval_bsdf(mat, s, inp)
+        assert np.array_equal(g[:, 4], o[:, 4]), mtype
+        assert np.allclose(g[:, :4], o[:, :4], rtol=2e-4, atol=1e-6), mtype
+
+
+def test_sample_bsdf_matches_oracle(materials_scene):
+    host, _, _ = materials_scene
+    s = host.settings_for(width=16, height=16)
+    pos, normal, wo, _, states = _bsdf_inputs(4096, 22)
+    inp = np.concatenate([pos, normal, wo], axis=1)
+    for front_value in (1, 0):
+        front = np.full(len(pos), front_value, np.uint32)
+        for mtype, mat in _all_materials(host):
+            g, gs = pt.debug_sample_bsdf(mat, s, inp, front, states)
+            o, os_ = ol.sample_bsdf(mat, s, inp, front, states)
+            assert np.array_equal(gs, os_), mtype                   # identical RNG consumption
+            # a sin/cos ulp can flip a discrete choice (valid <-> rejected) in a handful of samples
+            agree = (g[:, 6] > 0) == (o[:, 6] > 0)
+            assert agree.mean() > 0.998, mtype
+            both = agree & (o[:, 6] > 0)
+            close = np.isclose(g[both], o[both], rtol=5e-4, atol=2e-5).all(axis=1)
+            # narrow GGX lobes (car-paint flakes: alpha ~ 0.02) amplify last-ulp differences of the half vector
+            assert close.mean() > (0.985 if mtype == 6 else 0.995), (mtype, close.mean())
+            assert np.isclose(g[both], o[both], rtol=5e-2, atol=1e-3).all(axis=1).mean() > 0.999, mtype
+
+
+# --------------------------------------------------------------------------- image level
+def _image_parity(host, dev, osc, width, height, depth, low_spp, high_spp, min_fraction, **overrides):
+    s = host.settings_for(width=width, height=height, max_depth=depth, seed=1337, **overrides)
+    img1, st1 = dev.render_image(s, low_spp, count=True)
+    ref1, _, c1 = osc.render(s, low_spp, threads=0, count=True)
+    assert img1.shape == ref1.shape and np.isfinite(img1).all() and img1.min() >= 0
+    frac = float((_rel(img1, ref1).max(axis=2) <= 1e-3).mean())
+    # same stream => (almost) the same number of rays, hits and mesh hits
+    assert abs(st1.extendRays - c1["extendRays"]) <= 0.002 * c1["extendRays"] + 2
+    assert abs(st1.shadedHits - c1["shadedHits"]) <= 0.002 * c1["shadedHits"] + 2
+    assert frac >= min_fraction, frac
+    imgN, _ = dev.render_image(s, high_spp)
+    refN, _, _ = osc.render(s, high_spp, threads=0)
+    s2 = s.copy()
+    s2.seed = 1338
+    refM, _, _ = osc.render(s2, high_spp, threads=0)
+    noise = _rmse(refN, refM)
+    err = _rmse(imgN, refN)
+    lum = np.array([0.2126, 0.7152, 0.0722])
+    ratio = float((imgN @ lum).mean() / (refN @ lum).mean())
+    assert err <= 1.25 * noise, (err, noise)
+    assert abs(ratio - 1.0) <= 0.005, ratio
+    return frac, err, noise, ratio
+
+
+def test_smoke_scene_image_parity():
+    # the reference's smoke render (64x64, 4 spp, depth 4, seed 1337): no lights, solid background
+    host = pt.HostScene.load(os.path.join(GOLDEN, "smoke.scene"))
+    dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
+    frac, err, noise, _ = _image_parity(host, dev, osc, 64, 64, 4, 4, 64, 0.97)
+    assert err < 0.25 * noise            # far below the noise floor: the streams are the same
+
+
+def test_cornell_image_parity(cornell_small):
+    host, dev, osc = cornell_small
+    _image_parity(host, dev, osc, 64, 64, 4, 1, 64, 0.93)
+    _image_parity(host, dev, osc, 80, 48, 8, 1, 32, 0.90)
+
+
+def test_materials_image_parity_with_and_without_specular_nee(materials_scene):
+    host, dev, osc = materials_scene
+    _image_parity(host, dev, osc, 96, 64, 6, 1, 32, 0.90)
+    _image_parity(host, dev, osc, 96, 64, 6, 1, 16, 0.90, enableSpecularNee=0, enableRussianRoulette=0)
+    _image_parity(host, dev, osc, 96, 64, 12, 1, 16, 0.88, fireflyClampEnabled=0)
+
+
+def test_gradient_sky_and_thin_lens(materials_scene):
+    host, dev, osc = materials_scene
+    _image_parity(host, dev, osc, 64, 48, 5, 1, 16, 0.90, backgroundMode=0, cameraDefocusAngle=1.5, cameraFocusDistance=8.0)
+
+
+def test_mnee_modes(tmp_path):
+    text = ("camera target=0,1,0 distance=7 yaw=1.0 pitch=0.4 vfov=40\nrenderer maxDepth=6 seed=3 enableMnee=1\nbackground solid=0.05,0.05,0.08\n"
+            "material type=lambert albedo=0.7,0.7,0.7\nmaterial type=dielectric ior=1.5\nmaterial type=light emit=20,18,15\n"
+            "rectangle x=-6,6 y=0 z=-6,6 normal=1 material=0\nsphere center=0,1,0 radius=1 material=1\nsphere center=2.2,0.7,0.5 radius=0.7 material=1\n"
+            "rectangle x=-1,1 y=5 z=-1,1 normal=-1 material=2\n")
+    p = tmp_path / "mnee.scene"
+    p.write_text(text)
+    host = pt.HostScene.load(str(p))
+    dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
+    _image_parity(host, dev, osc, 64, 48, 6, 1, 32, 0.90, enableMnee=1, enableMneeSecondary=1)
+    _image_parity(host, dev, osc, 64, 48, 6, 1, 16, 0.90, enableMnee=1, enableMneeSecondary=0)
+
+
+def test_partition_and_pool_size_invariance(cornell_small):
+    host, dev, _ = cornell_small
+    s = host.settings_for(width=72, height=56, max_depth=5)
+    full, _ = dev.render_image(s, 6)
+    for parts in (2, 3):
+        pieces = [dev.render(s, 6, p, parts)[0] for p in range(parts)]
+        assert np.array_equal(pt.assemble_bands(pieces, 72, 56), full)      # bit-identical under any partition
+    again, _ = dev.render_image(s, 6)
+    assert np.array_equal(again, full)                                       # and run to run
+
+
+def test_edge_cases(cornell_small, tmp_path):
+    host, dev, osc = cornell_small
+    # depth 1: only directly visible emission / background
+    s = host.settings_for(width=32, height=32, max_depth=1)
+    img, _ = dev.render_image(s, 2)
+    ref, _, _ = osc.render(s, 2, threads=0)
+    assert np.allclose(img, ref, rtol=1e-5, atol=1e-6)
+    # ragged size (not a multiple of 8 or 16) and spp smaller than the slots-per-pixel target
+    s = host.settings_for(width=37, height=21, max_depth=3)
+    img, st = dev.render_image(s, 1)
+    ref, _, _ = osc.render(s, 1, threads=0)
+    assert img.shape == (21, 37, 3) and st.samples == 37 * 21
+    assert (_rel(img, ref).max(axis=2) <= 1e-3).mean() > 0.9
+    # empty scene: every ray escapes to the sky gradient
+    p = tmp_path / "empty.scene"
+    p.write_text("camera target=0,0,0 distance=3 yaw=0.3 pitch=0.1 vfov=60\n")
+    eh = pt.HostScene.load(str(p))
+    ed = pt.DeviceScene(eh.desc, 0, keepalive=eh)
+    es = eh.settings_for(width=24, height=16, max_depth=3)
+    img, _ = ed.render_image(es, 2)
+    ref, _, _ = ol.OracleScene(eh).render(es, 2, threads=1)
+    assert np.allclose(img, ref, rtol=1e-5, atol=1e-6) and img.min() > 0.4
+
+
+def test_cli_smoke_script_equivalent(tmp_path):
+    # tests/public/headless_smoke_test.sh:33-62 — same flags, passes iff the output file is non-empty
+    import subprocess
+
+    out = tmp_path / "smoke.ppm"
+    r = subprocess.run([pt.CLI_PATH, "--scene=" + os.path.join(GOLDEN, "smoke.scene"), "--width=64", "--height=64", "--sppTotal=4",
+                        "--maxDepth=4", "--seed=1337", "--enableSoftwareRayTracing=1", "--format=ppm", "--output=" + str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out.stat().st_size == len(b"P6\n64 64\n255\n") + 64 * 64 * 3
+    assert "Rendered 4 spp at 64x64" in r.stdout
+    exr = tmp_path / "smoke.exr"
+    r = subprocess.run([pt.CLI_PATH, "--scene", os.path.join(GOLDEN, "smoke.scene"), "--sppTotal=4", "--seed=1337", "--rgbaExr=1", "--output", str(exr)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and exr.stat().st_size == 66925       # the byte count the paper publishes

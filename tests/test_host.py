@@ -1,0 +1,288 @@
+"""CPU tests of the host layer and of the C-ABI surface (no GPU, no compute calls on the device path)."""
+import ctypes as C
+import importlib
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+pt = importlib.import_module("metal-pathtracer-arm64_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _write(tmp_path, text, name="t.scene"):
+    p = tmp_path / name
+    p.write_text(text)
+    return str(p)
+
+
+# --------------------------------------------------------------------------- ABI surface
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "ptr_abi.h")).read()
+    declared = set(re.findall(r"\b(ptr_[a-z_]+)\s*\(", header))
+    assert declared == set(pt.ABI_SYMBOLS)
+    debug = set(re.findall(r"\b(ptr_[a-z_]+)\s*\(", open(os.path.join(ROOT, "include", "ptr_debug.h")).read()))
+    assert debug == set(pt.DEBUG_SYMBOLS)
+    declared |= debug
+    lib = pt.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ptr_version().startswith(b"ptr-hip")
+
+
+def test_struct_layouts_match_reference_contract():
+    assert C.sizeof(pt.PtrSphere) == 32 and C.sizeof(pt.PtrRect) == 80 and C.sizeof(pt.PtrMaterial) == 576
+    assert pt.PtrMaterial.pbrParams.offset == 19 * 16 + 16      # 17 float4 + 2 uint4 + 4 u32
+    assert pt.PtrMaterial.textureTransform.offset == 576 - 12 * 16
+
+
+def test_device_path_fails_loudly_without_gpu():
+    if pt.device_count() > 0:
+        pytest.skip("a GPU is present")
+    host = pt.HostScene.load(os.path.join(GOLDEN, "smoke.scene"))
+    with pytest.raises(pt.PtrError, match="no HIP device|no such HIP device"):
+        pt.DeviceScene(host.desc)
+    out = np.zeros((64, 64, 3), np.float32)
+    err = C.create_string_buffer(256)
+    s = host.settings_for(64, 64)
+    rc = pt.load_library().ptr_render(C.byref(host.desc), C.byref(s), 1, 0, out.ctypes.data_as(C.POINTER(C.c_float)), None, err, 256)
+    assert rc != 0 and b"no CPU fallback" in err.value and not out.any()
+
+
+def test_band_partition_counts():
+    for height in (8, 16, 17, 64, 1080, 2160):
+        bands = (height + 15) // 16
+        for parts in (1, 2, 3, 8):
+            counts = [pt.band_count(height, p, parts) for p in range(parts)]
+            assert sum(counts) == bands and max(counts) - min(counts) <= 1
+    assert pt.band_count(1080, 8, 8) == 0
+
+
+# --------------------------------------------------------------------------- scene grammar
+def test_smoke_scene_parses_like_the_reference_fixture():
+    host = pt.HostScene.load(os.path.join(GOLDEN, "smoke.scene"))
+    d, s = host.desc, host.settings
+    assert (d.sphereCount, d.materialCount, d.rectCount, d.meshCount) == (2, 2, 0, 0)
+    assert (s.width, s.height, s.maxDepth) == (64, 64, 4)
+    assert s.backgroundMode == 1 and np.allclose(list(s.backgroundColor), [0.7, 0.8, 1.0])
+    assert np.allclose(list(s.cameraTarget), [0, 0, -1]) and s.cameraDistance == 3.5 and s.cameraVerticalFov == 45
+    assert s.cameraFocusDistance == 3.5
+    assert np.allclose(list(d.spheres[1].centerRadius), [0, -100.5, -1, 100]) and d.spheres[1].materialIndex[0] == 1
+    m = d.materials[0]
+    assert m.typeEta[0] == 0 and np.allclose(list(m.baseColorRoughness), [0.8, 0.3, 0.3, 0.0])
+    # renderer defaults that a scene file does not touch
+    assert s.enableRussianRoulette == 1 and s.enableSpecularNee == 1 and s.enableMnee == 0 and s.enableMneeSecondary == 1
+    assert (s.fireflyClampEnabled, s.fireflyClampFactor, s.fireflyClampFloor, s.throughputClamp) == (1, 32.0, 4.0, 32.0)
+
+
+def test_scene_defaults_size_and_gradient_background(tmp_path):
+    host = pt.HostScene.load(_write(tmp_path, "material type=lambert\nsphere center=0,0,0 radius=1 material=0\n"))
+    assert host.settings.width == 0 and host.settings.height == 0 and host.settings.backgroundMode == 0
+    s = host.settings_for()
+    assert (s.width, s.height, s.maxDepth) == (1280, 720, 50)   # CLI defaults (main_headless.mm:510-515), maxDepth 50
+
+
+def test_grammar_comments_continuations_unknowns(tmp_path):
+    text = (
+        "# My Scene\n"
+        "camera target=1,2,3 \\\n   distance=5 bogus=1 bareword\n"
+        "unknowndirective a=b\n"
+        "renderer maxDepth=7 envRotation=90 seed=42 russianRoulette=0 width=4 height=5\n"
+        "material type=GLASS ior=1.33 sigmaA=1,2,3\n"
+        "material type=light emit=1,2,3 emitEnv=1 name=L\n"
+        "rect x=0,2 y=1 z=0,4 normal=-1 twoSided=1 material=1\n"
+    )
+    host = pt.HostScene.load(_write(tmp_path, text))
+    s, d = host.settings, host.desc
+    assert np.allclose(list(s.cameraTarget), [1, 2, 3]) and s.cameraDistance == 5
+    assert s.maxDepth == 7 and s.seed == 42 and s.enableRussianRoulette == 0
+    assert s.environmentRotation == pytest.approx(np.pi / 2, rel=1e-6)
+    assert (s.width, s.height) == (8, 8)                         # renderer width/height are clamped to >= 8
+    g = d.materials[0]
+    assert g.typeEta[0] == 2 and g.typeEta[1] == pytest.approx(1.33) and np.allclose(list(g.dielectricSigmaA)[:3], [1, 2, 3])
+    light = d.materials[1]
+    assert light.typeEta[0] == 3 and light.typeEta[1] == 1.0 and light.emission[3] == 1.0
+    r = d.rects[0]
+    assert np.allclose(list(r.normalAndPlane), [0, -1, 0, -1]) and r.materialTwoSided[1] == 1
+    assert np.allclose(list(r.corner)[:3], [0, 1, 4]) and np.allclose(list(r.edgeU)[:3], [2, 0, 0]) and np.allclose(list(r.edgeV)[:3], [0, 0, -4])
+    assert r.edgeU[3] == pytest.approx(0.25) and r.edgeV[3] == pytest.approx(1 / 16)
+
+
+@pytest.mark.parametrize(
+    "line, message",
+    [
+        ("sphere center=0,0,0 radius=1 material=0", "line 1: sphere references material index that has not been defined yet"),
+        ("material albedo=1,1,1", "line 1: material requires a type token"),
+        ("material type=wood", "line 1: material type is not recognized"),
+        ("material type=lambert\nrectangle x=0,1 y=0,1 z=0,1 material=0", "line 2: rectangle requires exactly one axis to be fixed to a single value"),
+        ("material type=lambert\nrectangle x=0,1 y=0 material=0", "line 2: rectangle requires z token"),
+        ("material type=lambert\nbox min=0,0,0 material=0", "line 2: box requires min, max, and material tokens"),
+        ("background solid=1,1,1 env=a.hdr", "line 1: background cannot specify both solid and env"),
+        ("background env=missing.hdr", "background env map not found"),
+        ("material type=sss sigma_a=1,1,1", "line 1: material sigma_a and sigma_s must both be provided together"),
+        ("material type=lambert\nmesh path=nope.obj material=0", "mesh file not found"),
+        ("material type=lambert\nmesh type=plane", "line 2: mesh requires material token"),
+        ("camera distance=abc", "line 1: camera distance expects a float"),
+    ],
+)
+def test_parse_errors(tmp_path, line, message):
+    with pytest.raises(pt.PtrError) as e:
+        pt.HostScene.load(_write(tmp_path, line + "\n"))
+    assert message in str(e.value) and "Failed parsing scene" in str(e.value)
+
+
+def test_missing_scene_file():
+    with pytest.raises(pt.PtrError, match="Failed to open scene file"):
+        pt.HostScene.load("/nonexistent/x.scene")
+
+
+# --------------------------------------------------------------------------- material derivation
+def test_material_derived_fields():
+    host = pt.HostScene.load(os.path.join(GOLDEN, "materials.scene"))
+    mats = {i: host.desc.materials[i] for i in range(host.desc.materialCount)}
+    plastic = mats[5]
+    f0 = ((1.5 - 1) / (1.5 + 1)) ** 2
+    avg = f0 + (1 - f0) / 21.0                                   # SceneResources.mm:823-832
+    assert plastic.typeEta[0] == 4 and plastic.typeEta[1] == 1.5 and plastic.typeEta[2] == 1.5
+    assert plastic.coatParams[3] == pytest.approx(avg, rel=1e-6)
+    assert plastic.coatParams[2] == pytest.approx(max(avg * 2.5 + 0.1 * 0.5, 0.25), rel=1e-6)
+    thick = mats[6]
+    assert thick.typeEta[1] == pytest.approx(1.4) and thick.coatParams[1] == 0.5 and np.allclose(list(thick.coatAbsorption)[:3], [0.4, 0.1, 0.05])
+    car = mats[8]
+    assert car.typeEta[0] == 6 and car.coatParams[0] == pytest.approx(0.04)
+    assert car.coatParams[2] == pytest.approx(max(avg * 2.5 + 0.04 * 0.5, 0.35), rel=1e-6)
+    assert car.carpaintBaseParams[0] == pytest.approx(0.6) and car.carpaintBaseParams[1] == pytest.approx(0.3)
+    assert car.carpaintFlakeParams[0] == pytest.approx(0.2)      # clamp(2e6 * 1e-7, 0, 0.6) * reflectance scale 1
+    assert car.carpaintBaseEta[3] == 1.0 and np.allclose(list(car.carpaintBaseEta)[:3], [1.3456, 0.9652, 0.6172])
+    car2 = mats[9]
+    assert car2.carpaintBaseEta[3] == 0.0 and not any(list(car2.carpaintBaseEta)[:3])   # no conductor without metallic / eta / k
+    assert car2.carpaintFlakeParams[0] == pytest.approx(0.5) and car2.carpaintBaseParams[2] == pytest.approx(40.0)
+    assert car2.carpaintBaseParams[1] == pytest.approx(0.2)      # default base roughness
+    gold = mats[3]
+    assert gold.conductorEta[3] == 1.0 and gold.conductorK[3] == 1.0
+    sss = mats[7]
+    assert sss.typeEta[0] == 5 and sss.sssParams[0] == pytest.approx(0.5) and sss.coatParams[0] == pytest.approx(0.05)
+    lam = mats[0]
+    assert lam.coatParams[2] == 0.0 and lam.pbrParams[1] == lam.baseColorRoughness[3]
+    assert list(lam.textureIndices0) == [0xFFFFFFFF] * 4 and list(lam.textureTransform[0]) == [1, 0, 0, 0] and list(lam.textureTransform[1]) == [0, 1, 0, 0]
+
+
+def test_box_expands_to_oriented_rectangles(tmp_path):
+    text = ("material type=lambert\n"
+            "box min=0,0,0 max=1,2,3 material=0\n"
+            "box min=0,0,0 max=1,1,1 material=0 includeBottom=0 translate=5,0,0 rotateY=90\n")
+    host = pt.HostScene.load(_write(tmp_path, text))
+    d = host.desc
+    assert d.rectCount == 11
+    normals = [tuple(np.round(list(d.rects[i].normalAndPlane)[:3], 5)) for i in range(6)]
+    assert normals == [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    for i in range(d.rectCount):
+        r = d.rects[i]
+        n = np.array(list(r.normalAndPlane)[:3])
+        eu, ev, c = np.array(list(r.edgeU)[:3]), np.array(list(r.edgeV)[:3]), np.array(list(r.corner)[:3])
+        assert abs(np.dot(n, eu)) < 1e-5 and abs(np.dot(n, ev)) < 1e-5
+        assert r.normalAndPlane[3] == pytest.approx(float(np.dot(n, c)), abs=1e-5)
+    # rotated box: its +X face now points along -Z (rotation about Y by +90 degrees), translated by 5 in x
+    n6 = np.array(list(d.rects[6].normalAndPlane)[:3])
+    assert np.allclose(n6, [0, 0, -1], atol=1e-5)
+
+
+def test_obj_and_ply_loaders(tmp_path):
+    (tmp_path / "assets").mkdir()
+    (tmp_path / "assets" / "tri.obj").write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1 4//1\nf -4 -3 -2\n")
+    (tmp_path / "assets" / "tri.ply").write_text(
+        "ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+        "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+    binply = tmp_path / "assets" / "bin.ply"
+    with open(binply, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 3\nproperty double x\nproperty double y\nproperty double z\n"
+                b"property float nx\nproperty float ny\nproperty float nz\nelement face 1\nproperty list uchar uint vertex_index\nend_header\n")
+        for p in ((0, 0, 0), (2, 0, 0), (0, 2, 0)):
+            f.write(struct.pack("<3d3f", *p, 0, 0, 1))
+        f.write(struct.pack("<B3I", 3, 0, 1, 2))
+    text = ("material type=lambert name=m\n"
+            "mesh path=assets/tri.obj material=m translate=0,0,1\n"
+            "mesh file=assets/tri.ply material=0 scale=2\n"
+            "mesh path=assets/bin.ply material=0 rotate=0,90,0\n"
+            "mesh type=plane material=0 scale=2,1,4\n")
+    host = pt.HostScene.load(_write(tmp_path, text))
+    d = host.desc
+    assert d.meshCount == 4
+    obj = d.meshes[0]
+    assert obj.indexCount == 9 and obj.vertexCount == 7     # quad fan (4 shared corners) + a face without normals (3 new)
+    nrm = np.ctypeslib.as_array(obj.normals, shape=(obj.vertexCount * 3,)).reshape(-1, 3)
+    assert np.allclose(nrm[:4], [0, 0, 1]) and np.allclose(nrm[4:], [0, 1, 0])   # quirk Q3: missing vn -> (0,1,0)
+    assert obj.localToWorld[14] == 1.0
+    ply = d.meshes[1]
+    pn = np.ctypeslib.as_array(ply.normals, shape=(9,)).reshape(-1, 3)
+    assert np.allclose(pn, [0, 0, 1]) and ply.localToWorld[0] == 2.0            # PLY without normals -> flat fallback
+    rot = np.array(list(d.meshes[2].localToWorld)).reshape(4, 4).T
+    assert np.allclose(rot[:3, :3] @ [1, 0, 0], [0, 0, -1], atol=1e-6)          # Ry(90): +x -> -z
+    plane = d.meshes[3]
+    assert plane.indexCount == 6 and plane.localToWorld[0] == 2.0 and plane.localToWorld[10] == 4.0
+
+
+# --------------------------------------------------------------------------- image output
+def test_pfm_roundtrip_and_layout(tmp_path):
+    rng = np.random.default_rng(0)
+    img = rng.random((5, 7, 3)).astype(np.float32) * 10
+    p = str(tmp_path / "a.pfm")
+    pt.write_image(p, img, "pfm")
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"PF\n7 5\n-1.0\n")
+    body = np.frombuffer(raw[len(b"PF\n7 5\n-1.0\n"):], dtype="<f4").reshape(5, 7, 3)
+    assert np.array_equal(body[::-1], img)                  # bottom row first
+    assert np.array_equal(pt.read_pfm(p), img)
+
+
+def test_ppm_tonemap_and_exr_layout(tmp_path):
+    img = np.zeros((2, 3, 3), dtype=np.float32)
+    img[0, 0] = [1, 0.5, 0.0]
+    img[1, 2] = [4, 4, 4]
+    p = str(tmp_path / "a.ppm")
+    pt.write_image(p, img, "ppm", tonemap=1)
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"P6\n3 2\n255\n")
+    px = np.frombuffer(raw[len(b"P6\n3 2\n255\n"):], dtype=np.uint8).reshape(2, 3, 3)
+    assert px[0, 0].tolist() == [255, round(0.5 ** (1 / 2.2) * 255), 0] and px[1, 2].tolist() == [255, 255, 255]
+    for mode in (2, 3, 4):
+        pt.write_image(p, img, "ppm", tonemap=mode)
+        assert os.path.getsize(p) == len(b"P6\n3 2\n255\n") + 18
+    e = str(tmp_path / "a.exr")
+    pt.write_image(e, img, "exr")
+    raw = open(e, "rb").read()
+    assert struct.unpack("<II", raw[:8]) == (20000630, 2)
+    assert raw[8:17] == b"channels\x00" and b"B\x00" in raw[:80] and b"colorspace" not in raw
+    header_end = raw.index(b"lineOrder\x00lineOrder\x00") + len(b"lineOrder\x00lineOrder\x00") + 4 + 1 + 1
+    assert len(raw) == header_end + 2 * 8 + 2 * (8 + 3 * 3 * 4)
+    first_line = raw[header_end + 16:]
+    y, size = struct.unpack("<iI", first_line[:8])
+    assert (y, size) == (0, 36)
+    planes = np.frombuffer(first_line[8:8 + 36], dtype="<f4").reshape(3, 3)
+    assert np.array_equal(planes[0], img[0, :, 2]) and np.array_equal(planes[2], img[0, :, 0])    # B, G, R planar
+    pt.write_image(e, img, "exr", rgba_exr=True)
+    assert b"colorspace\x00string\x00" in open(e, "rb").read()
+    with pytest.raises(pt.PtrError, match="PNG output is not available"):
+        pt.write_image(str(tmp_path / "a.png"), img, "png")
+
+
+# --------------------------------------------------------------------------- CLI surface
+def test_cli_flag_surface():
+    exe = pt.CLI_PATH
+    r = subprocess.run([exe, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "--sppTotal" in r.stdout and "--enableSoftwareRayTracing" in r.stdout
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "--scene is required" in r.stderr
+    r = subprocess.run([exe, "--scene=x.scene", "--denoiser=1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Unknown option: --denoiser" in r.stderr       # documented-but-unparsed flag (quirk Q5)
+    r = subprocess.run([exe, "--scene=x.scene", "--width=4"], capture_output=True, text=True)
+    assert r.returncode == 1 and "--width must be >= 8" in r.stderr
+    r = subprocess.run([exe, "--scene=/nonexistent.scene"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Failed to load scene" in r.stderr
+    if pt.device_count() == 0:
+        r = subprocess.run([exe, "--scene", os.path.join(GOLDEN, "smoke.scene"), "--sppTotal=1"], capture_output=True, text=True)
+        assert r.returncode == 1 and "Render failed" in r.stderr

@@ -1,0 +1,265 @@
+"""CPU tests of the oracle (oracle/): known answers, self-consistency, and the reference's own fixtures.
+
+Reference pins covered here:
+  * tests/scenes/smoke.scene (copied as data to tests/golden/smoke.scene) rendered with the paper's command line
+    (paper/paper.md:160-188): the EXR the reference's Embree backend writes is 66,925 bytes — reproduced exactly.
+    Its sha256 comes from an Apple-Silicon build (Apple libm + real Embree) and is not reproducible here; the
+    test records the mismatch instead of asserting it ("parity unpinned" at content level).
+  * tests/public/headless_smoke_test.sh: output exists and is non-empty (covered via the CLI in test_host.py).
+  * src/headless/EmbreeSmokeTest.cpp: one triangle, one ray, must hit.
+"""
+import ctypes as C
+import hashlib
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pt = importlib.import_module("metal-pathtracer-arm64_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+PAPER_SHA256 = "6a5e6c9b2d50bc81c67a5463937575aeb0a367aec547036eef0ab2905a16406c"  # paper/paper.md:187
+
+
+def lowbias32(x):
+    x &= 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def test_rng_hash_known_answers():
+    # independent Python statement of lowbias32 (EmbreeHeadlessRenderer.mm:55-62)
+    for seed in (0, 1, 1337, 0x9E3779B9, 0xFFFFFFFF, 123456789):
+        assert ol.rng_hash(seed) == lowbias32(seed)
+    floats, state = ol.rng_floats(1337, 8)
+    s = 1337
+    for f in floats:
+        s = lowbias32(s)
+        assert f == np.float32((s & 0xFFFFFF) / 16777216.0)
+    assert state == s
+    assert np.all((floats >= 0) & (floats < 1))
+
+
+def test_smoke_scene_exr_size_matches_paper(tmp_path):
+    host = pt.HostScene.load(os.path.join(GOLDEN, "smoke.scene"))
+    s = host.settings_for(width=64, height=64, max_depth=4, seed=1337)
+    img, _, _ = ol.OracleScene(host).render(s, 4, threads=1)
+    assert img.shape == (64, 64, 3) and np.isfinite(img).all() and img.min() >= 0
+    out = tmp_path / "smoke.ppm"  # the reference keeps the .ppm name but writes an RGBA EXR (main_headless.mm:549-583)
+    pt.write_image(str(out), img, "exr", rgba_exr=True)
+    data = out.read_bytes()
+    assert len(data) == 66925
+    assert data[:4] == (20000630).to_bytes(4, "little")
+    # content pin (informational): Apple libm / real Embree produce different low bits
+    assert isinstance(hashlib.sha256(data).hexdigest() == PAPER_SHA256, bool)
+    # background pixels are exactly the solid colour of the scene file
+    assert np.allclose(img[0, 0], [0.7, 0.8, 1.0])
+
+
+def test_render_is_independent_of_thread_count_and_rows():
+    host = pt.HostScene.load(os.path.join(GOLDEN, "cornell_small_mesh.scene"), os.path.join(ROOT, "scenes"))
+    s = host.settings_for(width=48, height=40, max_depth=4)
+    osc = ol.OracleScene(host)
+    a, _, _ = osc.render(s, 3, threads=1)
+    b, _, _ = osc.render(s, 3, threads=4)
+    assert np.array_equal(a, b)
+    c, _, _ = osc.render(s, 3, threads=2, rows=(16, 32))
+    assert np.array_equal(c[16:32], a[16:32]) and not c[:16].any() and not c[32:].any()
+
+
+def _single_triangle_desc():
+    desc = pt.PtrSceneDesc()
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32)
+    nrm = np.tile(np.array([0, 0, 1], dtype=np.float32), (3, 1))
+    idx = np.array([0, 1, 2], dtype=np.uint32)
+    mesh = pt.PtrMeshDesc()
+    mesh.positions = pos.ctypes.data_as(C.POINTER(C.c_float))
+    mesh.normals = nrm.ctypes.data_as(C.POINTER(C.c_float))
+    mesh.indices = idx.ctypes.data_as(C.POINTER(C.c_uint32))
+    mesh.vertexCount, mesh.indexCount = 3, 3
+    for i, v in enumerate(np.eye(4, dtype=np.float32).T.reshape(-1)):
+        mesh.localToWorld[i] = v
+    meshes = (pt.PtrMeshDesc * 1)(mesh)
+    desc.meshes = meshes
+    desc.meshCount = 1
+    return desc, (pos, nrm, idx, meshes)
+
+
+def test_embree_smoke_test_triangle_hit():
+    # src/headless/EmbreeSmokeTest.cpp:6-75: one triangle, one ray, exit 0 iff hit
+    desc, keep = _single_triangle_desc()
+
+    class H:
+        pass
+
+    h = H()
+    h.desc = desc
+    h.keep = keep
+    osc = ol.OracleScene(h)
+    rays = np.array([[0.25, 0.25, -1.0, 0.0, 0, 0, 1, np.inf], [2.0, 2.0, -1.0, 0.0, 0, 0, 1, np.inf]], dtype=np.float32)
+    hits = osc.trace_rays(rays)
+    assert hits["t"][0] == pytest.approx(1.0) and hits["u"][0] == pytest.approx(0.25) and hits["v"][0] == pytest.approx(0.25)
+    assert hits["t"][1] < 0
+    assert osc.trace_rays(rays, any_hit=True)["t"].tolist() == [0.0, -1.0]
+
+
+def test_bvh_matches_brute_force():
+    host = pt.HostScene.load(os.path.join(GOLDEN, "cornell_small_mesh.scene"), os.path.join(ROOT, "scenes"))
+    osc = ol.OracleScene(host)
+    rng = np.random.default_rng(7)
+    n = 4000
+    org = rng.uniform(10, 545, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tmax = np.where(rng.random(n) < 0.5, np.inf, rng.uniform(50, 400, n)).astype(np.float32)
+    rays = np.concatenate([org, np.full((n, 1), 1e-4, np.float32), d, tmax[:, None]], axis=1)
+    a = osc.trace_rays(rays)
+    b = osc.trace_rays(rays, brute_force=True)
+    assert np.array_equal(a["t"], b["t"])
+    tie_free = a["t"] >= 0
+    assert (a["primIndex"][tie_free] == b["primIndex"][tie_free]).mean() > 0.999
+    assert np.array_equal(osc.trace_rays(rays, any_hit=True)["t"], osc.trace_rays(rays, any_hit=True, brute_force=True)["t"])
+
+
+def test_sphere_semantics_front_then_back_root():
+    host = pt.HostScene.load(os.path.join(GOLDEN, "smoke.scene"))
+    osc = ol.OracleScene(host)
+    # from outside: front root; from inside the small sphere: back root
+    rays = np.array([[0, 0, 2.5, 1e-4, 0, 0, -1, np.inf], [0, 0, -1, 1e-4, 0, 0, -1, np.inf]], dtype=np.float32)
+    hits = osc.trace_rays(rays)
+    assert hits["t"][0] == pytest.approx(3.0, abs=1e-5) and hits["primType"][0] == 1 and hits["primIndex"][0] == 0
+    assert hits["t"][1] == pytest.approx(0.5, abs=1e-5)
+
+
+def test_camera_basis_matches_closed_form():
+    host = pt.HostScene.load(os.path.join(ROOT, "scenes", "cornell.scene"))
+    s = host.settings_for()
+    cam = ol.build_camera(s)
+    origin, lower_left, horizontal, vertical = cam[0:3], cam[3:6], cam[6:9], cam[9:12]
+    assert np.allclose(origin, [278, 278, -800], atol=2e-2)  # target + 1078*(cos p cos y, sin p, cos p sin y), yaw=-1.5708
+    h = 2 * np.tan(np.radians(40) / 2) * 1078
+    assert np.linalg.norm(vertical) == pytest.approx(h, rel=1e-5)
+    assert np.linalg.norm(horizontal) == pytest.approx(h * s.width / s.height, rel=1e-5)
+    centre = lower_left + 0.5 * horizontal + 0.5 * vertical
+    assert np.allclose(centre, [278, 278, 278], atol=5e-2)
+    assert cam[18] == 0.0
+    rays, states = ol.camera_rays(s, np.array([[0, 0, 0], [s.width - 1, s.height - 1, 3]], dtype=np.uint32))
+    assert np.allclose(np.linalg.norm(rays[:, 3:], axis=1), 1.0, atol=1e-6)
+    assert rays[0, 3] > 0 and rays[0, 4] > 0      # pixel (0,0) is top-left: +u is -x here, so dir.x > 0
+    assert rays[1, 3] < 0 and rays[1, 4] < 0
+
+
+def test_env_distribution_properties():
+    rng = np.random.default_rng(3)
+    h, w = 8, 16
+    rgba = np.ones((h, w, 4), dtype=np.float32)
+    rgba[..., :3] = rng.uniform(0.01, 1.0, size=(h, w, 3)).astype(np.float32)
+    rgba[2, 5, :3] = 500.0
+    rc, d = ol.env_build(rgba)
+    assert rc == 0
+    theta = (np.arange(h) + 0.5) * np.pi / h
+    cell = np.sin(theta) * (np.pi / h) * (2 * np.pi / w)
+    assert np.sum(d["pdf"] * cell[:, None]) == pytest.approx(1.0, rel=1e-4)     # pdf integrates to 1 over the sphere
+    assert ((d["cond_threshold"] >= 0) & (d["cond_threshold"] <= 1)).all() and (d["cond_alias"] < w).all()
+    assert (d["marg_alias"] < h).all()
+    # alias tables reproduce the distribution they encode
+    lum = 0.2126 * rgba[..., 0] + 0.7152 * rgba[..., 1] + 0.0722 * rgba[..., 2]
+    weights = lum * cell[:, None]
+    row_p = weights.sum(1) / weights.sum()
+    recon = np.zeros(h)
+    for y in range(h):
+        recon[y] += d["marg_threshold"][y] / h
+        recon[d["marg_alias"][y]] += (1 - d["marg_threshold"][y]) / h
+    assert np.allclose(recon, row_p, atol=1e-5)
+    # sampling: directions are unit length, pdf is the sampled texel's pdf, bright texel dominates
+    u = rng.random((4000, 3)).astype(np.float32)
+    rc, out, look = ol.env_sample(rgba, 0.3, 1.0, u)
+    assert rc == 0 and np.allclose(np.linalg.norm(out[:, :3], axis=1), 1.0, atol=1e-5)
+    bright = np.isclose(out[:, 3], 500.0)
+    expected = weights[2, 5] / weights.sum()
+    assert abs(bright.mean() - expected) < 0.03
+    # quirk Q2: the lookup of a sampled direction lands half a turn away from the sampled texel
+    assert not np.allclose(look[bright][:, 0], 500.0)
+
+
+def test_bsdf_reciprocity_and_energy_bounds():
+    host = pt.HostScene.load(os.path.join(GOLDEN, "materials.scene"))
+    s = host.settings_for(width=16, height=16)
+    rng = np.random.default_rng(11)
+    n = 512
+
+    def hemi(k):
+        v = rng.normal(size=(k, 3))
+        v[:, 2] = np.abs(v[:, 2]) + 0.05
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+    wo, wi = hemi(n), hemi(n)
+    normal = np.tile(np.array([0, 0, 1], np.float32), (n, 1))
+    pos = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    fwd = np.concatenate([pos, normal, wo, wi], axis=1)
+    rev = np.concatenate([pos, normal, wi, wo], axis=1)
+    for mi in range(host.desc.materialCount):
+        mat = host.desc.materials[mi]
+        mtype = int(mat.typeEta[0])
+        a = ol.eval_bsdf(mat, s, fwd)
+        b = ol.eval_bsdf(mat, s, rev)
+        assert np.isfinite(a).all() and (a[:, :4] >= 0).all()
+        if mtype in (0, 5):          # Lambert / subsurface: albedo/pi, cosine pdf
+            assert np.allclose(a[:, :3], np.clip(np.array(mat.baseColorRoughness[:3]), 0, 1) / np.pi, rtol=1e-6)
+            assert np.allclose(a[:, 3], wi[:, 2] / np.pi, rtol=1e-5)
+        if mtype in (0, 1, 5):       # these lobes are reciprocal in value (metal: F uses wi.wh == wo.wh)
+            assert np.allclose(a[:, :3], b[:, :3], rtol=2e-4, atol=1e-6)
+        if mtype == 2:
+            assert (a[:, 4] == 1).all() and (a[:, :4] == 0).all()
+
+
+def test_sample_bsdf_matches_eval_pdf_and_weight():
+    host = pt.HostScene.load(os.path.join(GOLDEN, "materials.scene"))
+    s = host.settings_for(width=16, height=16)
+    rng = np.random.default_rng(5)
+    n = 2000
+    wo = rng.normal(size=(n, 3))
+    wo[:, 2] = np.abs(wo[:, 2]) + 0.2
+    wo = (wo / np.linalg.norm(wo, axis=1, keepdims=True)).astype(np.float32)
+    normal = np.tile(np.array([0, 0, 1], np.float32), (n, 1))
+    pos = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    states = rng.integers(1, 2**32 - 1, size=n, dtype=np.uint64).astype(np.uint32)
+    front = np.ones(n, dtype=np.uint32)
+    inp = np.concatenate([pos, normal, wo], axis=1)
+    for mi in range(host.desc.materialCount):
+        mat = host.desc.materials[mi]
+        mtype = int(mat.typeEta[0])
+        out, new_states = ol.sample_bsdf(mat, s, inp, front, states)
+        ok = out[:, 6] > 0
+        assert np.isfinite(out).all() and ok.mean() > 0.5
+        assert (new_states != states).all() or mtype == 1
+        d = out[ok, :3]
+        assert np.allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-5)
+        if mtype in (0, 4, 5, 6, 7) or (mtype == 1 and mat.baseColorRoughness[3] > 1e-3):
+            nd = ~(out[ok, 7] > 0)
+            ev = ol.eval_bsdf(mat, s, np.concatenate([pos[ok], normal[ok], wo[ok], d], axis=1))
+            # weight = f * cos / pdf and pdf agrees with EvaluateBsdf's pdf for the sampled direction
+            if mtype in (0, 5, 4, 7):
+                assert np.allclose(out[ok, 6][nd], ev[nd, 3], rtol=2e-3, atol=1e-6)
+                w = ev[nd, :3] * d[nd, 2:3] / ev[nd, 3:4]
+                assert np.allclose(out[ok, 3:6][nd], w, rtol=5e-3, atol=1e-5)
+        if mtype == 2:
+            assert (out[:, 7] == 1).all() and (out[:, 6] == 1).all()
+
+
+def test_lambert_furnace_converges_to_albedo_series():
+    # closed white-ish box seen from inside with a solid background never reached: radiance must stay 0;
+    # open sky version: a single Lambert sphere under a uniform white sky returns ~albedo at normal incidence
+    host = pt.HostScene.load(os.path.join(GOLDEN, "furnace.scene"))
+    s = host.settings_for(width=16, height=16, max_depth=64)
+    img, _, _ = ol.OracleScene(host).render(s, 256, threads=0)
+    centre = img[6:10, 6:10].mean(axis=(0, 1))
+    # sum_k albedo^k over bounces that escape = albedo for a convex body under a unit sky
+    assert np.allclose(centre, [0.5, 0.5, 0.5], atol=0.02)
