@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -156,7 +157,8 @@ struct PtrDeviceScene {
     double uploadSeconds = 0.0;
 
     // render-time resources, grown on demand and kept across calls
-    DeviceBuffer<float4> rayOrg, rayDir, hit, throughput, accum, recBuf;
+    DeviceBuffer<float4> rayOrg, rayDir, hit, throughput, accum, recBuf, itemAccum;
+    uint64_t poolSlots = 4ull << 20;
     DeviceBuffer<uint4> state;
     DeviceBuffer<uint32_t> shadowQueue, scalars, pixelOfLocal, spill;
     DeviceBuffer<uint64_t> counters;
@@ -175,7 +177,12 @@ struct PtrDeviceScene {
 
 namespace {
 
-constexpr uint32_t kAliveRing = 16;   // scalars[0] = shadow count, scalars[1..16] = alive counters
+// scalars: [0] shadow-queue length, [1] k_extend work head, [2] k_connect work head, [3] pad,
+//          [4..19] ring of alive counters, [20] next unclaimed work item
+constexpr uint32_t kAliveRing = 16;
+constexpr uint32_t kAliveBase = 4;
+constexpr uint32_t kNextItemIndex = kAliveBase + kAliveRing;
+constexpr uint32_t kScalarCount = kNextItemIndex + 1;
 
 // 576 B MaterialData -> the 12 float4 the integrator reads (kernels/device_types.h MaterialSlot).
 void compactMaterial(const PtrMaterial& m, std::vector<float>& out) {
@@ -380,8 +387,12 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     HIP_CHECK(hipGetDeviceProperties(&prop, ds.device));
     const uint32_t cus = prop.multiProcessorCount > 0 ? static_cast<uint32_t>(prop.multiProcessorCount) : 256u;
     ds.traceGrid = cus * 8u;   // 8 blocks of 256 threads per CU: fills the wave slots, grid-stride the rest
+    if (const char* e = std::getenv("PTR_POOL_SLOTS")) {   // tuning knob: resident path slots
+        const unsigned long long v = std::strtoull(e, nullptr, 10);
+        if (v >= 1024) ds.poolSlots = v;
+    }
     ds.spill.ensure(static_cast<size_t>(kTraversalStackDepth - kLdsStackLevels) * ds.traceGrid * kTraceBlock);
-    ds.scalars.ensure(1 + kAliveRing);
+    ds.scalars.ensure(kScalarCount);
     ds.counters.ensure(kCounterSlots);
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ds.pinnedAlive), sizeof(uint32_t) * 4, hipHostMallocDefault));
     ds.uploadSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -512,13 +523,17 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
         return;
     }
 
-    // slots in flight: enough to keep every CU's wave slots full several times over
-    const uint64_t targetSlots = 4ull << 20;
-    uint32_t inFlight = static_cast<uint32_t>(std::max<uint64_t>(1, targetSlots / localPixels));
-    inFlight = std::min(inFlight, rp.spp);
-    rp.samplesInFlight = inFlight;
+    // Work items = (pixel, chunk of C consecutive samples).  Slots claim items from a global counter, so the
+    // pool stays full until the last chunks regardless of how path length varies over the image.
+    const uint32_t chunkSize = rp.spp >= 128 ? 4u : (rp.spp >= 16 ? 2u : 1u);
+    rp.chunkSize = chunkSize;
+    rp.chunkCount = (rp.spp + chunkSize - 1) / chunkSize;
     rp.localPixels = localPixels;
-    const uint32_t slots = localPixels * inFlight;
+    const uint64_t itemCount64 = static_cast<uint64_t>(localPixels) * rp.chunkCount;
+    if (itemCount64 > 0xFFFFFFF0ull) throw HipError{"too many work items (reduce spp or resolution)"};
+    rp.itemCount = static_cast<uint32_t>(itemCount64);
+    const uint64_t targetSlots = ds.poolSlots;   // enough to keep every CU's wave slots full several times over
+    const uint32_t slots = static_cast<uint32_t>(std::min<uint64_t>(targetSlots, itemCount64));
 
     ds.rayOrg.ensure(slots);
     ds.rayDir.ensure(slots);
@@ -526,6 +541,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     ds.throughput.ensure(slots);
     ds.accum.ensure(slots);
     ds.state.ensure(slots);
+    ds.itemAccum.ensure(rp.itemCount);
     ds.recBuf.ensure(static_cast<size_t>(slots) * kRecSlots * 4u);
     ds.shadowQueue.ensure(static_cast<size_t>(slots) * kRecSlots);
 
@@ -537,6 +553,8 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     pool.throughput = ds.throughput.ptr;
     pool.accum = ds.accum.ptr;
     pool.state = ds.state.ptr;
+    pool.itemAccum = ds.itemAccum.ptr;
+    pool.nextItem = ds.scalars.ptr + kNextItemIndex;
     for (uint32_t k = 0; k < kRecSlots; ++k) {
         float4* base = ds.recBuf.ptr + static_cast<size_t>(k) * 4u * slots;
         pool.rec[k].org = base;
@@ -546,12 +564,12 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     }
     pool.shadowQueue = ds.shadowQueue.ptr;
     pool.shadowCount = ds.scalars.ptr;
-    pool.aliveCount = ds.scalars.ptr + 1;
+    pool.aliveCount = ds.scalars.ptr + kAliveBase;
     pool.pixelOfLocal = ds.pixelOfLocal.ptr;
     pool.counters = ds.counters.ptr;
     pool.slots = slots;
 
-    LaunchConfig cfg{ds.traceGrid, ds.spill.ptr};
+    LaunchConfig cfg{ds.traceGrid, ds.spill.ptr, ds.scalars.ptr + 1};
 
     const bool timed = stats != nullptr;
     EventTimer timer;
@@ -573,18 +591,20 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     };
 
     if (count) HIP_CHECK(hipMemsetAsync(ds.counters.ptr, 0, sizeof(uint64_t) * kCounterSlots, stream));
-    HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * (1 + kAliveRing), stream));
+    HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * kScalarCount, stream));
+    HIP_CHECK(hipMemcpyAsync(pool.nextItem, &slots, sizeof(uint32_t), hipMemcpyHostToDevice, stream));   // items 0..slots-1 are pre-assigned
+    if (rp.maxDepth == 0) HIP_CHECK(hipMemsetAsync(ds.itemAccum.ptr, 0, sizeof(float4) * rp.itemCount, stream));
 
     const auto wall0 = std::chrono::steady_clock::now();
     launchGenerate(rp, pool, stream);
     uint64_t iterations = 0;
     // Worst case: every sample runs maxDepth bounces in sequence on its slot.
-    const uint64_t maxIterations = static_cast<uint64_t>(rp.maxDepth) * ((rp.spp + inFlight - 1) / inFlight) + 4;
+    const uint64_t maxIterations = static_cast<uint64_t>(rp.maxDepth) * ((itemCount64 + slots - 1) / slots + 1) * chunkSize + 8;
     const uint32_t checkEvery = 4;
     while (rp.maxDepth > 0) {
         const uint32_t ring = static_cast<uint32_t>(iterations % kAliveRing);
-        uint32_t* aliveSlot = ds.scalars.ptr + 1 + ring;
-        HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t), stream));      // shadow queue length
+        uint32_t* aliveSlot = ds.scalars.ptr + kAliveBase + ring;
+        HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * 3, stream));  // shadow queue length + both work heads
         HIP_CHECK(hipMemsetAsync(aliveSlot, 0, sizeof(uint32_t), stream));
         timedLaunch(0, [&] { launchExtend(ds.view, pool, cfg, count, stream); });
         timedLaunch(1, [&] { launchShade(rp, ds.view, pool, aliveSlot, count, stream); });
@@ -762,7 +782,7 @@ int ptr_trace_rays(PtrDeviceScene* scene, const float* rays, uint64_t n, int any
         scene->rayBatch.upload(reinterpret_cast<const float4*>(rays), n * 2);
         scene->hitBatch.ensure(n);
         HIP_CHECK(hipMemset(scene->counters.ptr, 0, sizeof(uint64_t) * kCounterSlots));
-        LaunchConfig cfg{scene->traceGrid, scene->spill.ptr};
+        LaunchConfig cfg{scene->traceGrid, scene->spill.ptr, scene->scalars.ptr + 1};
         launchTraceRays(scene->view, scene->rayBatch.ptr, n, any_hit != 0, scene->hitBatch.ptr, cfg, scene->counters.ptr, nullptr);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipDeviceSynchronize());

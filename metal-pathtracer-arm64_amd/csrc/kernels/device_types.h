@@ -68,7 +68,9 @@ struct RenderParams {
     uint32_t maxDepth;
     uint32_t seedBase;
     uint32_t spp;
-    uint32_t samplesInFlight;      // S: slots per pixel; slot (lp, j) renders samples j, j+S, ...
+    uint32_t chunkSize;            // C: consecutive samples of one pixel rendered by one slot (a work item)
+    uint32_t chunkCount;           // ceil(spp / C)
+    uint32_t itemCount;            // localPixels * chunkCount; item w = chunk * localPixels + localPixel
     uint32_t localPixels;          // pixels owned by this partition
     uint32_t enableRussianRoulette, enableSpecularNee, enableMnee, enableMneeSecondary;
     uint32_t backgroundMode;
@@ -101,8 +103,10 @@ struct PathPool {
     float4* rayDir;        // xyz direction
     float4* hit;           // (t, u, v, bits(primRef))
     float4* throughput;    // xyz throughput, w lastBsdfPdf
-    float4* accum;         // xyz radiance sum over this slot's samples
-    uint4* state;          // x rng, y sample index, z flags, w pending mask (bit k = record slot k)
+    float4* accum;         // xyz radiance sum of the slot's current work item; w = bits(item to flush)
+    uint4* state;          // x rng, y work item, z flags, w = pending mask (bits 0..4) | sample-in-chunk << 8
+    float4* itemAccum;     // [itemCount] finished work items (summed per pixel, in chunk order, by k_resolve)
+    uint32_t* nextItem;    // [1] next unclaimed work item
     ShadowRecordView rec[kRecSlots];
     uint32_t* shadowQueue;     // entries = slot*kRecSlots + which
     uint32_t* shadowCount;     // [1]
@@ -115,6 +119,7 @@ struct PathPool {
 // flags word
 constexpr uint32_t kFlagAlive = 1u << 0;
 constexpr uint32_t kFlagLastDelta = 1u << 1;
+constexpr uint32_t kFlagFlush = 1u << 2;        // accumulator belongs to a finished item: store it, then zero
 constexpr uint32_t kFlagDepthShift = 8u;        // 12 bits
 constexpr uint32_t kFlagSpecDepthShift = 20u;   // 12 bits
 constexpr uint32_t kFlagFieldMask = 0xFFFu;

@@ -11,6 +11,7 @@ namespace ptrk {
 struct LaunchConfig {
     uint32_t traceGrid;      // blocks of kTraceBlock threads for extend / connect (grid-stride)
     uint32_t* spill;         // traversal stack spill area: (kTraversalStackDepth-kLdsStackLevels) * traceGrid*kTraceBlock words
+    uint32_t* workCounters;  // [2] work-queue heads of k_extend / k_connect, zeroed by the host before each launch
 };
 
 void launchGenerate(const RenderParams& rp, const PathPool& pool, hipStream_t stream);

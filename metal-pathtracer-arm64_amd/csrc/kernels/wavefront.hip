@@ -73,6 +73,47 @@ __device__ __forceinline__ void addCounter(uint64_t* counters, uint32_t slot, ui
     if (laneId() == 0 && total != 0u) atomicAdd(reinterpret_cast<unsigned long long*>(counters + slot), static_cast<unsigned long long>(total));
 }
 
+// Hands out work indices [0, total) to the idle lanes of a persistent wave.  The wave owns a chunk of
+// kChunk consecutive indices at a time (one global atomic per chunk); inside a chunk, idle lanes take
+// consecutive indices by rank, so neighbouring lanes still load neighbouring path slots.
+struct WaveFeeder {
+    static constexpr uint32_t kChunk = 256u;
+    static constexpr uint32_t kNone = 0xFFFFFFFFu;
+    uint32_t* counter;
+    uint32_t total, next, end;
+    bool exhausted;
+    __device__ __forceinline__ void init(uint32_t* c, uint32_t n) {
+        counter = c;
+        total = n;
+        next = 0u;
+        end = 0u;
+        exhausted = (n == 0u);
+    }
+    // must be called by all 64 lanes (converged)
+    __device__ __forceinline__ uint32_t take(bool idle) {
+        const unsigned long long mask = __ballot(idle);
+        if (mask == 0ull || exhausted) return kNone;
+        if (next >= end) {
+            uint32_t base = 0u;
+            if (laneId() == 0u) base = atomicAdd(counter, kChunk);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= total) {
+                exhausted = true;
+                return kNone;
+            }
+            next = base;
+            end = min(base + kChunk, total);
+        }
+        const uint32_t avail = end - next;
+        const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << laneId()) - 1ull)));
+        const uint32_t idx = (idle && rank < avail) ? (next + rank) : kNone;
+        next += min(static_cast<uint32_t>(__popcll(mask)), avail);
+        return idx;
+    }
+};
+
+constexpr int kRefillBelow = 48;   // hand out new rays once fewer than this many lanes are still traversing
+
 // ---------------------------------------------------------------- camera
 __device__ __forceinline__ void cameraRay(const RenderParams& rp, uint32_t x, uint32_t y, uint32_t& rng, f3& org, f3& dir) {
     const CameraParams& c = rp.cam;
@@ -323,14 +364,15 @@ __device__ __forceinline__ void storeRecord(const PathPool& pool, uint32_t slot,
 __global__ void __launch_bounds__(256) k_generate(RenderParams rp, PathPool pool) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= pool.slots) return;
-    const uint32_t lp = slot % rp.localPixels;
-    const uint32_t j = slot / rp.localPixels;
-    uint4 st = make_uint4(0u, j, 0u, 0u);
+    // slot i starts with work item i; later items are claimed from pool.nextItem (initialised to `slots`)
+    uint4 st = make_uint4(0u, slot, 0u, 0u);
     pool.accum[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (j < rp.spp && rp.maxDepth > 0u) {
+    if (slot < rp.itemCount && rp.maxDepth > 0u) {
+        const uint32_t lp = slot % rp.localPixels;
+        const uint32_t chunk = slot / rp.localPixels;
         uint32_t rng;
         f3 o, d;
-        beginSample(rp, pool.pixelOfLocal[lp], j, rng, o, d);
+        beginSample(rp, pool.pixelOfLocal[lp], chunk * rp.chunkSize, rng, o, d);
         st.x = rng;
         st.z = kFlagAlive | kFlagLastDelta;
         pool.rayOrg[slot] = mk4(o, 0.0f);
@@ -344,22 +386,40 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams rp, PathPool pool
 // k_extend: closest hit for every live slot
 // =====================================================================================================
 template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride) {
+__global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride, uint32_t* workCounter) {
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
     stack.lds = ldsStack + threadIdx.x;
     stack.spill = spill + gtid;
     stack.spillStride = spillStride;
+    stack.sp = 0u;
     TraceCounters cnt{0u, 0u};
     uint32_t rays = 0u;
-    for (uint32_t slot = gtid; slot < pool.slots; slot += gridDim.x * kTraceBlock) {
-        if (!(pool.state[slot].z & kFlagAlive)) continue;
-        const f3 o = mk3(pool.rayOrg[slot]);
-        const f3 d = mk3(pool.rayDir[slot]);
-        const TraceHit h = traverse<false, COUNT>(sc, o, d, kEps, INFINITY, stack, cnt);
-        pool.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
-        if (COUNT) ++rays;
+
+    WaveFeeder feeder;
+    feeder.init(workCounter, pool.slots);
+    Trav t;
+    t.cur = 0u;
+    bool active = false;
+    uint32_t mySlot = 0u;
+    while (true) {
+        const int nActive = __popcll(__ballot(active));
+        if (nActive < kRefillBelow && !feeder.exhausted) {
+            const uint32_t idx = feeder.take(!active);
+            if (idx != WaveFeeder::kNone && (pool.state[idx].z & kFlagAlive)) {
+                mySlot = idx;
+                if (COUNT) ++rays;
+                active = travBegin(sc, t, mk3(pool.rayOrg[idx]), mk3(pool.rayDir[idx]), kEps, INFINITY, false, stack);
+                if (!active) pool.hit[idx] = make_float4(INFINITY, 0.0f, 0.0f, __uint_as_float(kHitMiss));
+            }
+            continue;
+        }
+        if (nActive == 0) break;
+        if (active && !travStep<COUNT>(sc, t, stack, cnt)) {
+            active = false;
+            pool.hit[mySlot] = make_float4(t.hit.t, t.hit.u, t.hit.v, __uint_as_float(t.hit.prim));
+        }
     }
     if (COUNT) {
         addCounter(pool.counters, kCntExtendRays, rays);
@@ -377,39 +437,50 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(RenderParams rp, SceneVie
     const bool inRange = slot < pool.slots;
     uint4 st = inRange ? pool.state[slot] : make_uint4(0u, 0u, 0u, 0u);
     const bool active = inRange && (st.z & kFlagAlive);
-    const bool touched = inRange && (active || st.w != 0u);   // state/accum will be rewritten
+    const bool touched = inRange && (active || (st.w & 0xFFu) != 0u || (st.z & kFlagFlush));   // state/accum rewritten
 
     bool want[kRecSlots] = {false, false, false, false, false};
-    bool stillAlive = false;
+    bool stillAlive = false, needItem = false;
     uint32_t shadedHit = 0u, triHit = 0u, primary = 0u;
+    uint32_t sampleInChunk = (st.w >> 8) & 0xFFu;
+    uint32_t rng = st.x;
+    uint32_t depth = 0u, specDepth = 0u;
+    bool lastDelta = true, flushNext = false;
+    f3 acc = mk3(0.0f), thr = mk3(1.0f), nextO = mk3(0.0f), nextD = mk3(0.0f);
+    float lastPdf = 1.0f;
+    uint32_t flushItem = 0u;
 
     if (touched) {
         const ClampCfg cc = clampCfg(rp);
-        f3 acc = mk3(pool.accum[slot]);
+        const float4 acc4 = pool.accum[slot];
+        acc = mk3(acc4);
         // light connections queued last bounce have been resolved by k_connect: add them in slot order
 #pragma unroll
         for (uint32_t k = 0; k < kRecSlots; ++k) {
             if (st.w & (1u << k)) acc += mk3(pool.rec[k].a[slot]);
         }
-        st.w = 0u;
+        if (st.z & kFlagFlush) {
+            // the previous work item of this slot is complete (its last connections just landed): publish it
+            pool.itemAccum[__float_as_uint(acc4.w)] = mk4(acc, 0.0f);
+            acc = mk3(0.0f);
+        }
 
         if (active) {
-            const uint32_t lp = slot % rp.localPixels;
-            uint32_t rng = st.x;
-            uint32_t depth = (st.z >> kFlagDepthShift) & kFlagFieldMask;
-            uint32_t specDepth = (st.z >> kFlagSpecDepthShift) & kFlagFieldMask;
-            bool lastDelta = (st.z & kFlagLastDelta) != 0u;
+            depth = (st.z >> kFlagDepthShift) & kFlagFieldMask;
+            specDepth = (st.z >> kFlagSpecDepthShift) & kFlagFieldMask;
+            lastDelta = (st.z & kFlagLastDelta) != 0u;
             const f3 rayO = mk3(pool.rayOrg[slot]);
             const f3 rayD = mk3(pool.rayDir[slot]);
             const float4 hitv = pool.hit[slot];
             const float4 thr4 = pool.throughput[slot];
-            f3 thr = mk3(thr4);
-            float lastPdf = thr4.w;
+            thr = mk3(thr4);
+            lastPdf = thr4.w;
             const uint32_t prim = __float_as_uint(hitv.w);
             if (COUNT && depth == 0u) primary = 1u;
 
             bool endPath = false;
-            f3 nextO = rayO, nextD = rayD;
+            nextO = rayO;
+            nextD = rayD;
 
             if (prim == kHitMiss) {
                 // ---- escaped: background, MIS-weighted against environment sampling ----
@@ -610,32 +681,38 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(RenderParams rp, SceneVie
             if (depth >= rp.maxDepth) endPath = true;
 
             if (endPath) {
-                // this slot's next sample of the same pixel
-                const uint32_t s = st.y + rp.samplesInFlight;
-                st.y = s;
-                if (s < rp.spp) {
-                    beginSample(rp, pool.pixelOfLocal[lp], s, rng, nextO, nextD);
-                    thr = mk3(1.0f);
-                    lastPdf = 1.0f;
-                    lastDelta = true;
-                    depth = 0u;
-                    specDepth = 0u;
+                // next sample of the same work item, or (below, wave-wide) a new work item
+                ++sampleInChunk;
+                const uint32_t chunk = st.y / rp.localPixels;
+                const uint32_t s = chunk * rp.chunkSize + sampleInChunk;
+                thr = mk3(1.0f);
+                lastPdf = 1.0f;
+                lastDelta = true;
+                depth = 0u;
+                specDepth = 0u;
+                if (sampleInChunk < rp.chunkSize && s < rp.spp) {
+                    beginSample(rp, pool.pixelOfLocal[st.y % rp.localPixels], s, rng, nextO, nextD);
                     stillAlive = true;
+                } else {
+                    needItem = true;
+                    flushNext = true;       // publish this item after its last connections have been added
+                    flushItem = st.y;
                 }
             } else {
                 stillAlive = true;
             }
-
-            st.x = rng;
-            st.z = (stillAlive ? kFlagAlive : 0u) | (lastDelta ? kFlagLastDelta : 0u) | (depth << kFlagDepthShift) |
-                   (specDepth << kFlagSpecDepthShift);
-            if (stillAlive) {
-                pool.rayOrg[slot] = mk4(nextO, 0.0f);
-                pool.rayDir[slot] = mk4(nextD, 0.0f);
-                pool.throughput[slot] = mk4(thr, lastPdf);
-            }
         }
-        pool.accum[slot] = mk4(acc, 0.0f);
+    }
+
+    // ---- claim new work items (one atomic per wave) ----
+    {
+        const uint32_t item = waveAppend(pool.nextItem, needItem);
+        if (needItem && item < rp.itemCount) {
+            st.y = item;
+            sampleInChunk = 0u;
+            beginSample(rp, pool.pixelOfLocal[item % rp.localPixels], (item / rp.localPixels) * rp.chunkSize, rng, nextO, nextD);
+            stillAlive = true;
+        }
     }
 
     // ---- enqueue this bounce's light connections (one atomic per wave and record slot) ----
@@ -649,8 +726,17 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(RenderParams rp, SceneVie
         }
     }
     if (touched) {
-        st.w = pendingMask;
+        st.x = rng;
+        st.z = (stillAlive ? kFlagAlive : 0u) | (lastDelta ? kFlagLastDelta : 0u) | (flushNext ? kFlagFlush : 0u) |
+               (depth << kFlagDepthShift) | (specDepth << kFlagSpecDepthShift);
+        st.w = pendingMask | (sampleInChunk << 8);
         pool.state[slot] = st;
+        pool.accum[slot] = mk4(acc, __uint_as_float(flushItem));
+        if (stillAlive) {
+            pool.rayOrg[slot] = mk4(nextO, 0.0f);
+            pool.rayDir[slot] = mk4(nextD, 0.0f);
+            pool.throughput[slot] = mk4(thr, lastPdf);
+        }
     }
     const uint32_t aliveInWave = static_cast<uint32_t>(__popcll(__ballot(stillAlive)));
     if (laneId() == 0 && aliveInWave != 0u) atomicAdd(aliveSlot, aliveInWave);
@@ -701,77 +787,121 @@ __device__ __forceinline__ f3 alongEnv(const RenderParams& rp, const SceneView& 
     return finite3(contrib) ? clampFirefly(thr, contrib, cc) : mk3(0.0f);
 }
 
+
+
+// Contribution of a specular-NEE ray whose closest hit `h` has been found (kind 1 records).
+__device__ __forceinline__ f3 rectContribution(const RenderParams& rp, const SceneView& sc, const ClampCfg& cc, f3 org, f3 dir,
+                                               const TraceHit& h, f3 weight, float bsdfPdfIn, f3 thr) {
+    if (h.prim == kHitMiss) return mk3(0.0f);
+    const Surface ls = reconstruct(sc, org, dir, h.t, h.u, h.v, h.prim);
+    f3 emission;
+    float pdf;
+    if (!rectLightHit(sc, ls, org, rp.emissionScale, emission, pdf)) return mk3(0.0f);
+    const float lightPdf = smax(pdf, kSpecNeePdfFloor);
+    const float invLightPdf = smin(1.0f / lightPdf, kSpecNeeInvPdfClamp);
+    const float bsdfPdf = smax(bsdfPdfIn, kSpecNeePdfFloor);
+    const float denom = lightPdf + bsdfPdf;
+    float mis = denom > 0.0f ? (lightPdf / denom) : 0.0f;
+    mis = clampf(mis, kMisMin, kMisMax);
+    const f3 contrib = (weight * emission) * (mis * invLightPdf);
+    return finite3(contrib) ? clampFirefly(thr, contrib, cc) : mk3(0.0f);
+}
+
+// MNEE second bounce (kind 2 records): follow the specular ray to the next delta surface, scatter with a copy
+// of the rng, then look for the environment / a rectangle light along the second specular direction.
+template <bool COUNT>
+__device__ f3 mneeChain(const RenderParams& rp, const SceneView& sc, const ClampCfg& cc, f3 org, f3 dir, uint32_t rngCopy, f3 weight,
+                        float bsdfPdf, f3 thr, LaneStack& stack, TraceCounters& cntAny, TraceCounters& cntClosest, uint32_t& raysAny,
+                        uint32_t& raysClosest) {
+    f3 result = mk3(0.0f);
+    if (COUNT) ++raysClosest;
+    const TraceHit h = traverse<false, COUNT>(sc, org, dir, kEps, INFINITY, stack, cntClosest);
+    if (h.prim == kHitMiss || sc.materialCount == 0u) return result;
+    const Surface cs = reconstruct(sc, org, dir, h.t, h.u, h.v, h.prim);
+    f3 tmpE;
+    float tmpP;
+    if (sc.rectLightCount > 0u && rectLightHit(sc, cs, org, rp.emissionScale, tmpE, tmpP)) return result;
+    const Mat cm{sc.materials + static_cast<size_t>(min(cs.material, sc.materialCount - 1u)) * kMaterialVec4};
+    if (!materialIsDelta(cm)) return result;
+    f3 cn = cs.normal;
+    if (dot(cn, cn) <= 0.0f) cn = mk3(0.0f, 1.0f, 0.0f);
+    cn = normalize(cn);
+    const f3 cin = normalize(dir);
+    const BsdfSampleResult s2 = sampleBsdf(cm, cs.position, cn, -cin, cin, cs.frontFace, rngCopy, cc);
+    if (!(s2.pdf > 0.0f && s2.isDelta && dot(s2.dir, s2.dir) > 0.0f && finite3(s2.weight))) return result;
+    const f3 d2 = normalize(s2.dir);
+    const f3 o2 = offsetOrigin(cs, d2);
+    const f3 w2 = weight * s2.weight;
+    const float pdf2 = bsdfPdf * s2.pdf;
+    if (sc.envSampling) {
+        if (COUNT) ++raysAny;
+        result += alongEnv<COUNT>(rp, sc, cc, o2, d2, w2, pdf2, thr, stack, cntAny);
+    }
+    if (sc.rectLightCount > 0u) {
+        if (COUNT) ++raysClosest;
+        result += alongRect<COUNT>(rp, sc, cc, o2, d2, w2, pdf2, thr, stack, cntClosest);
+    }
+    return result;
+}
+
 }  // namespace
 
 template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride) {
+__global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride,
+                                                          uint32_t* workCounter) {
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
     stack.lds = ldsStack + threadIdx.x;
     stack.spill = spill + gtid;
     stack.spillStride = spillStride;
+    stack.sp = 0u;
     TraceCounters cnt{0u, 0u}, cntClosest{0u, 0u};
     uint32_t rays = 0u, raysClosest = 0u, early = 0u;
-    const uint32_t total = *pool.shadowCount;
     const ClampCfg cc = clampCfg(rp);
-    for (uint32_t q = gtid; q < total; q += gridDim.x * kTraceBlock) {
-        const uint32_t entry = pool.shadowQueue[q];
-        const uint32_t slot = entry / kRecSlots, which = entry % kRecSlots;
-        const ShadowRecordView& r = pool.rec[which];
-        const float4 o4 = r.org[slot], d4 = r.dir[slot];
-        const f3 org = mk3(o4), dir = mk3(d4);
-        const uint32_t kind = __float_as_uint(d4.w);
-        if (kind == 0u) {
-            const TraceHit h = traverse<true, COUNT>(sc, org, dir, kEps, o4.w, stack, cnt);
-            if (COUNT) { ++rays; early += (h.prim != kHitMiss) ? 1u : 0u; }
-            if (h.prim != kHitMiss) r.a[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        } else if (kind == 1u) {
-            const float4 a4 = r.a[slot];
-            const f3 thr = mk3(r.b[slot]);
-            if (COUNT) ++raysClosest;
-            const f3 c = alongRect<COUNT>(rp, sc, cc, org, dir, mk3(a4), a4.w, thr, stack, cntClosest);
-            r.a[slot] = mk4(c, 0.0f);
-        } else {
-            // MNEE second bounce: follow the refracted ray to the next delta surface, scatter with a copy of
-            // the rng, then look for the environment / a rectangle light along the second specular direction
-            const float4 a4 = r.a[slot];
-            const f3 thr = mk3(r.b[slot]);
-            f3 result = mk3(0.0f);
-            if (COUNT) ++raysClosest;
-            const TraceHit h = traverse<false, COUNT>(sc, org, dir, kEps, INFINITY, stack, cntClosest);
-            if (h.prim != kHitMiss && sc.materialCount > 0u) {
-                const Surface cs = reconstruct(sc, org, dir, h.t, h.u, h.v, h.prim);
-                f3 tmpE;
-                float tmpP;
-                const bool isLight = sc.rectLightCount > 0u && rectLightHit(sc, cs, org, rp.emissionScale, tmpE, tmpP);
-                if (!isLight) {
-                    const Mat cm{sc.materials + static_cast<size_t>(min(cs.material, sc.materialCount - 1u)) * kMaterialVec4};
-                    if (materialIsDelta(cm)) {
-                        f3 cn = cs.normal;
-                        if (dot(cn, cn) <= 0.0f) cn = mk3(0.0f, 1.0f, 0.0f);
-                        cn = normalize(cn);
-                        const f3 cin = normalize(dir);
-                        uint32_t chainRng = __float_as_uint(o4.w);
-                        const BsdfSampleResult s2 = sampleBsdf(cm, cs.position, cn, -cin, cin, cs.frontFace, chainRng, cc);
-                        if (s2.pdf > 0.0f && s2.isDelta && dot(s2.dir, s2.dir) > 0.0f && finite3(s2.weight)) {
-                            const f3 d2 = normalize(s2.dir);
-                            const f3 o2 = offsetOrigin(cs, d2);
-                            const f3 w2 = mk3(a4) * s2.weight;
-                            const float pdf2 = a4.w * s2.pdf;
-                            if (sc.envSampling) {
-                                if (COUNT) ++rays;
-                                result += alongEnv<COUNT>(rp, sc, cc, o2, d2, w2, pdf2, thr, stack, cnt);
-                            }
-                            if (sc.rectLightCount > 0u) {
-                                if (COUNT) ++raysClosest;
-                                result += alongRect<COUNT>(rp, sc, cc, o2, d2, w2, pdf2, thr, stack, cntClosest);
-                            }
-                        }
-                    }
+
+    WaveFeeder feeder;
+    feeder.init(workCounter, *pool.shadowCount);
+    Trav t;
+    t.cur = 0u;
+    bool active = false;
+    uint32_t myEntry = 0u;
+    while (true) {
+        const int nActive = __popcll(__ballot(active));
+        if (nActive < kRefillBelow && !feeder.exhausted) {
+            const uint32_t q = feeder.take(!active);
+            if (q != WaveFeeder::kNone) {
+                const uint32_t entry = pool.shadowQueue[q];
+                const uint32_t slot = entry / kRecSlots, which = entry % kRecSlots;
+                const ShadowRecordView& r = pool.rec[which];
+                const float4 o4 = r.org[slot], d4 = r.dir[slot];
+                const uint32_t kind = __float_as_uint(d4.w);
+                if (kind != 2u) {   // kind 2 (MNEE chains) is resolved by k_connect_chain
+                    myEntry = entry;
+                    if (COUNT) { if (kind == 0u) ++rays; else ++raysClosest; }
+                    active = travBegin(sc, t, mk3(o4), mk3(d4), kEps, kind == 0u ? o4.w : INFINITY, kind == 0u, stack);
+                    if (!active && kind != 0u) r.a[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 }
             }
-            r.a[slot] = mk4(result, 0.0f);
+            continue;
+        }
+        if (nActive == 0) break;
+        if (active) {
+            // nodes/prims of closest-hit (kind 1) rays are booked with the extend counters
+            const bool more = t.anyHit ? travStep<COUNT>(sc, t, stack, cnt) : travStep<COUNT>(sc, t, stack, cntClosest);
+            if (!more) {
+                active = false;
+                const uint32_t slot = myEntry / kRecSlots, which = myEntry % kRecSlots;
+                const ShadowRecordView& r = pool.rec[which];
+                if (t.anyHit) {
+                    if (COUNT) early += (t.hit.prim != kHitMiss) ? 1u : 0u;
+                    if (t.hit.prim != kHitMiss) r.a[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                } else {
+                    const float4 a4 = r.a[slot];
+                    const f3 c = rectContribution(rp, sc, cc, t.org, t.dir, t.hit, mk3(a4), a4.w, mk3(r.b[slot]));
+                    r.a[slot] = mk4(c, 0.0f);
+                }
+            }
         }
     }
     if (COUNT) {
@@ -785,22 +915,64 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams rp, SceneV
     }
 }
 
+// MNEE two-bounce chains (kind 2 records; only launched when enableMnee && enableMneeSecondary).
+template <bool COUNT>
+__global__ void __launch_bounds__(kTraceBlock) k_connect_chain(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride) {
+    __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
+    const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
+    LaneStack stack;
+    stack.lds = ldsStack + threadIdx.x;
+    stack.spill = spill + gtid;
+    stack.spillStride = spillStride;
+    stack.sp = 0u;
+    TraceCounters cnt{0u, 0u}, cntClosest{0u, 0u};
+    uint32_t rays = 0u, raysClosest = 0u;
+    const ClampCfg cc = clampCfg(rp);
+    const uint32_t total = *pool.shadowCount;
+    for (uint32_t q = gtid; q < total; q += gridDim.x * kTraceBlock) {
+        const uint32_t entry = pool.shadowQueue[q];
+        const uint32_t slot = entry / kRecSlots, which = entry % kRecSlots;
+        const ShadowRecordView& r = pool.rec[which];
+        const float4 d4 = r.dir[slot];
+        if (__float_as_uint(d4.w) != 2u) continue;
+        const float4 o4 = r.org[slot], a4 = r.a[slot];
+        const f3 c = mneeChain<COUNT>(rp, sc, cc, mk3(o4), mk3(d4), __float_as_uint(o4.w), mk3(a4), a4.w, mk3(r.b[slot]), stack, cnt,
+                                      cntClosest, rays, raysClosest);
+        r.a[slot] = mk4(c, 0.0f);
+    }
+    if (COUNT) {
+        addCounter(pool.counters, kCntShadowRays, rays);
+        addCounter(pool.counters, kCntShadowNodes, cnt.nodes);
+        addCounter(pool.counters, kCntShadowPrims, cnt.prims);
+        addCounter(pool.counters, kCntExtendRays, raysClosest);
+        addCounter(pool.counters, kCntExtendNodes, cntClosest.nodes);
+        addCounter(pool.counters, kCntExtendPrims, cntClosest.prims);
+    }
+}
+
 // =====================================================================================================
 // k_resolve: fixed-order per-pixel reduction
 // =====================================================================================================
+__global__ void __launch_bounds__(256) k_flush(RenderParams rp, PathPool pool) {
+    // after the last bounce: add the connections still outstanding and publish unfinished/unflushed items
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= pool.slots) return;
+    const uint4 st = pool.state[slot];
+    if (!(st.z & kFlagFlush)) return;
+    const float4 acc4 = pool.accum[slot];
+    f3 acc = mk3(acc4);
+    for (uint32_t k = 0; k < kRecSlots; ++k) {
+        if (st.w & (1u << k)) acc += mk3(pool.rec[k].a[slot]);
+    }
+    pool.itemAccum[__float_as_uint(acc4.w)] = mk4(acc, 0.0f);
+    (void)rp;
+}
+
 __global__ void __launch_bounds__(256) k_resolve(RenderParams rp, PathPool pool, uint32_t partCount, float* out) {
     const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
     if (lp >= rp.localPixels) return;
     f3 sum = mk3(0.0f);
-    for (uint32_t j = 0; j < rp.samplesInFlight; ++j) {
-        const uint32_t slot = j * rp.localPixels + lp;
-        f3 acc = mk3(pool.accum[slot]);
-        const uint32_t pending = pool.state[slot].w;
-        for (uint32_t k = 0; k < kRecSlots; ++k) {
-            if (pending & (1u << k)) acc += mk3(pool.rec[k].a[slot]);
-        }
-        sum += acc;
-    }
+    for (uint32_t c = 0; c < rp.chunkCount; ++c) sum += mk3(pool.itemAccum[static_cast<size_t>(c) * rp.localPixels + lp]);
     const f3 avg = sum / static_cast<float>(rp.spp);
     const uint32_t pixel = pool.pixelOfLocal[lp];
     const uint32_t x = pixel % rp.width, y = pixel / rp.width;
@@ -926,9 +1098,9 @@ void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig&
     const uint32_t stride = cfg.traceGrid * kTraceBlock;
     const uint32_t grid = std::min(cfg.traceGrid, ceilDiv(pool.slots, kTraceBlock));
     if (count) {
-        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride);
+        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters);
     } else {
-        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride);
+        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters);
     }
 }
 
@@ -944,13 +1116,21 @@ void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& po
 void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count, hipStream_t stream) {
     const uint32_t stride = cfg.traceGrid * kTraceBlock;
     if (count) {
-        hipLaunchKernelGGL(k_connect<true>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride);
+        hipLaunchKernelGGL(k_connect<true>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1);
     } else {
-        hipLaunchKernelGGL(k_connect<false>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride);
+        hipLaunchKernelGGL(k_connect<false>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1);
+    }
+    if (rp.enableMnee && rp.enableMneeSecondary) {
+        if (count) {
+            hipLaunchKernelGGL(k_connect_chain<true>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride);
+        } else {
+            hipLaunchKernelGGL(k_connect_chain<false>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride);
+        }
     }
 }
 
 void launchResolve(const RenderParams& rp, const PathPool& pool, uint32_t partCount, float* dOut, hipStream_t stream) {
+    hipLaunchKernelGGL(k_flush, dim3(ceilDiv(pool.slots, 256)), dim3(256), 0, stream, rp, pool);
     hipLaunchKernelGGL(k_resolve, dim3(ceilDiv(rp.localPixels, 256)), dim3(256), 0, stream, rp, pool, partCount, dOut);
 }
 
