@@ -160,7 +160,8 @@ struct PtrDeviceScene {
     DeviceBuffer<float4> rayOrg, rayDir, hit, throughput, accum, recBuf, itemAccum;
     uint64_t poolSlots = 4ull << 20;
     DeviceBuffer<uint4> state;
-    DeviceBuffer<uint32_t> shadowQueue, scalars, pixelOfLocal, spill;
+    DeviceBuffer<uint32_t> scalars, pixelOfLocal, spill;
+    DeviceBuffer<uint2> itemReserve;
     DeviceBuffer<uint64_t> counters;
     DeviceBuffer<float> outBands;
     DeviceBuffer<float4> rayBatch;
@@ -543,7 +544,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     ds.state.ensure(slots);
     ds.itemAccum.ensure(rp.itemCount);
     ds.recBuf.ensure(static_cast<size_t>(slots) * kRecSlots * 4u);
-    ds.shadowQueue.ensure(static_cast<size_t>(slots) * kRecSlots);
+    ds.itemReserve.ensure((slots + 63u) / 64u);
 
     PathPool pool;
     std::memset(&pool, 0, sizeof(pool));
@@ -562,8 +563,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
         pool.rec[k].a = base + 2ull * slots;
         pool.rec[k].b = base + 3ull * slots;
     }
-    pool.shadowQueue = ds.shadowQueue.ptr;
-    pool.shadowCount = ds.scalars.ptr;
+    pool.itemReserve = ds.itemReserve.ptr;
     pool.aliveCount = ds.scalars.ptr + kAliveBase;
     pool.pixelOfLocal = ds.pixelOfLocal.ptr;
     pool.counters = ds.counters.ptr;
@@ -593,6 +593,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     if (count) HIP_CHECK(hipMemsetAsync(ds.counters.ptr, 0, sizeof(uint64_t) * kCounterSlots, stream));
     HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * kScalarCount, stream));
     HIP_CHECK(hipMemcpyAsync(pool.nextItem, &slots, sizeof(uint32_t), hipMemcpyHostToDevice, stream));   // items 0..slots-1 are pre-assigned
+    HIP_CHECK(hipMemsetAsync(ds.itemReserve.ptr, 0, sizeof(uint2) * ((slots + 63u) / 64u), stream));
     if (rp.maxDepth == 0) HIP_CHECK(hipMemsetAsync(ds.itemAccum.ptr, 0, sizeof(float4) * rp.itemCount, stream));
 
     const auto wall0 = std::chrono::steady_clock::now();
@@ -601,19 +602,26 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     // Worst case: every sample runs maxDepth bounces in sequence on its slot.
     const uint64_t maxIterations = static_cast<uint64_t>(rp.maxDepth) * ((itemCount64 + slots - 1) / slots + 1) * chunkSize + 8;
     const uint32_t checkEvery = 4;
+    // Phase 1: while unclaimed work items remain nobody needs to count survivors; the host only peeks at the
+    // item head every few bounces.  Phase 2 (queue dry): k_shade counts live slots so the loop can stop.
+    bool queueDry = false;
     while (rp.maxDepth > 0) {
         const uint32_t ring = static_cast<uint32_t>(iterations % kAliveRing);
         uint32_t* aliveSlot = ds.scalars.ptr + kAliveBase + ring;
-        HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * 3, stream));  // shadow queue length + both work heads
-        HIP_CHECK(hipMemsetAsync(aliveSlot, 0, sizeof(uint32_t), stream));
+        HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * 3, stream));  // work heads of k_extend / k_connect
+        if (queueDry) HIP_CHECK(hipMemsetAsync(aliveSlot, 0, sizeof(uint32_t), stream));
         timedLaunch(0, [&] { launchExtend(ds.view, pool, cfg, count, stream); });
-        timedLaunch(1, [&] { launchShade(rp, ds.view, pool, aliveSlot, count, stream); });
+        timedLaunch(1, [&] { launchShade(rp, ds.view, pool, aliveSlot, queueDry, count, stream); });
         timedLaunch(2, [&] { launchConnect(rp, ds.view, pool, cfg, count, stream); });
         ++iterations;
         if (iterations % checkEvery == 0 || iterations >= maxIterations) {
-            HIP_CHECK(hipMemcpyAsync(ds.pinnedAlive, aliveSlot, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(ds.pinnedAlive, queueDry ? aliveSlot : pool.nextItem, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
-            if (ds.pinnedAlive[0] == 0u) break;
+            if (queueDry) {
+                if (ds.pinnedAlive[0] == 0u) break;
+            } else if (ds.pinnedAlive[0] >= rp.itemCount) {
+                queueDry = true;
+            }
             if (iterations >= maxIterations) throw HipError{"wavefront loop did not terminate"};
         }
     }

@@ -108,9 +108,8 @@ struct PathPool {
     float4* itemAccum;     // [itemCount] finished work items (summed per pixel, in chunk order, by k_resolve)
     uint32_t* nextItem;    // [1] next unclaimed work item
     ShadowRecordView rec[kRecSlots];
-    uint32_t* shadowQueue;     // entries = slot*kRecSlots + which
-    uint32_t* shadowCount;     // [1]
-    uint32_t* aliveCount;      // [1]
+    uint2* itemReserve;        // [slots/64] per-wave reservation {next, end} of work items (one atomic per 64 items)
+    uint32_t* aliveCount;      // ring of alive counters (host termination check)
     const uint32_t* pixelOfLocal;  // local pixel -> y*width + x
     uint64_t* counters;        // kCounterSlots
     uint32_t slots;

@@ -16,8 +16,8 @@ struct LaunchConfig {
 
 void launchGenerate(const RenderParams& rp, const PathPool& pool, hipStream_t stream);
 void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count, hipStream_t stream);
-void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, uint32_t* aliveSlot, bool count,
-                 hipStream_t stream);
+void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, uint32_t* aliveSlot, bool countAlive,
+                 bool count, hipStream_t stream);
 void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count,
                    hipStream_t stream);
 // Adds outstanding light connections, reduces the slots of each pixel in fixed order and writes

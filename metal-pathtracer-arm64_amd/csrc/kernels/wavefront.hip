@@ -112,6 +112,7 @@ struct WaveFeeder {
     }
 };
 
+constexpr uint32_t kItemReserve = 64u;   // work items a wave reserves per atomic on the global head
 constexpr int kRefillBelow = 48;   // hand out new rays once fewer than this many lanes are still traversing
 
 // ---------------------------------------------------------------- camera
@@ -432,7 +433,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool p
 // k_shade
 // =====================================================================================================
 template <bool COUNT>
-__global__ void __launch_bounds__(kShadeBlock) k_shade(RenderParams rp, SceneView sc, PathPool pool, uint32_t* aliveSlot) {
+__global__ void __launch_bounds__(kShadeBlock) k_shade(RenderParams rp, SceneView sc, PathPool pool, uint32_t* aliveSlot, uint32_t countAlive) {
     const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x;
     const bool inRange = slot < pool.slots;
     uint4 st = inRange ? pool.state[slot] : make_uint4(0u, 0u, 0u, 0u);
@@ -704,26 +705,45 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(RenderParams rp, SceneVie
         }
     }
 
-    // ---- claim new work items (one atomic per wave) ----
+    // ---- claim new work items ----
+    // Each wave holds a reservation of kItemReserve consecutive items in HBM and refills it with ONE atomic on
+    // the global head (a per-lane or even per-wave-per-bounce atomic on one address caps at ~88 ops/us chip-wide).
     {
-        const uint32_t item = waveAppend(pool.nextItem, needItem);
-        if (needItem && item < rp.itemCount) {
-            st.y = item;
-            sampleInChunk = 0u;
-            beginSample(rp, pool.pixelOfLocal[item % rp.localPixels], (item / rp.localPixels) * rp.chunkSize, rng, nextO, nextD);
-            stillAlive = true;
+        const unsigned long long mask = __ballot(needItem);
+        if (mask != 0ull) {
+            const uint32_t waveId = slot / 64u;     // slot >= pool.slots lanes never need items
+            const uint32_t firstLane = static_cast<uint32_t>(__ffsll(static_cast<long long>(mask))) - 1u;
+            uint2 res = pool.itemReserve[__builtin_amdgcn_readfirstlane(waveId)];
+            const uint32_t n = static_cast<uint32_t>(__popcll(mask));
+            const uint32_t avail = res.y - res.x;
+            uint32_t newBase = 0u;
+            if (avail < n) {
+                if (laneId() == firstLane) newBase = atomicAdd(pool.nextItem, kItemReserve);
+                newBase = __shfl(newBase, static_cast<int>(firstLane), 64);
+            }
+            const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << laneId()) - 1ull)));
+            const uint32_t item = (rank < avail) ? (res.x + rank) : (newBase + (rank - avail));
+            if (avail < n) {
+                res.x = newBase + (n - avail);
+                res.y = newBase + kItemReserve;
+            } else {
+                res.x += n;
+            }
+            if (laneId() == firstLane) pool.itemReserve[waveId] = res;
+            if (needItem && item < rp.itemCount) {
+                st.y = item;
+                sampleInChunk = 0u;
+                beginSample(rp, pool.pixelOfLocal[item % rp.localPixels], (item / rp.localPixels) * rp.chunkSize, rng, nextO, nextD);
+                stillAlive = true;
+            }
         }
     }
 
-    // ---- enqueue this bounce's light connections (one atomic per wave and record slot) ----
+    // light connections of this bounce: k_connect walks the slots and reads the pending mask
     uint32_t pendingMask = 0u;
 #pragma unroll
     for (uint32_t k = 0; k < kRecSlots; ++k) {
-        const uint32_t idx = waveAppend(pool.shadowCount, want[k]);
-        if (want[k]) {
-            pool.shadowQueue[idx] = slot * kRecSlots + k;
-            pendingMask |= 1u << k;
-        }
+        if (want[k]) pendingMask |= 1u << k;
     }
     if (touched) {
         st.x = rng;
@@ -738,8 +758,10 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(RenderParams rp, SceneVie
             pool.throughput[slot] = mk4(thr, lastPdf);
         }
     }
-    const uint32_t aliveInWave = static_cast<uint32_t>(__popcll(__ballot(stillAlive)));
-    if (laneId() == 0 && aliveInWave != 0u) atomicAdd(aliveSlot, aliveInWave);
+    if (countAlive) {   // only requested once the item queue has run dry (host termination check)
+        const uint32_t aliveInWave = static_cast<uint32_t>(__popcll(__ballot(stillAlive)));
+        if (laneId() == 0 && aliveInWave != 0u) atomicAdd(aliveSlot, aliveInWave);
+    }
     if (COUNT) {
         addCounter(pool.counters, kCntShadedHits, shadedHit);
         addCounter(pool.counters, kCntTriangleHits, triHit);
@@ -860,46 +882,55 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams rp, SceneV
     uint32_t rays = 0u, raysClosest = 0u, early = 0u;
     const ClampCfg cc = clampCfg(rp);
 
+    // The work list is the slot pool itself: a lane takes a slot, reads its pending mask and resolves that
+    // slot's records one after another (no compaction queue -> no hot atomic counter in k_shade).
     WaveFeeder feeder;
-    feeder.init(workCounter, *pool.shadowCount);
+    feeder.init(workCounter, pool.slots);
     Trav t;
     t.cur = 0u;
     bool active = false;
-    uint32_t myEntry = 0u;
+    uint32_t mySlot = 0u, myRec = 0u, bits = 0u;
     while (true) {
+        if (!active && bits != 0u) {
+            // next record of the slot this lane already holds
+            myRec = static_cast<uint32_t>(__ffs(static_cast<int>(bits))) - 1u;
+            bits &= bits - 1u;
+            const ShadowRecordView& r = pool.rec[myRec];
+            const float4 o4 = r.org[mySlot], d4 = r.dir[mySlot];
+            const uint32_t kind = __float_as_uint(d4.w);
+            if (kind != 2u) {   // kind 2 (MNEE chains) is resolved by k_connect_chain
+                if (COUNT) { if (kind == 0u) ++rays; else ++raysClosest; }
+                active = travBegin(sc, t, mk3(o4), mk3(d4), kEps, kind == 0u ? o4.w : INFINITY, kind == 0u, stack);
+                if (!active && kind != 0u) r.a[mySlot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
         const int nActive = __popcll(__ballot(active));
+        const bool anyBits = __ballot(bits != 0u) != 0ull;
         if (nActive < kRefillBelow && !feeder.exhausted) {
-            const uint32_t q = feeder.take(!active);
-            if (q != WaveFeeder::kNone) {
-                const uint32_t entry = pool.shadowQueue[q];
-                const uint32_t slot = entry / kRecSlots, which = entry % kRecSlots;
-                const ShadowRecordView& r = pool.rec[which];
-                const float4 o4 = r.org[slot], d4 = r.dir[slot];
-                const uint32_t kind = __float_as_uint(d4.w);
-                if (kind != 2u) {   // kind 2 (MNEE chains) is resolved by k_connect_chain
-                    myEntry = entry;
-                    if (COUNT) { if (kind == 0u) ++rays; else ++raysClosest; }
-                    active = travBegin(sc, t, mk3(o4), mk3(d4), kEps, kind == 0u ? o4.w : INFINITY, kind == 0u, stack);
-                    if (!active && kind != 0u) r.a[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
+            const uint32_t idx = feeder.take(!active && bits == 0u);
+            if (idx != WaveFeeder::kNone) {
+                mySlot = idx;
+                bits = pool.state[idx].w & ((1u << kRecSlots) - 1u);
             }
             continue;
         }
-        if (nActive == 0) break;
+        if (nActive == 0) {
+            if (!anyBits) break;
+            continue;
+        }
         if (active) {
             // nodes/prims of closest-hit (kind 1) rays are booked with the extend counters
             const bool more = t.anyHit ? travStep<COUNT>(sc, t, stack, cnt) : travStep<COUNT>(sc, t, stack, cntClosest);
             if (!more) {
                 active = false;
-                const uint32_t slot = myEntry / kRecSlots, which = myEntry % kRecSlots;
-                const ShadowRecordView& r = pool.rec[which];
+                const ShadowRecordView& r = pool.rec[myRec];
                 if (t.anyHit) {
                     if (COUNT) early += (t.hit.prim != kHitMiss) ? 1u : 0u;
-                    if (t.hit.prim != kHitMiss) r.a[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (t.hit.prim != kHitMiss) r.a[mySlot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 } else {
-                    const float4 a4 = r.a[slot];
-                    const f3 c = rectContribution(rp, sc, cc, t.org, t.dir, t.hit, mk3(a4), a4.w, mk3(r.b[slot]));
-                    r.a[slot] = mk4(c, 0.0f);
+                    const float4 a4 = r.a[mySlot];
+                    const f3 c = rectContribution(rp, sc, cc, t.org, t.dir, t.hit, mk3(a4), a4.w, mk3(r.b[mySlot]));
+                    r.a[mySlot] = mk4(c, 0.0f);
                 }
             }
         }
@@ -915,7 +946,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams rp, SceneV
     }
 }
 
-// MNEE two-bounce chains (kind 2 records; only launched when enableMnee && enableMneeSecondary).
+// MNEE two-bounce chains (record slot 4, kind 2; only launched when enableMnee && enableMneeSecondary).
 template <bool COUNT>
 __global__ void __launch_bounds__(kTraceBlock) k_connect_chain(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride) {
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
@@ -928,11 +959,9 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect_chain(RenderParams rp, 
     TraceCounters cnt{0u, 0u}, cntClosest{0u, 0u};
     uint32_t rays = 0u, raysClosest = 0u;
     const ClampCfg cc = clampCfg(rp);
-    const uint32_t total = *pool.shadowCount;
-    for (uint32_t q = gtid; q < total; q += gridDim.x * kTraceBlock) {
-        const uint32_t entry = pool.shadowQueue[q];
-        const uint32_t slot = entry / kRecSlots, which = entry % kRecSlots;
-        const ShadowRecordView& r = pool.rec[which];
+    for (uint32_t slot = gtid; slot < pool.slots; slot += gridDim.x * kTraceBlock) {
+        if (!(pool.state[slot].w & (1u << 4))) continue;
+        const ShadowRecordView& r = pool.rec[4];
         const float4 d4 = r.dir[slot];
         if (__float_as_uint(d4.w) != 2u) continue;
         const float4 o4 = r.org[slot], a4 = r.a[slot];
@@ -1104,12 +1133,14 @@ void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig&
     }
 }
 
-void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, uint32_t* aliveSlot, bool count, hipStream_t stream) {
+void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, uint32_t* aliveSlot, bool countAlive, bool count,
+                 hipStream_t stream) {
     const uint32_t grid = ceilDiv(pool.slots, kShadeBlock);
+    const uint32_t ca = countAlive ? 1u : 0u;
     if (count) {
-        hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, aliveSlot);
+        hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, aliveSlot, ca);
     } else {
-        hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, aliveSlot);
+        hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, aliveSlot, ca);
     }
 }
 
