@@ -158,7 +158,7 @@ struct PtrDeviceScene {
 
     // render-time resources, grown on demand and kept across calls
     DeviceBuffer<float4> rayOrg, rayDir, hit, throughput, accum, recBuf, itemAccum;
-    uint64_t poolSlots = 4ull << 20;
+    uint64_t poolSlots = 8ull << 20;
     DeviceBuffer<uint4> state;
     DeviceBuffer<uint32_t> scalars, pixelOfLocal, spill;
     DeviceBuffer<uint2> itemReserve;
@@ -388,6 +388,10 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     HIP_CHECK(hipGetDeviceProperties(&prop, ds.device));
     const uint32_t cus = prop.multiProcessorCount > 0 ? static_cast<uint32_t>(prop.multiProcessorCount) : 256u;
     ds.traceGrid = cus * 8u;   // 8 blocks of 256 threads per CU: fills the wave slots, grid-stride the rest
+    if (const char* e = std::getenv("PTR_TRACE_BLOCKS_PER_CU")) {   // tuning knob
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 16) ds.traceGrid = cus * static_cast<uint32_t>(v);
+    }
     if (const char* e = std::getenv("PTR_POOL_SLOTS")) {   // tuning knob: resident path slots
         const unsigned long long v = std::strtoull(e, nullptr, 10);
         if (v >= 1024) ds.poolSlots = v;

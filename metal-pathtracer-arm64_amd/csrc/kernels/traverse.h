@@ -102,14 +102,17 @@ __device__ __forceinline__ bool sphereTest(float4 s, f3 org, f3 dir, float tnear
 }
 
 // ---- stepwise traversal (persistent waves with lane refill) -------------------------------------------
-// A lane owns one ray at a time; travStep() advances it by one node or one leaf.  The wave keeps looping over
-// travStep while idle lanes are handed new rays (wavefront.hip: WaveFeeder), so a long traversal in one lane
-// no longer idles the other 63 — measured lane utilisation of the plain per-ray loop was ~11 %.
+// A lane owns one ray at a time and is either at an internal node or inside a leaf.  Each wave iteration runs
+// ONE kind of step, chosen by majority vote over the lanes (travVote): a node step (one 64 B node, two slab
+// tests) or a primitive step (one 48 B triangle / one sphere).  The branch is wave-uniform, so the wave never
+// executes both bodies in one iteration, and lanes of the minority kind simply wait until they are the
+// majority.  With the plain per-ray loop VALU lane utilisation was ~11 %; lane refill alone gave ~30 %.
 struct Trav {
     f3 org, dir, inv;
     float tnear;
     TraceHit hit;
-    uint32_t cur;
+    uint32_t cur;        // internal node index, or leaf reference while primitives remain
+    uint32_t leafPos;    // next primitive inside the current leaf
     bool anyHit;
 };
 
@@ -125,63 +128,91 @@ __device__ __forceinline__ bool travBegin(const SceneView& sc, Trav& t, f3 org, 
     t.hit.prim = kHitMiss;
     t.anyHit = anyHit;
     t.cur = sc.rootRef;
+    t.leafPos = 0u;
     stack.sp = 0;
     return sc.rootRef != kRefEmpty;
 }
 
-// One traversal step; returns false once the ray is finished (result in t.hit).
-template <bool COUNT>
-__device__ __forceinline__ bool travStep(const SceneView& sc, Trav& t, LaneStack& stack, TraceCounters& cnt) {
-    const uint32_t cur = t.cur;
-    if (!(cur & kRefLeafBit)) {
-        const float4* n = sc.nodes + static_cast<size_t>(cur) * 4u;
-        const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-        if (COUNT) ++cnt.nodes;
-        const uint32_t ref0 = __float_as_uint(n0.w), ref1 = __float_as_uint(n1.w);
-        float e0, e1;
-        const bool h0 = (ref0 != kRefEmpty) && slabTest(mk3(n0), mk3(n1), t.org, t.inv, t.tnear, t.hit.t, e0);
-        const bool h1 = (ref1 != kRefEmpty) && slabTest(mk3(n2), mk3(n3), t.org, t.inv, t.tnear, t.hit.t, e1);
-        if (h0 && h1) {
-            const bool firstIs0 = e0 <= e1;
-            stack.push(firstIs0 ? ref1 : ref0);
-            t.cur = firstIs0 ? ref0 : ref1;
-            return true;
-        }
-        if (h0) { t.cur = ref0; return true; }
-        if (h1) { t.cur = ref1; return true; }
-    } else {
-        const uint32_t first = cur & kRefOffsetMask;
-        const uint32_t count = ((cur >> kRefCountShift) & 0xFu) + 1u;
-        if (COUNT) { ++cnt.nodes; cnt.prims += count; }
-        if (cur & kRefSphereBit) {
-            for (uint32_t i = 0; i < count; ++i) {
-                float tt;
-                if (sphereTest(sc.spheres[first + i], t.org, t.dir, t.tnear, t.hit.t, tt)) {
-                    t.hit.t = tt;
-                    t.hit.u = 0.0f;
-                    t.hit.v = 0.0f;
-                    t.hit.prim = (first + i) | kHitSphereBit;
-                    if (t.anyHit) return false;
-                }
-            }
-        } else {
-            for (uint32_t i = 0; i < count; ++i) {
-                const float4* tp = sc.tris + static_cast<size_t>(first + i) * 3u;
-                const float4 a = tp[0], b = tp[1], c = tp[2];
-                float tt, u, v;
-                if (triangleTest(mk3(a), mk3(b), mk3(c), t.org, t.dir, t.tnear, t.hit.t, tt, u, v)) {
-                    t.hit.t = tt;
-                    t.hit.u = u;
-                    t.hit.v = v;
-                    t.hit.prim = first + i;
-                    if (t.anyHit) return false;
-                }
-            }
-        }
-    }
+__device__ __forceinline__ bool travAtLeaf(const Trav& t) { return (t.cur & kRefLeafBit) != 0u; }
+
+// pops the next subtree; false when the traversal is complete
+__device__ __forceinline__ bool travPop(Trav& t, LaneStack& stack) {
     if (stack.sp == 0) return false;
     t.cur = stack.pop();
+    t.leafPos = 0u;
     return true;
+}
+
+// Node step (t.cur is an internal node).  Returns false once the ray is finished.
+template <bool COUNT>
+__device__ __forceinline__ bool travNodeStep(const SceneView& sc, Trav& t, LaneStack& stack, TraceCounters& cnt) {
+    const float4* n = sc.nodes + static_cast<size_t>(t.cur) * 4u;
+    const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+    if (COUNT) ++cnt.nodes;
+    const uint32_t ref0 = __float_as_uint(n0.w), ref1 = __float_as_uint(n1.w);
+    float e0, e1;
+    const bool h0 = (ref0 != kRefEmpty) && slabTest(mk3(n0), mk3(n1), t.org, t.inv, t.tnear, t.hit.t, e0);
+    const bool h1 = (ref1 != kRefEmpty) && slabTest(mk3(n2), mk3(n3), t.org, t.inv, t.tnear, t.hit.t, e1);
+    t.leafPos = 0u;
+    if (h0 && h1) {
+        const bool firstIs0 = e0 <= e1;
+        stack.push(firstIs0 ? ref1 : ref0);
+        t.cur = firstIs0 ? ref0 : ref1;
+        return true;
+    }
+    if (h0) { t.cur = ref0; return true; }
+    if (h1) { t.cur = ref1; return true; }
+    return travPop(t, stack);
+}
+
+// Primitive step (t.cur is a leaf): tests primitive number t.leafPos of the leaf.  Returns false once finished.
+template <bool COUNT>
+__device__ __forceinline__ bool travPrimStep(const SceneView& sc, Trav& t, LaneStack& stack, TraceCounters& cnt) {
+    const uint32_t cur = t.cur;
+    const uint32_t first = cur & kRefOffsetMask;
+    const uint32_t count = ((cur >> kRefCountShift) & 0xFu) + 1u;
+    const uint32_t index = first + t.leafPos;
+    if (COUNT) { ++cnt.prims; if (t.leafPos == 0u) ++cnt.nodes; }
+    if (cur & kRefSphereBit) {
+        float tt;
+        if (sphereTest(sc.spheres[index], t.org, t.dir, t.tnear, t.hit.t, tt)) {
+            t.hit.t = tt;
+            t.hit.u = 0.0f;
+            t.hit.v = 0.0f;
+            t.hit.prim = index | kHitSphereBit;
+            if (t.anyHit) return false;
+        }
+    } else {
+        const float4* tp = sc.tris + static_cast<size_t>(index) * 3u;
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        float tt, u, v;
+        if (triangleTest(mk3(a), mk3(b), mk3(c), t.org, t.dir, t.tnear, t.hit.t, tt, u, v)) {
+            t.hit.t = tt;
+            t.hit.u = u;
+            t.hit.v = v;
+            t.hit.prim = index;
+            if (t.anyHit) return false;
+        }
+    }
+    if (++t.leafPos < count) return true;
+    return travPop(t, stack);
+}
+
+// One wave iteration for all traversing lanes: majority vote between node steps and primitive steps.
+// Returns (per lane) false when that lane's ray has just finished.  Lanes not voted for return true unchanged.
+template <bool COUNT>
+__device__ __forceinline__ bool travVote(const SceneView& sc, Trav& t, bool active, LaneStack& stack, TraceCounters& cnt) {
+    const bool wantsPrim = active && travAtLeaf(t);
+    const bool wantsNode = active && !travAtLeaf(t);
+    const int nPrim = __popcll(__ballot(wantsPrim));
+    const int nNode = __popcll(__ballot(wantsNode));
+    bool more = true;
+    if (nNode >= nPrim) {
+        if (wantsNode) more = travNodeStep<COUNT>(sc, t, stack, cnt);
+    } else {
+        if (wantsPrim) more = travPrimStep<COUNT>(sc, t, stack, cnt);
+    }
+    return more;
 }
 
 // Closest hit (ANY = false) or first hit (ANY = true).  Returns hit.prim == kHitMiss on a miss.

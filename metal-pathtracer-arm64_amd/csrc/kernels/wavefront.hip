@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool p
             continue;
         }
         if (nActive == 0) break;
-        if (active && !travStep<COUNT>(sc, t, stack, cnt)) {
+        if (!travVote<COUNT>(sc, t, active, stack, cnt)) {
             active = false;
             pool.hit[mySlot] = make_float4(t.hit.t, t.hit.u, t.hit.v, __uint_as_float(t.hit.prim));
         }
@@ -918,9 +918,15 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams rp, SceneV
             if (!anyBits) break;
             continue;
         }
-        if (active) {
-            // nodes/prims of closest-hit (kind 1) rays are booked with the extend counters
-            const bool more = t.anyHit ? travStep<COUNT>(sc, t, stack, cnt) : travStep<COUNT>(sc, t, stack, cntClosest);
+        {
+            // counting build: nodes/prims of closest-hit (kind 1) rays are booked with the extend counters
+            TraceCounters step{0u, 0u};
+            const bool more = travVote<COUNT>(sc, t, active, stack, step);
+            if (COUNT) {
+                TraceCounters& dst = t.anyHit ? cnt : cntClosest;
+                dst.nodes += step.nodes;
+                dst.prims += step.prims;
+            }
             if (!more) {
                 active = false;
                 const ShadowRecordView& r = pool.rec[myRec];
