@@ -14,7 +14,6 @@ namespace ptr {
 namespace {
 
 constexpr int kBins = 16;
-constexpr uint32_t kLeafMax = 4;                                   // SAH may stop at <= 4 primitives
 constexpr uint32_t kDepthLimit = ptrk::kTraversalStackDepth - 2;   // leaves sit at depth <= kDepthLimit
 constexpr uint32_t kParallelThreshold = 1u << 16;
 
@@ -53,6 +52,7 @@ struct Builder {
     std::vector<TempNode> nodes;
     std::atomic<uint32_t> nextNode{1};
     std::atomic<int> freeThreads{0};
+    uint32_t kLeafMax = 4;   // SAH may stop at <= kLeafMax primitives
 
     explicit Builder(const std::vector<BuildPrim>& p) : prims(p) {}
 
@@ -278,12 +278,13 @@ struct Flattener {
 
 }  // namespace
 
-void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t threads) {
+void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t threads, uint32_t leafMax) {
     out = FlatBvh{};
     const uint32_t n = static_cast<uint32_t>(prims.size());
     if (n == 0) return;
 
     Builder b(prims);
+    b.kLeafMax = std::min(std::max(leafMax, 1u), ptrk::kMaxLeafPrims);
     b.centers.resize(static_cast<size_t>(n) * 3);
     for (uint32_t i = 0; i < n; ++i) {
         for (int a = 0; a < 3; ++a) b.centers[static_cast<size_t>(i) * 3 + a] = 0.5f * (prims[i].lo[a] + prims[i].hi[a]);
@@ -310,6 +311,47 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
     out.sphereOrder.reserve(sph);
     f.run(std::max(static_cast<double>(b.nodes[0].box.halfArea()), 1e-30));
     out.rootRef = 0u;
+
+    // 16-bit grid version of the nodes.  lo is rounded down and hi up, plus one cell of padding on each
+    // side, so a quantised box always contains the float box (the traversal stays conservative).
+    const Aabb& scene = b.nodes[0].box;
+    double cell[3];
+    for (int a = 0; a < 3; ++a) {
+        const double extent = static_cast<double>(scene.hi[a]) - scene.lo[a];
+        cell[a] = extent > 0.0 ? extent / 65531.0 : 1.0;          // cells 2..65533 span the scene, rest is padding
+        out.gridCell[a] = static_cast<float>(cell[a]);
+        out.gridOrigin[a] = static_cast<float>(scene.lo[a] - 2.0 * cell[a]);
+    }
+    out.qnodes.assign(static_cast<size_t>(out.nodeCount) * 8, 0u);
+    auto quant = [&](float v, int axis, bool up) -> uint32_t {
+        const double g = (static_cast<double>(v) - out.gridOrigin[axis]) / static_cast<double>(out.gridCell[axis]);
+        const double q = up ? std::ceil(g) + 1.0 : std::floor(g) - 1.0;
+        return static_cast<uint32_t>(std::min(std::max(q, 0.0), 65535.0));
+    };
+    for (uint32_t i = 0; i < out.nodeCount; ++i) {
+        const float* n = out.nodes.data() + static_cast<size_t>(i) * 16;
+        uint32_t* q = out.qnodes.data() + static_cast<size_t>(i) * 8;
+        for (int c = 0; c < 2; ++c) {
+            const float* lo = n + c * 8;
+            const float* hi = n + c * 8 + 4;
+            uint32_t ref;
+            std::memcpy(&ref, n + (c == 0 ? 3 : 7), 4);
+            uint32_t* w = q + c * 4;
+            if (ref == ptrk::kRefEmpty) {
+                w[0] = w[1] = w[2] = 0u;
+            } else {
+                w[0] = quant(lo[0], 0, false) | (quant(lo[1], 1, false) << 16);
+                w[1] = quant(lo[2], 2, false) | (quant(hi[0], 0, true) << 16);
+                w[2] = quant(hi[1], 1, true) | (quant(hi[2], 2, true) << 16);
+            }
+            w[3] = ref;
+        }
+    }
+    double extentSum = 0.0;
+    for (const BuildPrim& p : prims) {
+        extentSum += std::max(std::max(p.hi[0] - p.lo[0], p.hi[1] - p.lo[1]), p.hi[2] - p.lo[2]);
+    }
+    out.meanPrimExtent = static_cast<float>(extentSum / n);
 }
 
 }  // namespace ptr

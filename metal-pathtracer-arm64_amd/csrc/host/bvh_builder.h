@@ -23,6 +23,10 @@ struct BuildPrim {
 
 struct FlatBvh {
     std::vector<float> nodes;          // 16 floats per node (see device_types.h)
+    std::vector<uint32_t> qnodes;      // 8 words per node: 16-bit grid boxes + child refs (see device_types.h)
+    float gridOrigin[3] = {0, 0, 0};
+    float gridCell[3] = {1, 1, 1};
+    float meanPrimExtent = 0.0f;       // mean of the primitives' largest box edge (quantisation quality gate)
     std::vector<uint32_t> triOrder;    // leaf-order -> index into the triangle input
     std::vector<uint32_t> sphereOrder; // leaf-order -> index into the sphere input
     uint32_t rootRef = 0xFFFFFFFFu;
@@ -32,6 +36,6 @@ struct FlatBvh {
 
 // prims: triangles and spheres mixed (isSphere flag); indices in triOrder/sphereOrder refer to the n-th
 // triangle / n-th sphere of the input in input order.
-void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t threads = 0);
+void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t threads = 0, uint32_t leafMax = 4);
 
 }  // namespace ptr

@@ -147,6 +147,7 @@ float bitsToFloat(uint32_t u) {
 
 struct PtrDeviceScene {
     int device = 0;
+    DeviceBuffer<uint4> qnodes;
     DeviceBuffer<float4> nodes, tris, triNormals, spheres, materials, rects, rectLights, envRgba;
     DeviceBuffer<uint2> sphereInfo;
     DeviceBuffer<int32_t> lightIndexByRect;
@@ -159,6 +160,7 @@ struct PtrDeviceScene {
     // render-time resources, grown on demand and kept across calls
     DeviceBuffer<float4> rayOrg, rayDir, hit, throughput, accum, recBuf, itemAccum;
     uint64_t poolSlots = 8ull << 20;
+    int refillBelow = 40;
     DeviceBuffer<uint4> state;
     DeviceBuffer<uint32_t> scalars, pixelOfLocal, spill;
     DeviceBuffer<uint2> itemReserve;
@@ -279,7 +281,9 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     if (prims.size() > kRefOffsetMask) throw HipError{"scene exceeds 64M primitives"};
 
     ptr::FlatBvh bvh;
-    ptr::BuildFlatBvh(prims, bvh);
+    uint32_t leafMax = 4;
+    if (const char* e = std::getenv("PTR_LEAF_MAX")) leafMax = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 8));
+    ptr::BuildFlatBvh(prims, bvh, 0, leafMax);
 
     // leaf-order SoA arrays
     std::vector<float> triData, triNrm, sphData;
@@ -331,6 +335,7 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
 
     HIP_CHECK(hipSetDevice(ds.device));
     ds.nodes.upload(reinterpret_cast<const float4*>(bvh.nodes.data()), bvh.nodes.size() / 4);
+    ds.qnodes.upload(reinterpret_cast<const uint4*>(bvh.qnodes.data()), bvh.qnodes.size() / 4);
     ds.tris.upload(reinterpret_cast<const float4*>(triData.data()), triData.size() / 4);
     ds.triNormals.upload(reinterpret_cast<const float4*>(triNrm.data()), triNrm.size() / 4);
     ds.spheres.upload(reinterpret_cast<const float4*>(sphData.data()), sphData.size() / 4);
@@ -351,6 +356,14 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     v.rects = ds.rects.ptr;
     v.rectLights = ds.rectLights.ptr;
     v.lightIndexByRect = ds.lightIndexByRect.ptr;
+    v.qnodes = ds.qnodes.ptr;
+    std::memcpy(v.gridOrigin, bvh.gridOrigin, sizeof(v.gridOrigin));
+    std::memcpy(v.gridCell, bvh.gridCell, sizeof(v.gridCell));
+    // 32 B quantised nodes halve the node fetches; use them unless the 16-bit grid is coarse next to the
+    // primitives (cell > 1/8 of the mean primitive extent would inflate leaf boxes noticeably)
+    const float maxCell = std::max(std::max(bvh.gridCell[0], bvh.gridCell[1]), bvh.gridCell[2]);
+    v.useQuantized = (bvh.nodeCount > 0 && maxCell * 8.0f <= bvh.meanPrimExtent) ? 1u : 0u;
+    if (const char* e = std::getenv("PTR_QUANTIZED_NODES")) v.useQuantized = std::atoi(e) != 0 ? 1u : 0u;
     v.rootRef = bvh.rootRef;
     v.materialCount = desc.materialCount;
     v.rectCount = desc.rectCount;
@@ -388,6 +401,10 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     HIP_CHECK(hipGetDeviceProperties(&prop, ds.device));
     const uint32_t cus = prop.multiProcessorCount > 0 ? static_cast<uint32_t>(prop.multiProcessorCount) : 256u;
     ds.traceGrid = cus * 8u;   // 8 blocks of 256 threads per CU: fills the wave slots, grid-stride the rest
+    if (const char* e = std::getenv("PTR_REFILL_BELOW")) {   // tuning knob
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 64) ds.refillBelow = v;
+    }
     if (const char* e = std::getenv("PTR_TRACE_BLOCKS_PER_CU")) {   // tuning knob
         const int v = std::atoi(e);
         if (v >= 1 && v <= 16) ds.traceGrid = cus * static_cast<uint32_t>(v);
@@ -573,7 +590,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     pool.counters = ds.counters.ptr;
     pool.slots = slots;
 
-    LaunchConfig cfg{ds.traceGrid, ds.spill.ptr, ds.scalars.ptr + 1};
+    LaunchConfig cfg{ds.traceGrid, ds.spill.ptr, ds.scalars.ptr + 1, ds.refillBelow};
 
     const bool timed = stats != nullptr;
     EventTimer timer;
@@ -794,7 +811,7 @@ int ptr_trace_rays(PtrDeviceScene* scene, const float* rays, uint64_t n, int any
         scene->rayBatch.upload(reinterpret_cast<const float4*>(rays), n * 2);
         scene->hitBatch.ensure(n);
         HIP_CHECK(hipMemset(scene->counters.ptr, 0, sizeof(uint64_t) * kCounterSlots));
-        LaunchConfig cfg{scene->traceGrid, scene->spill.ptr, scene->scalars.ptr + 1};
+        LaunchConfig cfg{scene->traceGrid, scene->spill.ptr, scene->scalars.ptr + 1, scene->refillBelow};
         launchTraceRays(scene->view, scene->rayBatch.ptr, n, any_hit != 0, scene->hitBatch.ptr, cfg, scene->counters.ptr, nullptr);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipDeviceSynchronize());

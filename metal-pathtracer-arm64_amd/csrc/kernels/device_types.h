@@ -16,8 +16,16 @@ namespace ptrk {
 //   kind: 0 = mesh triangle (geomIndex = mesh index), 2 = rectangle half (geomIndex = rectangle index)
 // Triangle normals (3 x float4, same order): world-space vertex normals (mesh) / rectangle normal.
 // Sphere (float4 centre+radius; uint2 {sphereIndex, materialIndex}), BVH leaf order.
+// Quantised node (2 x uint4 = 32 B): child boxes as 16-bit grid coordinates over the scene bounds
+// (lo rounded down, hi rounded up, one extra cell of padding), so a node is TWO 16-byte fetches per lane:
+//   q[0] = (c0.lo.x | c0.lo.y<<16, c0.lo.z | c0.hi.x<<16, c0.hi.y | c0.hi.z<<16, ref0)   q[1] = same for child 1
+// The slab test runs in grid space: t = (q - (org - gridOrigin)/cell) * (cell / dir).
 struct SceneView {
     const float4* nodes;
+    const uint4* qnodes;
+    float gridOrigin[3];
+    float gridCell[3];
+    uint32_t useQuantized;
     const float4* tris;
     const float4* triNormals;
     const float4* spheres;

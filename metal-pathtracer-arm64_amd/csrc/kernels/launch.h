@@ -12,6 +12,7 @@ struct LaunchConfig {
     uint32_t traceGrid;      // blocks of kTraceBlock threads for extend / connect (grid-stride)
     uint32_t* spill;         // traversal stack spill area: (kTraversalStackDepth-kLdsStackLevels) * traceGrid*kTraceBlock words
     uint32_t* workCounters;  // [2] work-queue heads of k_extend / k_connect, zeroed by the host before each launch
+    int refillBelow;         // persistent waves hand out new rays once fewer than this many lanes are traversing
 };
 
 void launchGenerate(const RenderParams& rp, const PathPool& pool, hipStream_t stream);

@@ -108,7 +108,8 @@ __device__ __forceinline__ bool sphereTest(float4 s, f3 org, f3 dir, float tnear
 // executes both bodies in one iteration, and lanes of the minority kind simply wait until they are the
 // majority.  With the plain per-ray loop VALU lane utilisation was ~11 %; lane refill alone gave ~30 %.
 struct Trav {
-    f3 org, dir, inv;
+    f3 org, dir, inv;    // inv = 1/dir, or cell/dir when the scene uses quantised nodes
+    f3 orgQ;             // (org - gridOrigin) / cell  (quantised nodes only)
     float tnear;
     TraceHit hit;
     uint32_t cur;        // internal node index, or leaf reference while primitives remain
@@ -121,6 +122,12 @@ __device__ __forceinline__ bool travBegin(const SceneView& sc, Trav& t, f3 org, 
     t.org = org;
     t.dir = dir;
     t.inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    t.orgQ = mk3(0.0f);
+    if (sc.useQuantized) {
+        const f3 cell = mk3(sc.gridCell[0], sc.gridCell[1], sc.gridCell[2]);
+        t.orgQ = (org - mk3(sc.gridOrigin[0], sc.gridOrigin[1], sc.gridOrigin[2])) / cell;
+        t.inv = t.inv * cell;
+    }
     t.tnear = tnear;
     t.hit.t = tfar;
     t.hit.u = 0.0f;
@@ -143,16 +150,35 @@ __device__ __forceinline__ bool travPop(Trav& t, LaneStack& stack) {
     return true;
 }
 
+__device__ __forceinline__ f3 gridLo(uint32_t w0, uint32_t w1) {
+    return mk3(static_cast<float>(w0 & 0xFFFFu), static_cast<float>(w0 >> 16), static_cast<float>(w1 & 0xFFFFu));
+}
+__device__ __forceinline__ f3 gridHi(uint32_t w1, uint32_t w2) {
+    return mk3(static_cast<float>(w1 >> 16), static_cast<float>(w2 & 0xFFFFu), static_cast<float>(w2 >> 16));
+}
+
 // Node step (t.cur is an internal node).  Returns false once the ray is finished.
 template <bool COUNT>
 __device__ __forceinline__ bool travNodeStep(const SceneView& sc, Trav& t, LaneStack& stack, TraceCounters& cnt) {
-    const float4* n = sc.nodes + static_cast<size_t>(t.cur) * 4u;
-    const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-    if (COUNT) ++cnt.nodes;
-    const uint32_t ref0 = __float_as_uint(n0.w), ref1 = __float_as_uint(n1.w);
+    uint32_t ref0, ref1;
     float e0, e1;
-    const bool h0 = (ref0 != kRefEmpty) && slabTest(mk3(n0), mk3(n1), t.org, t.inv, t.tnear, t.hit.t, e0);
-    const bool h1 = (ref1 != kRefEmpty) && slabTest(mk3(n2), mk3(n3), t.org, t.inv, t.tnear, t.hit.t, e1);
+    bool h0, h1;
+    if (sc.useQuantized) {
+        const uint4* n = sc.qnodes + static_cast<size_t>(t.cur) * 2u;
+        const uint4 q0 = n[0], q1 = n[1];
+        ref0 = q0.w;
+        ref1 = q1.w;
+        h0 = (ref0 != kRefEmpty) && slabTest(gridLo(q0.x, q0.y), gridHi(q0.y, q0.z), t.orgQ, t.inv, t.tnear, t.hit.t, e0);
+        h1 = (ref1 != kRefEmpty) && slabTest(gridLo(q1.x, q1.y), gridHi(q1.y, q1.z), t.orgQ, t.inv, t.tnear, t.hit.t, e1);
+    } else {
+        const float4* n = sc.nodes + static_cast<size_t>(t.cur) * 4u;
+        const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+        ref0 = __float_as_uint(n0.w);
+        ref1 = __float_as_uint(n1.w);
+        h0 = (ref0 != kRefEmpty) && slabTest(mk3(n0), mk3(n1), t.org, t.inv, t.tnear, t.hit.t, e0);
+        h1 = (ref1 != kRefEmpty) && slabTest(mk3(n2), mk3(n3), t.org, t.inv, t.tnear, t.hit.t, e1);
+    }
+    if (COUNT) ++cnt.nodes;
     t.leafPos = 0u;
     if (h0 && h1) {
         const bool firstIs0 = e0 <= e1;
@@ -215,73 +241,18 @@ __device__ __forceinline__ bool travVote(const SceneView& sc, Trav& t, bool acti
     return more;
 }
 
-// Closest hit (ANY = false) or first hit (ANY = true).  Returns hit.prim == kHitMiss on a miss.
+// Whole-ray loop for one lane (ray-batch queries, MNEE chains): closest hit (ANY = false) or first hit
+// (ANY = true).  Returns hit.prim == kHitMiss on a miss.  Same step functions as the persistent kernels.
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ TraceHit traverse(const SceneView& sc, f3 org, f3 dir, float tnear, float tfar,
                                              LaneStack& stack, TraceCounters& cnt) {
-    TraceHit hit;
-    hit.t = tfar;
-    hit.u = 0.0f;
-    hit.v = 0.0f;
-    hit.prim = kHitMiss;
-    const f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-    stack.sp = 0;
-    uint32_t cur = sc.rootRef;
-    if (cur == kRefEmpty) return hit;
-
-    while (true) {
-        if (!(cur & kRefLeafBit)) {
-            // ---- internal node: both child boxes arrive with one 64 B fetch ----
-            const float4* n = sc.nodes + static_cast<size_t>(cur) * 4u;
-            const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-            if (COUNT) ++cnt.nodes;
-            const uint32_t ref0 = __float_as_uint(n0.w), ref1 = __float_as_uint(n1.w);
-            float e0, e1;
-            const bool h0 = (ref0 != kRefEmpty) && slabTest(mk3(n0), mk3(n1), org, inv, tnear, hit.t, e0);
-            const bool h1 = (ref1 != kRefEmpty) && slabTest(mk3(n2), mk3(n3), org, inv, tnear, hit.t, e1);
-            if (h0 && h1) {
-                const bool firstIs0 = e0 <= e1;
-                stack.push(firstIs0 ? ref1 : ref0);   // far child waits on the stack
-                cur = firstIs0 ? ref0 : ref1;
-                continue;
-            }
-            if (h0) { cur = ref0; continue; }
-            if (h1) { cur = ref1; continue; }
-        } else {
-            // ---- leaf: primitives are stored contiguously in leaf order ----
-            const uint32_t first = cur & kRefOffsetMask;
-            const uint32_t count = ((cur >> kRefCountShift) & 0xFu) + 1u;
-            if (COUNT) { ++cnt.nodes; cnt.prims += count; }
-            if (cur & kRefSphereBit) {
-                for (uint32_t i = 0; i < count; ++i) {
-                    float t;
-                    if (sphereTest(sc.spheres[first + i], org, dir, tnear, hit.t, t)) {
-                        hit.t = t;
-                        hit.u = 0.0f;
-                        hit.v = 0.0f;
-                        hit.prim = (first + i) | kHitSphereBit;
-                        if (ANY) return hit;
-                    }
-                }
-            } else {
-                for (uint32_t i = 0; i < count; ++i) {
-                    const float4* tp = sc.tris + static_cast<size_t>(first + i) * 3u;
-                    const float4 a = tp[0], b = tp[1], c = tp[2];
-                    float t, u, v;
-                    if (triangleTest(mk3(a), mk3(b), mk3(c), org, dir, tnear, hit.t, t, u, v)) {
-                        hit.t = t;
-                        hit.u = u;
-                        hit.v = v;
-                        hit.prim = first + i;
-                        if (ANY) return hit;
-                    }
-                }
-            }
-        }
-        if (stack.sp == 0) break;
-        cur = stack.pop();
+    Trav t;
+    if (!travBegin(sc, t, org, dir, tnear, tfar, ANY, stack)) return t.hit;
+    bool more = true;
+    while (more) {
+        more = travAtLeaf(t) ? travPrimStep<COUNT>(sc, t, stack, cnt) : travNodeStep<COUNT>(sc, t, stack, cnt);
     }
-    return hit;
+    return t.hit;
 }
 
 }  // namespace ptrk

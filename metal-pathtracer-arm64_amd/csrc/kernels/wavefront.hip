@@ -113,7 +113,6 @@ struct WaveFeeder {
 };
 
 constexpr uint32_t kItemReserve = 64u;   // work items a wave reserves per atomic on the global head
-constexpr int kRefillBelow = 48;   // hand out new rays once fewer than this many lanes are still traversing
 
 // ---------------------------------------------------------------- camera
 __device__ __forceinline__ void cameraRay(const RenderParams& rp, uint32_t x, uint32_t y, uint32_t& rng, f3& org, f3& dir) {
@@ -387,7 +386,8 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams rp, PathPool pool
 // k_extend: closest hit for every live slot
 // =====================================================================================================
 template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride, uint32_t* workCounter) {
+__global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride, uint32_t* workCounter,
+                                                         int kRefillBelow) {
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
@@ -870,7 +870,7 @@ __device__ f3 mneeChain(const RenderParams& rp, const SceneView& sc, const Clamp
 
 template <bool COUNT>
 __global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride,
-                                                          uint32_t* workCounter) {
+                                                          uint32_t* workCounter, int kRefillBelow) {
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
@@ -1133,9 +1133,9 @@ void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig&
     const uint32_t stride = cfg.traceGrid * kTraceBlock;
     const uint32_t grid = std::min(cfg.traceGrid, ceilDiv(pool.slots, kTraceBlock));
     if (count) {
-        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters);
+        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters, cfg.refillBelow);
     } else {
-        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters);
+        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters, cfg.refillBelow);
     }
 }
 
@@ -1153,9 +1153,9 @@ void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& po
 void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count, hipStream_t stream) {
     const uint32_t stride = cfg.traceGrid * kTraceBlock;
     if (count) {
-        hipLaunchKernelGGL(k_connect<true>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1);
+        hipLaunchKernelGGL(k_connect<true>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1, cfg.refillBelow);
     } else {
-        hipLaunchKernelGGL(k_connect<false>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1);
+        hipLaunchKernelGGL(k_connect<false>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1, cfg.refillBelow);
     }
     if (rp.enableMnee && rp.enableMneeSecondary) {
         if (count) {
