@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "cornell_mesh.scene"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save", default="", help="write the last image as PFM (rank 0)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo); numbers are not comparable")
     args = ap.parse_args()
 
     import numpy as np
@@ -59,11 +62,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="gloo")
 
     if rank == 0:
         ensure_assets()
@@ -107,8 +115,9 @@ def main():
         trace_launches += stats.traceLaunches
     fence()
     elapsed = time.perf_counter() - t_start
+    cdev = device if args.backend == "nccl" else torch.device("cpu")   # where the small reductions live
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -116,8 +125,8 @@ def main():
     cstats = scene.render_device(settings, args.spp, local.data_ptr(), stream.cuda_stream, rank, world, count=True, want_stats=True)
     counters = torch.tensor([cstats.extendNodesVisited, cstats.extendLeafPrimTests, cstats.nodesVisited, cstats.leafPrimTests,
                              cstats.shadedHits, cstats.triangleHits, cstats.extendRays, cstats.shadowRays],
-                            dtype=torch.float64, device=device)
-    kernel_times = torch.tensor([trace_ms, float(trace_launches)], dtype=torch.float64, device=device)
+                            dtype=torch.float64, device=cdev)
+    kernel_times = torch.tensor([trace_ms, float(trace_launches)], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(counters, op=dist.ReduceOp.SUM)
         dist.all_reduce(kernel_times, op=dist.ReduceOp.MAX)

@@ -24,6 +24,12 @@ int ptr_debug_sample_bsdf(const PtrMaterial* material, const PtrSettings* settin
 int ptr_debug_camera_rays(const PtrSettings* settings, const uint32_t* xys, uint64_t n, float* out,
                           uint32_t* out_states, char* err, size_t err_cap);
 
+/* Host-side (no GPU): the environment importance tables the device sampler is fed
+ * (src/renderer/EnvImportanceSampler.mm:70-171).  Outputs sized by the caller: texel_pdf, cond_alias,
+ * cond_threshold: w*h; marg_alias, marg_threshold: h.  Returns non-zero if the map has no positive radiance. */
+int ptr_debug_env_distribution(const float* rgba, uint32_t w, uint32_t h, float* texel_pdf, uint32_t* cond_alias,
+                               float* cond_threshold, uint32_t* marg_alias, float* marg_threshold, float* total_weight);
+
 #ifdef __cplusplus
 }
 #endif

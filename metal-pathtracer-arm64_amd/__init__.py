@@ -192,7 +192,7 @@ ABI_SYMBOLS = (
     "ptr_host_read_pfm", "ptr_version",
 )
 # include/ptr_debug.h (test-only device-function probes)
-DEBUG_SYMBOLS = ("ptr_debug_eval_bsdf", "ptr_debug_sample_bsdf", "ptr_debug_camera_rays")
+DEBUG_SYMBOLS = ("ptr_debug_eval_bsdf", "ptr_debug_sample_bsdf", "ptr_debug_camera_rays", "ptr_debug_env_distribution")
 
 _lib: Optional[C.CDLL] = None
 
@@ -236,6 +236,7 @@ def load_library() -> C.CDLL:
     lib.ptr_debug_eval_bsdf.argtypes = [C.POINTER(PtrMaterial), C.POINTER(PtrSettings), fp, u64, fp, cp, sz]
     lib.ptr_debug_sample_bsdf.argtypes = [C.POINTER(PtrMaterial), C.POINTER(PtrSettings), fp, up, up, u64, fp, up, cp, sz]
     lib.ptr_debug_camera_rays.argtypes = [C.POINTER(PtrSettings), up, u64, fp, up, cp, sz]
+    lib.ptr_debug_env_distribution.argtypes = [fp, u32, u32, fp, up, fp, up, fp, fp]
     _lib = lib
     return lib
 
@@ -457,3 +458,20 @@ def debug_camera_rays(settings: PtrSettings, xys: np.ndarray):
     _check(load_library().ptr_debug_camera_rays(C.byref(settings), _uptr(xys), xys.shape[0], _fptr(out), _uptr(states),
                                                err, len(err)), err)
     return out, states
+
+
+def debug_env_distribution(rgba: np.ndarray) -> dict:
+    """Host-side environment importance tables (no GPU needed)."""
+    rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+    h, w = rgba.shape[0], rgba.shape[1]
+    pdf = np.zeros((h, w), np.float32)
+    ca = np.zeros((h, w), np.uint32)
+    ct = np.zeros((h, w), np.float32)
+    ma = np.zeros(h, np.uint32)
+    mt = np.zeros(h, np.float32)
+    total = C.c_float()
+    rc = load_library().ptr_debug_env_distribution(_fptr(rgba), w, h, _fptr(pdf), _uptr(ca), _fptr(ct), _uptr(ma), _fptr(mt),
+                                                   C.byref(total))
+    if rc != 0:
+        raise PtrError("environment map has no positive radiance")
+    return dict(pdf=pdf, cond_alias=ca, cond_threshold=ct, marg_alias=ma, marg_threshold=mt, total=total.value)

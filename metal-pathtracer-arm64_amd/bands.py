@@ -38,6 +38,8 @@ def gather_bands(local, height: int, rank: int, world: int, group=None):
         return local[:height]
     rows = max_band_count(height, world) * BAND_ROWS
     assert local.shape[0] == rows, (local.shape, rows)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()   # CPU rehearsal backend: stage through host memory
     if rank == 0:
         recv: Optional[List] = [torch.empty_like(local) for _ in range(world)]
     else:

@@ -5,9 +5,11 @@
 #include <memory>
 #include <string>
 
+#include "env_importance_sampler.h"
 #include "headless.h"
 #include "image_writer.h"
 #include "ptr_abi.h"
+#include "ptr_debug.h"
 #include "scene_manager.h"
 
 struct PtrHostScene {
@@ -122,5 +124,23 @@ int ptr_host_read_pfm(const char* path, float* out_rgb, uint32_t cap_floats, uin
 }
 
 const char* ptr_version(void) { return "ptr-hip 0.1 (gfx950)"; }
+
+int ptr_debug_env_distribution(const float* rgba, uint32_t w, uint32_t h, float* texel_pdf, uint32_t* cond_alias,
+                               float* cond_threshold, uint32_t* marg_alias, float* marg_threshold, float* total_weight) {
+    ptr::EnvImportanceDistribution d;
+    if (!ptr::BuildEnvImportanceDistribution(rgba, w, h, &d)) return 1;
+    const size_t n = static_cast<size_t>(w) * h;
+    for (size_t i = 0; i < n; ++i) {
+        texel_pdf[i] = d.texelPdf[i];
+        cond_alias[i] = d.conditional[i].alias;
+        cond_threshold[i] = d.conditional[i].threshold;
+    }
+    for (uint32_t y = 0; y < h; ++y) {
+        marg_alias[y] = d.marginal[y].alias;
+        marg_threshold[y] = d.marginal[y].threshold;
+    }
+    if (total_weight) *total_weight = d.totalWeight;
+    return 0;
+}
 
 }  // extern "C"

@@ -68,6 +68,45 @@ def blob_obj(path: str, n: int = 188, radius: float = 100.0) -> int:
     return tris
 
 
+def sky_hdr(path: str, width: int, height: int) -> None:
+    """Synthetic equirectangular environment (Radiance RGBE, flat scanlines): blue-to-white sky gradient,
+    a dim ground, and three Gaussian suns of very different peak radiance at fixed (theta, phi)."""
+    import struct
+
+    suns = [(0.9, 1.0, 5.0e4, 0.03, (1.0, 0.9, 0.7)), (1.2, 3.6, 8.0e2, 0.08, (0.7, 0.8, 1.0)), (0.5, 5.2, 60.0, 0.2, (1.0, 0.5, 0.3))]
+    rows = []
+    for y in range(height):
+        theta = math.pi * (y + 0.5) / height
+        row = bytearray()
+        for x in range(width):
+            phi = 2.0 * math.pi * (x + 0.5) / width
+            up = math.cos(theta)
+            if up > 0.0:
+                t = up
+                rgb = [0.9 * (1 - t) + 0.25 * t, 0.95 * (1 - t) + 0.45 * t, 1.0 * (1 - t) + 0.9 * t]
+            else:
+                rgb = [0.12, 0.10, 0.08]
+            d = (math.sin(theta) * math.cos(phi), math.cos(theta), math.sin(theta) * math.sin(phi))
+            for st, sp, peak, sigma, tint in suns:
+                sd = (math.sin(st) * math.cos(sp), math.cos(st), math.sin(st) * math.sin(sp))
+                cosang = max(-1.0, min(1.0, d[0] * sd[0] + d[1] * sd[1] + d[2] * sd[2]))
+                ang = math.acos(cosang)
+                g = peak * math.exp(-0.5 * (ang / sigma) ** 2)
+                rgb = [rgb[i] + g * tint[i] for i in range(3)]
+            m = max(rgb)
+            if m < 1e-32:
+                row += bytes((0, 0, 0, 0))
+            else:
+                mant, e = math.frexp(m)
+                scale = mant * 256.0 / m
+                row += bytes((int(rgb[0] * scale), int(rgb[1] * scale), int(rgb[2] * scale), e + 128))
+        rows.append(bytes(row))
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (height, width))
+        for r in rows:
+            f.write(r)
+
+
 def ensure_assets(verbose: bool = False) -> None:
     assets = os.path.join(HERE, "assets")
     os.makedirs(assets, exist_ok=True)
@@ -81,6 +120,12 @@ def ensure_assets(verbose: bool = False) -> None:
         tris = blob_obj(small, 24)
         if verbose:
             print("wrote", small, tris, "triangles")
+    for name, w, h in (("sky_96x48.hdr", 96, 48), ("sky_1024x512.hdr", 1024, 512)):
+        path = os.path.join(assets, name)
+        if not os.path.exists(path):
+            sky_hdr(path, w, h)
+            if verbose:
+                print("wrote", path)
 
 
 if __name__ == "__main__":

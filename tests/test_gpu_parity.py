@@ -228,6 +228,14 @@ def test_materials_image_parity_with_and_without_specular_nee(materials_scene):
     _image_parity(host, dev, osc, 96, 64, 12, 1, 16, 0.88, fireflyClampEnabled=0)
 
 
+def test_environment_lit_image_parity():
+    # env NEE (alias tables), MIS against the env pdf, bilinear lookups, specular NEE along delta bounces, env portal
+    host = pt.HostScene.load(os.path.join(GOLDEN, "env_materials.scene"), SCENES)
+    dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
+    _image_parity(host, dev, osc, 96, 64, 6, 1, 32, 0.88)
+    _image_parity(host, dev, osc, 64, 48, 4, 1, 16, 0.88, environmentRotation=2.1, environmentIntensity=0.5, enableSpecularNee=0)
+
+
 def test_gradient_sky_and_thin_lens(materials_scene):
     host, dev, osc = materials_scene
     _image_parity(host, dev, osc, 64, 48, 5, 1, 16, 0.90, backgroundMode=0, cameraDefocusAngle=1.5, cameraFocusDistance=8.0)

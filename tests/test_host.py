@@ -286,3 +286,31 @@ def test_cli_flag_surface():
     if pt.device_count() == 0:
         r = subprocess.run([exe, "--scene", os.path.join(GOLDEN, "smoke.scene"), "--sppTotal=1"], capture_output=True, text=True)
         assert r.returncode == 1 and "Render failed" in r.stderr
+
+
+# --------------------------------------------------------------------------- environment maps
+def test_env_tables_match_oracle_bitwise_and_hdr_loader(tmp_path):
+    import oracle_lib as ol
+
+    host = pt.HostScene.load(os.path.join(GOLDEN, "env_materials.scene"), os.path.join(ROOT, "scenes"))
+    d = host.desc
+    assert (d.envWidth, d.envHeight) == (96, 48) and host.settings.backgroundMode == 2
+    assert host.settings.environmentRotation == pytest.approx(np.radians(30.0), rel=1e-6)
+    rgba = np.ctypeslib.as_array(d.envRgba, shape=(48, 96, 4)).copy()
+    assert np.isfinite(rgba).all() and rgba[..., 3].min() == 1.0 and rgba[..., :3].max() > 1.0e4   # the brightest sun survives RGBE
+    ours = pt.debug_env_distribution(rgba)
+    rc, theirs = ol.env_build(rgba)
+    assert rc == 0
+    for key in ("pdf", "cond_alias", "cond_threshold", "marg_alias", "marg_threshold"):
+        assert np.array_equal(ours[key], theirs[key]), key
+    assert ours["total"] == theirs["total"]
+    with pytest.raises(pt.PtrError):
+        pt.debug_env_distribution(np.zeros((4, 8, 4), np.float32))
+    # PFM is accepted as an environment format too (rows stored bottom-up)
+    small = np.random.default_rng(1).random((4, 8, 3)).astype(np.float32)
+    (tmp_path / "assets").mkdir()
+    pt.write_image(str(tmp_path / "assets" / "e.pfm"), small, "pfm")
+    (tmp_path / "s.scene").write_text("background env=assets/e.pfm\n")
+    h2 = pt.HostScene.load(str(tmp_path / "s.scene"))
+    got = np.ctypeslib.as_array(h2.desc.envRgba, shape=(4, 8, 4))
+    assert np.array_equal(got[..., :3], small)
