@@ -90,7 +90,7 @@ def main():
 
     def step(want_stats):
         stats = scene.render_device(settings, args.spp, local.data_ptr(), stream.cuda_stream, rank, world,
-                                    count=False, want_stats=want_stats)
+                                    count=os.environ.get("PTR_BENCH_COUNTING", "0") == "1", want_stats=want_stats)
         image = bands.gather_bands(local, args.height, rank, world)
         return stats, image
 

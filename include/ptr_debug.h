@@ -30,6 +30,14 @@ int ptr_debug_camera_rays(const PtrSettings* settings, const uint32_t* xys, uint
 int ptr_debug_env_distribution(const float* rgba, uint32_t w, uint32_t h, float* texel_pdf, uint32_t* cond_alias,
                                float* cond_threshold, uint32_t* marg_alias, float* marg_threshold, float* total_weight);
 
+/* Host-side (no GPU): run the geometry preparation ptr_scene_upload performs (world-space bake, BVH build,
+ * leaf-order flattening; src/renderer/SceneAccel.mm:23-325 is the reference's counterpart) and walk the result.
+ * out[0..15]: nodes, leaves, triangles referenced, spheres referenced, max depth, max leaf size, unreferenced
+ * primitives, multiply referenced primitives, box containment violations, quantised-box violations, bad child
+ * references, triangle count, sphere count, SAH cost * 1000, build milliseconds (gather+build+flatten), quantised
+ * nodes usable (grid fine enough).  leaf_max = 0 uses the default.  Returns non-zero with a message on bad input. */
+int ptr_debug_scene_geometry(const PtrSceneDesc* scene, uint32_t leaf_max, uint64_t out[16], char* err, size_t err_cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -192,7 +192,8 @@ ABI_SYMBOLS = (
     "ptr_host_read_pfm", "ptr_version",
 )
 # include/ptr_debug.h (test-only device-function probes)
-DEBUG_SYMBOLS = ("ptr_debug_eval_bsdf", "ptr_debug_sample_bsdf", "ptr_debug_camera_rays", "ptr_debug_env_distribution")
+DEBUG_SYMBOLS = ("ptr_debug_eval_bsdf", "ptr_debug_sample_bsdf", "ptr_debug_camera_rays", "ptr_debug_env_distribution",
+                 "ptr_debug_scene_geometry")
 
 _lib: Optional[C.CDLL] = None
 
@@ -206,9 +207,10 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise PtrError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` first")
-    lib = C.CDLL(LIB_PATH)
+    path = os.environ.get("PTR_HIP_LIBRARY", LIB_PATH)   # override: A/B builds of the same library (tools/)
+    if not os.path.exists(path):
+        raise PtrError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` first")
+    lib = C.CDLL(path)
     vp, cp, u32, u64, sz = C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint64, C.c_size_t
     lib.ptr_device_count.restype = C.c_int
     lib.ptr_scene_upload.argtypes = [C.POINTER(PtrSceneDesc), C.c_int, C.POINTER(vp), cp, sz]
@@ -237,6 +239,7 @@ def load_library() -> C.CDLL:
     lib.ptr_debug_sample_bsdf.argtypes = [C.POINTER(PtrMaterial), C.POINTER(PtrSettings), fp, up, up, u64, fp, up, cp, sz]
     lib.ptr_debug_camera_rays.argtypes = [C.POINTER(PtrSettings), up, u64, fp, up, cp, sz]
     lib.ptr_debug_env_distribution.argtypes = [fp, u32, u32, fp, up, fp, up, fp, fp]
+    lib.ptr_debug_scene_geometry.argtypes = [C.POINTER(PtrSceneDesc), u32, C.POINTER(u64), cp, sz]
     _lib = lib
     return lib
 
@@ -475,3 +478,16 @@ def debug_env_distribution(rgba: np.ndarray) -> dict:
     if rc != 0:
         raise PtrError("environment map has no positive radiance")
     return dict(pdf=pdf, cond_alias=ca, cond_threshold=ct, marg_alias=ma, marg_threshold=mt, total=total.value)
+
+
+GEOMETRY_FIELDS = ("nodes", "leaves", "triangles_referenced", "spheres_referenced", "max_depth", "max_leaf_size",
+                   "unreferenced", "multiply_referenced", "box_violations", "quant_violations", "bad_refs", "triangles",
+                   "spheres", "sah_cost_milli", "build_ms", "quantized_usable")
+
+
+def debug_scene_geometry(desc: PtrSceneDesc, leaf_max: int = 0) -> dict:
+    """Host-side (no GPU): build the BVH / leaf-order arrays exactly as ptr_scene_upload does and validate them."""
+    out = (C.c_uint64 * 16)()
+    err = _err_buf()
+    _check(load_library().ptr_debug_scene_geometry(C.byref(desc), leaf_max, out, err, len(err)), err)
+    return dict(zip(GEOMETRY_FIELDS, [int(v) for v in out]))

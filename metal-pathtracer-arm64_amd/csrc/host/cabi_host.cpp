@@ -1,4 +1,5 @@
 // Host-side (no GPU) entry points of the C-ABI: scene loading and image output.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <filesystem>
@@ -10,6 +11,7 @@
 #include "image_writer.h"
 #include "ptr_abi.h"
 #include "ptr_debug.h"
+#include "scene_geometry.h"
 #include "scene_manager.h"
 
 struct PtrHostScene {
@@ -140,6 +142,29 @@ int ptr_debug_env_distribution(const float* rgba, uint32_t w, uint32_t h, float*
         marg_threshold[y] = d.marginal[y].threshold;
     }
     if (total_weight) *total_weight = d.totalWeight;
+    return 0;
+}
+
+int ptr_debug_scene_geometry(const PtrSceneDesc* scene, uint32_t leaf_max, uint64_t out[16], char* err, size_t err_cap) {
+    if (!scene || !out) {
+        if (err && err_cap) std::snprintf(err, err_cap, "ptr_debug_scene_geometry: null argument");
+        return 1;
+    }
+    ptr::SceneGeometry geo;
+    std::string error;
+    if (!ptr::BuildSceneGeometry(*scene, leaf_max, geo, error)) {
+        if (err && err_cap) std::snprintf(err, err_cap, "%s", error.c_str());
+        return 1;
+    }
+    ptr::GeometryCheck c;
+    ptr::ValidateSceneGeometry(geo, c);
+    const float maxCell = std::max(std::max(geo.bvh.gridCell[0], geo.bvh.gridCell[1]), geo.bvh.gridCell[2]);
+    const uint64_t vals[16] = {c.nodes, c.leaves, c.trianglesReferenced, c.spheresReferenced, c.maxDepth, c.maxLeafSize,
+                               c.unreferenced, c.multiplyReferenced, c.boxViolations, c.quantViolations, c.badRefs,
+                               geo.triCount, geo.sphereCount, static_cast<uint64_t>(geo.bvh.sahCost * 1000.0),
+                               static_cast<uint64_t>((geo.gatherSeconds + geo.buildSeconds + geo.flattenSeconds) * 1000.0),
+                               (geo.bvh.nodeCount > 0 && maxCell * 8.0f <= geo.bvh.meanPrimExtent) ? 1u : 0u};
+    std::memcpy(out, vals, sizeof(vals));
     return 0;
 }
 

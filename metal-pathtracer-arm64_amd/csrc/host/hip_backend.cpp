@@ -23,6 +23,7 @@
 #include "env_importance_sampler.h"
 #include "ptr_abi.h"
 #include "ptr_debug.h"
+#include "scene_geometry.h"
 #include "vecmath.h"
 
 using namespace ptrk;
@@ -72,63 +73,6 @@ struct DeviceBuffer {
 };
 
 using ptr::float3;
-
-struct M4 {
-    float m[4][4];  // m[col][row]
-};
-
-M4 loadM4(const float* p) {
-    M4 r;
-    std::memcpy(r.m, p, sizeof(r.m));
-    return r;
-}
-
-// Cofactor inverse in float (the Embree backend calls simd_inverse for the normal matrix).
-M4 inverse(const M4& a) {
-    const float* s = &a.m[0][0];
-    float c[16];
-    auto d3 = [&](int r0, int r1, int r2, int c0, int c1, int c2) {
-        auto e = [&](int r, int col) { return s[col * 4 + r]; };
-        return e(r0, c0) * (e(r1, c1) * e(r2, c2) - e(r1, c2) * e(r2, c1)) - e(r0, c1) * (e(r1, c0) * e(r2, c2) - e(r1, c2) * e(r2, c0)) +
-               e(r0, c2) * (e(r1, c0) * e(r2, c1) - e(r1, c1) * e(r2, c0));
-    };
-    const int idx[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};
-    for (int row = 0; row < 4; ++row) {
-        for (int col = 0; col < 4; ++col) {
-            const float minor = d3(idx[row][0], idx[row][1], idx[row][2], idx[col][0], idx[col][1], idx[col][2]);
-            c[row * 4 + col] = ((row + col) & 1) ? -minor : minor;   // cofactor of element (row, col)
-        }
-    }
-    float det = 0.0f;
-    for (int col = 0; col < 4; ++col) det += s[col * 4 + 0] * c[0 * 4 + col];
-    M4 r;
-    const float invDet = 1.0f / det;
-    // inverse(row, col) = cofactor(col, row) / det; stored column-major
-    for (int col = 0; col < 4; ++col) {
-        for (int row = 0; row < 4; ++row) r.m[col][row] = c[col * 4 + row] * invDet;
-    }
-    return r;
-}
-
-float3 transformPoint(const M4& t, const float* p) {
-    return {((t.m[0][0] * p[0] + t.m[1][0] * p[1]) + t.m[2][0] * p[2]) + t.m[3][0],
-            ((t.m[0][1] * p[0] + t.m[1][1] * p[1]) + t.m[2][1] * p[2]) + t.m[3][1],
-            ((t.m[0][2] * p[0] + t.m[1][2] * p[1]) + t.m[2][2] * p[2]) + t.m[3][2]};
-}
-
-struct HostTri {
-    float3 v0, e1, e2;
-    float3 n0, n1, n2;
-    uint32_t material, meta, primIndex;
-};
-
-void padBounds(ptr::BuildPrim& p) {
-    for (int a = 0; a < 3; ++a) {
-        const float pad = 1e-5f * std::max(std::max(std::fabs(p.lo[a]), std::fabs(p.hi[a])), 1.0f);
-        p.lo[a] -= pad;
-        p.hi[a] += pad;
-    }
-}
 
 void put4(std::vector<float>& dst, const float3& v, float w) {
     dst.push_back(v.x);
@@ -201,109 +145,11 @@ void compactMaterial(const PtrMaterial& m, std::vector<float>& out) {
 
 void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<HostTri> tris;
-    std::vector<ptr::BuildPrim> prims;
-
-    auto addTri = [&](const float3& v0, const float3& v1, const float3& v2, const float3& n0, const float3& n1, const float3& n2,
-                      uint32_t material, uint32_t kind, uint32_t geomIndex, uint32_t primIndex) {
-        HostTri t;
-        t.v0 = v0;
-        t.e1 = v0 - v1;
-        t.e2 = v2 - v0;
-        t.n0 = n0;
-        t.n1 = n1;
-        t.n2 = n2;
-        t.material = material;
-        t.meta = (kind << 30) | (geomIndex & 0x3FFFFFFFu);
-        t.primIndex = primIndex;
-        tris.push_back(t);
-        ptr::BuildPrim p;
-        const float3* vs[3] = {&v0, &v1, &v2};
-        for (int a = 0; a < 3; ++a) {
-            p.lo[a] = std::min(std::min((&vs[0]->x)[a], (&vs[1]->x)[a]), (&vs[2]->x)[a]);
-            p.hi[a] = std::max(std::max((&vs[0]->x)[a], (&vs[1]->x)[a]), (&vs[2]->x)[a]);
-        }
-        p.isSphere = 0;
-        padBounds(p);
-        prims.push_back(p);
-    };
-
-    // meshes: baked to world space, normals through the inverse-transpose (EmbreeHeadlessRenderer.mm:2100-2166)
-    for (uint32_t mi = 0; mi < desc.meshCount; ++mi) {
-        const PtrMeshDesc& mesh = desc.meshes[mi];
-        if (mesh.vertexCount == 0 || mesh.indexCount == 0) continue;
-        const M4 l2w = loadM4(mesh.localToWorld);
-        const M4 w2l = inverse(l2w);
-        const float3 nc0{w2l.m[0][0], w2l.m[1][0], w2l.m[2][0]};
-        const float3 nc1{w2l.m[0][1], w2l.m[1][1], w2l.m[2][1]};
-        const float3 nc2{w2l.m[0][2], w2l.m[1][2], w2l.m[2][2]};
-        std::vector<float3> pos(mesh.vertexCount), nrm(mesh.vertexCount);
-        for (uint32_t v = 0; v < mesh.vertexCount; ++v) {
-            pos[v] = transformPoint(l2w, mesh.positions + 3 * v);
-            const float* n = mesh.normals + 3 * v;
-            const float3 wn = (nc0 * n[0] + nc1 * n[1]) + nc2 * n[2];
-            nrm[v] = ptr::length(wn) > 0.0f ? ptr::normalize(wn) : wn;
-        }
-        for (uint32_t t = 0; t + 2 < mesh.indexCount; t += 3) {
-            const uint32_t i0 = mesh.indices[t], i1 = mesh.indices[t + 1], i2 = mesh.indices[t + 2];
-            if (i0 >= mesh.vertexCount || i1 >= mesh.vertexCount || i2 >= mesh.vertexCount) {
-                throw HipError{"mesh index out of range"};
-            }
-            addTri(pos[i0], pos[i1], pos[i2], nrm[i0], nrm[i1], nrm[i2], mesh.materialIndex, 0u, mi, t / 3);
-        }
-    }
-    // rectangles: two triangles each, winding chosen to agree with the stored normal (:2211-2257)
-    for (uint32_t ri = 0; ri < desc.rectCount; ++ri) {
-        const PtrRect& r = desc.rects[ri];
-        const float3 c{r.corner[0], r.corner[1], r.corner[2]}, eu{r.edgeU[0], r.edgeU[1], r.edgeU[2]},
-            ev{r.edgeV[0], r.edgeV[1], r.edgeV[2]};
-        const float3 n = ptr::normalize(float3{r.normalAndPlane[0], r.normalAndPlane[1], r.normalAndPlane[2]});
-        const float3 p[4] = {c, c + eu, c + ev, (c + eu) + ev};
-        const bool flip = ptr::dot(ptr::normalize(ptr::cross(eu, ev)), n) < 0.0f;
-        const int order[2][6] = {{0, 1, 2, 2, 1, 3}, {0, 2, 1, 1, 2, 3}};
-        const int* o = order[flip ? 1 : 0];
-        addTri(p[o[0]], p[o[1]], p[o[2]], n, n, n, r.materialTwoSided[0], 2u, ri, ri * 2u);
-        addTri(p[o[3]], p[o[4]], p[o[5]], n, n, n, r.materialTwoSided[0], 2u, ri, ri * 2u + 1u);
-    }
-    const uint32_t triCount = static_cast<uint32_t>(tris.size());
-    for (uint32_t si = 0; si < desc.sphereCount; ++si) {
-        const PtrSphere& s = desc.spheres[si];
-        ptr::BuildPrim p;
-        const float rad = std::fabs(s.centerRadius[3]);
-        for (int a = 0; a < 3; ++a) {
-            p.lo[a] = s.centerRadius[a] - rad;
-            p.hi[a] = s.centerRadius[a] + rad;
-        }
-        p.isSphere = 1;
-        padBounds(p);
-        prims.push_back(p);
-    }
-    if (prims.size() > kRefOffsetMask) throw HipError{"scene exceeds 64M primitives"};
-
-    ptr::FlatBvh bvh;
-    uint32_t leafMax = 4;
-    if (const char* e = std::getenv("PTR_LEAF_MAX")) leafMax = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 8));
-    ptr::BuildFlatBvh(prims, bvh, 0, leafMax);
-
-    // leaf-order SoA arrays
-    std::vector<float> triData, triNrm, sphData;
-    std::vector<uint2> sphInfo;
-    triData.reserve(static_cast<size_t>(triCount) * 12);
-    triNrm.reserve(static_cast<size_t>(triCount) * 12);
-    for (uint32_t idx : bvh.triOrder) {
-        const HostTri& t = tris[idx];
-        put4(triData, t.v0, bitsToFloat(t.material));
-        put4(triData, t.e1, bitsToFloat(t.meta));
-        put4(triData, t.e2, bitsToFloat(t.primIndex));
-        put4(triNrm, t.n0, 0.0f);
-        put4(triNrm, t.n1, 0.0f);
-        put4(triNrm, t.n2, 0.0f);
-    }
-    for (uint32_t idx : bvh.sphereOrder) {
-        const PtrSphere& s = desc.spheres[idx];
-        sphData.insert(sphData.end(), s.centerRadius, s.centerRadius + 4);
-        sphInfo.push_back(make_uint2(idx, s.materialIndex[0]));
-    }
+    ptr::SceneGeometry geo;
+    std::string geoError;
+    if (!ptr::BuildSceneGeometry(desc, 0, geo, geoError)) throw HipError{geoError};
+    const ptr::FlatBvh& bvh = geo.bvh;
+    const uint32_t triCount = geo.triCount;
 
     // compact materials
     std::vector<float> mats;
@@ -336,10 +182,10 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     HIP_CHECK(hipSetDevice(ds.device));
     ds.nodes.upload(reinterpret_cast<const float4*>(bvh.nodes.data()), bvh.nodes.size() / 4);
     ds.qnodes.upload(reinterpret_cast<const uint4*>(bvh.qnodes.data()), bvh.qnodes.size() / 4);
-    ds.tris.upload(reinterpret_cast<const float4*>(triData.data()), triData.size() / 4);
-    ds.triNormals.upload(reinterpret_cast<const float4*>(triNrm.data()), triNrm.size() / 4);
-    ds.spheres.upload(reinterpret_cast<const float4*>(sphData.data()), sphData.size() / 4);
-    ds.sphereInfo.upload(sphInfo.data(), sphInfo.size());
+    ds.tris.upload(reinterpret_cast<const float4*>(geo.triData.data()), geo.triData.size() / 4);
+    ds.triNormals.upload(reinterpret_cast<const float4*>(geo.triNormals.data()), geo.triNormals.size() / 4);
+    ds.spheres.upload(reinterpret_cast<const float4*>(geo.sphereData.data()), geo.sphereData.size() / 4);
+    ds.sphereInfo.upload(reinterpret_cast<const uint2*>(geo.sphereInfo.data()), geo.sphereInfo.size() / 2);
     ds.materials.upload(reinterpret_cast<const float4*>(mats.data()), mats.size() / 4);
     ds.rects.upload(reinterpret_cast<const float4*>(desc.rects), static_cast<size_t>(desc.rectCount) * 5);
     ds.rectLights.upload(reinterpret_cast<const float4*>(lights.data()), lights.size() / 4);
@@ -364,6 +210,11 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     const float maxCell = std::max(std::max(bvh.gridCell[0], bvh.gridCell[1]), bvh.gridCell[2]);
     v.useQuantized = (bvh.nodeCount > 0 && maxCell * 8.0f <= bvh.meanPrimExtent) ? 1u : 0u;
     if (const char* e = std::getenv("PTR_QUANTIZED_NODES")) v.useQuantized = std::atoi(e) != 0 ? 1u : 0u;
+    const size_t nodeBytes = v.useQuantized ? bvh.qnodes.size() * 4u : bvh.nodes.size() * 4u;
+    const size_t triBytes = geo.triData.size() * 4u;
+    if (nodeBytes > 0xFFFFFFFFull || triBytes > 0xFFFFFFFFull) throw HipError{"scene exceeds the 4 GiB node/triangle array limit"};
+    v.nodeBytes = static_cast<uint32_t>(nodeBytes);
+    v.triBytes = static_cast<uint32_t>(triBytes);
     v.rootRef = bvh.rootRef;
     v.materialCount = desc.materialCount;
     v.rectCount = desc.rectCount;

@@ -45,6 +45,8 @@ struct SceneView {
     uint32_t envWidth;
     uint32_t envHeight;
     uint32_t envSampling;          // distribution present
+    uint32_t nodeBytes;            // size of the node array in use (qnodes or nodes): buffer-descriptor range
+    uint32_t triBytes;             // size of the triangle array
     uint32_t pad;
 };
 

@@ -23,8 +23,12 @@ struct TraceCounters {
     uint32_t prims;   // primitive tests
 };
 
+// LDS words are addressed through an address-space-3 pointer so the stack always compiles to ds_read/ds_write
+// (a generic pointer made the compiler merge the LDS and spill paths into one flat_load behind a branch).
+typedef __attribute__((address_space(3))) uint32_t LdsWord;
+
 struct LaneStack {
-    uint32_t* lds;        // &ldsStack[threadIdx.x]; stride kTraceBlock
+    LdsWord* lds;         // &ldsStack[threadIdx.x]; stride kTraceBlock
     uint32_t* spill;      // &spill[globalThread]; stride spillStride
     uint32_t spillStride;
     uint32_t sp;
@@ -45,18 +49,48 @@ struct LaneStack {
     }
 };
 
+// Buffer descriptors of the two arrays every traversal step reads.  raw_buffer_load_b128 always issues one
+// 16 B load per call (plain loads of the 32 B / 48 B records were split into 3-5 narrower ones and the
+// reference words sunk behind the box tests as dependent loads), takes a 32-bit byte offset instead of 64-bit
+// address arithmetic, and returns zeros instead of faulting if an index were ever out of range.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct SceneMem {
+    __amdgpu_buffer_rsrc_t nodes;   // quantised or float nodes, whichever the scene uses
+    __amdgpu_buffer_rsrc_t tris;
+};
+
+__device__ __forceinline__ SceneMem sceneMem(const SceneView& sc) {
+    SceneMem m;
+    const void* nodes = sc.useQuantized ? static_cast<const void*>(sc.qnodes) : static_cast<const void*>(sc.nodes);
+    m.nodes = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nodes), 0, sc.nodeBytes, 0x00020000);
+    m.tris = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(sc.tris), 0, sc.triBytes, 0x00020000);
+    return m;
+}
+
+__device__ __forceinline__ uint4 load16u(__amdgpu_buffer_rsrc_t r, uint32_t byteOffset) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byteOffset, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 load16f(__amdgpu_buffer_rsrc_t r, uint32_t byteOffset) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byteOffset, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 struct TraceHit {
     float t, u, v;
     uint32_t prim;   // kHitMiss, or leaf-order index (| kHitSphereBit for spheres)
 };
 
-// Slab test of one child box.  fminf/fmaxf drop NaNs from 0*inf, boxes are padded at build time, and the
-// final comparison carries 4 ulp of slack, so a box is never culled when a primitive inside it passes
-// the exact test.
-__device__ __forceinline__ bool slabTest(f3 lo, f3 hi, f3 org, f3 inv, float tnear, float tfar, float& entry) {
-    const float ax = (lo.x - org.x) * inv.x, bx = (hi.x - org.x) * inv.x;
-    const float ay = (lo.y - org.y) * inv.y, by = (hi.y - org.y) * inv.y;
-    const float az = (lo.z - org.z) * inv.z, bz = (hi.z - org.z) * inv.z;
+// Slab test of one child box in the form t = plane*inv - org*inv (one fma per plane; `oi` = org*inv is
+// computed once per ray).  fminf/fmaxf drop the NaNs of axis-parallel rays (inf - inf), which only makes the
+// test more permissive; boxes are padded at build time (float nodes: 1e-5 relative, quantised nodes: one whole
+// cell) and the final comparison carries 4 ulp of slack, so a box is never culled when a primitive inside it
+// passes the exact test.  Box tests only prune: their rounding never reaches the reported hit.
+__device__ __forceinline__ bool slabTest(f3 lo, f3 hi, f3 oi, f3 inv, float tnear, float tfar, float& entry) {
+    const float ax = __builtin_fmaf(lo.x, inv.x, -oi.x), bx = __builtin_fmaf(hi.x, inv.x, -oi.x);
+    const float ay = __builtin_fmaf(lo.y, inv.y, -oi.y), by = __builtin_fmaf(hi.y, inv.y, -oi.y);
+    const float az = __builtin_fmaf(lo.z, inv.z, -oi.z), bz = __builtin_fmaf(hi.z, inv.z, -oi.z);
     const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tnear));
     const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tfar));
     entry = t0;
@@ -109,7 +143,7 @@ __device__ __forceinline__ bool sphereTest(float4 s, f3 org, f3 dir, float tnear
 // majority.  With the plain per-ray loop VALU lane utilisation was ~11 %; lane refill alone gave ~30 %.
 struct Trav {
     f3 org, dir, inv;    // inv = 1/dir, or cell/dir when the scene uses quantised nodes
-    f3 orgQ;             // (org - gridOrigin) / cell  (quantised nodes only)
+    f3 oi;               // org*inv in the space of the node boxes (world, or grid cells for quantised nodes)
     float tnear;
     TraceHit hit;
     uint32_t cur;        // internal node index, or leaf reference while primitives remain
@@ -121,12 +155,21 @@ __device__ __forceinline__ bool travBegin(const SceneView& sc, Trav& t, f3 org, 
                                           LaneStack& stack) {
     t.org = org;
     t.dir = dir;
-    t.inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-    t.orgQ = mk3(0.0f);
+    // 1/dir clamped to a finite range: with the fma slab form an infinite reciprocal (a direction component of
+    // exactly 0, e.g. a cosine sample with u1 = 0 -> the normal itself; ~1 ray in 2^24) turns both planes of that
+    // axis into inf - inf = NaN, the axis stops culling, and that one ray walks most of the tree while its
+    // persistent wave holds the whole launch (measured: k_extend 10x slower).  A clamped reciprocal treats the
+    // component as +-1e-28: still "parallel" for any scene, and all box arithmetic stays finite.
+    constexpr float kInvMax = 1.0e28f;
+    t.inv = mk3(fminf(fmaxf(1.0f / dir.x, -kInvMax), kInvMax), fminf(fmaxf(1.0f / dir.y, -kInvMax), kInvMax),
+                fminf(fmaxf(1.0f / dir.z, -kInvMax), kInvMax));
     if (sc.useQuantized) {
         const f3 cell = mk3(sc.gridCell[0], sc.gridCell[1], sc.gridCell[2]);
-        t.orgQ = (org - mk3(sc.gridOrigin[0], sc.gridOrigin[1], sc.gridOrigin[2])) / cell;
+        const f3 orgQ = (org - mk3(sc.gridOrigin[0], sc.gridOrigin[1], sc.gridOrigin[2])) / cell;
         t.inv = t.inv * cell;
+        t.oi = orgQ * t.inv;
+    } else {
+        t.oi = org * t.inv;
     }
     t.tnear = tnear;
     t.hit.t = tfar;
@@ -159,41 +202,45 @@ __device__ __forceinline__ f3 gridHi(uint32_t w1, uint32_t w2) {
 
 // Node step (t.cur is an internal node).  Returns false once the ray is finished.
 template <bool COUNT>
-__device__ __forceinline__ bool travNodeStep(const SceneView& sc, Trav& t, LaneStack& stack, TraceCounters& cnt) {
+__device__ __forceinline__ bool travNodeStep(const SceneView& sc, const SceneMem& mem, Trav& t, LaneStack& stack, TraceCounters& cnt) {
     uint32_t ref0, ref1;
     float e0, e1;
     bool h0, h1;
+    // both halves of the node are fetched up front and both boxes tested without branching: a short-circuit
+    // on the child reference made the compiler issue the second half as a dependent load
     if (sc.useQuantized) {
-        const uint4* n = sc.qnodes + static_cast<size_t>(t.cur) * 2u;
-        const uint4 q0 = n[0], q1 = n[1];
+        const uint4 q0 = load16u(mem.nodes, t.cur * 32u), q1 = load16u(mem.nodes, t.cur * 32u + 16u);
         ref0 = q0.w;
         ref1 = q1.w;
-        h0 = (ref0 != kRefEmpty) && slabTest(gridLo(q0.x, q0.y), gridHi(q0.y, q0.z), t.orgQ, t.inv, t.tnear, t.hit.t, e0);
-        h1 = (ref1 != kRefEmpty) && slabTest(gridLo(q1.x, q1.y), gridHi(q1.y, q1.z), t.orgQ, t.inv, t.tnear, t.hit.t, e1);
+        h0 = slabTest(gridLo(q0.x, q0.y), gridHi(q0.y, q0.z), t.oi, t.inv, t.tnear, t.hit.t, e0);
+        h1 = slabTest(gridLo(q1.x, q1.y), gridHi(q1.y, q1.z), t.oi, t.inv, t.tnear, t.hit.t, e1);
     } else {
-        const float4* n = sc.nodes + static_cast<size_t>(t.cur) * 4u;
-        const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+        const uint32_t at = t.cur * 64u;
+        const float4 n0 = load16f(mem.nodes, at), n1 = load16f(mem.nodes, at + 16u), n2 = load16f(mem.nodes, at + 32u),
+                     n3 = load16f(mem.nodes, at + 48u);
         ref0 = __float_as_uint(n0.w);
         ref1 = __float_as_uint(n1.w);
-        h0 = (ref0 != kRefEmpty) && slabTest(mk3(n0), mk3(n1), t.org, t.inv, t.tnear, t.hit.t, e0);
-        h1 = (ref1 != kRefEmpty) && slabTest(mk3(n2), mk3(n3), t.org, t.inv, t.tnear, t.hit.t, e1);
+        h0 = slabTest(mk3(n0), mk3(n1), t.oi, t.inv, t.tnear, t.hit.t, e0);
+        h1 = slabTest(mk3(n2), mk3(n3), t.oi, t.inv, t.tnear, t.hit.t, e1);
     }
+    h0 = h0 & (ref0 != kRefEmpty);
+    h1 = h1 & (ref1 != kRefEmpty);
     if (COUNT) ++cnt.nodes;
     t.leafPos = 0u;
-    if (h0 && h1) {
-        const bool firstIs0 = e0 <= e1;
-        stack.push(firstIs0 ? ref1 : ref0);
-        t.cur = firstIs0 ? ref0 : ref1;
+    const bool firstIs0 = e0 <= e1;
+    const uint32_t nearRef = (h0 & (firstIs0 | !h1)) ? ref0 : ref1;
+    const uint32_t farRef = firstIs0 ? ref1 : ref0;
+    if (h0 & h1) stack.push(farRef);
+    if (h0 | h1) {
+        t.cur = nearRef;
         return true;
     }
-    if (h0) { t.cur = ref0; return true; }
-    if (h1) { t.cur = ref1; return true; }
     return travPop(t, stack);
 }
 
 // Primitive step (t.cur is a leaf): tests primitive number t.leafPos of the leaf.  Returns false once finished.
 template <bool COUNT>
-__device__ __forceinline__ bool travPrimStep(const SceneView& sc, Trav& t, LaneStack& stack, TraceCounters& cnt) {
+__device__ __forceinline__ bool travPrimStep(const SceneView& sc, const SceneMem& mem, Trav& t, LaneStack& stack, TraceCounters& cnt) {
     const uint32_t cur = t.cur;
     const uint32_t first = cur & kRefOffsetMask;
     const uint32_t count = ((cur >> kRefCountShift) & 0xFu) + 1u;
@@ -209,8 +256,8 @@ __device__ __forceinline__ bool travPrimStep(const SceneView& sc, Trav& t, LaneS
             if (t.anyHit) return false;
         }
     } else {
-        const float4* tp = sc.tris + static_cast<size_t>(index) * 3u;
-        const float4 a = tp[0], b = tp[1], c = tp[2];
+        const uint32_t at = index * 48u;
+        const float4 a = load16f(mem.tris, at), b = load16f(mem.tris, at + 16u), c = load16f(mem.tris, at + 32u);
         float tt, u, v;
         if (triangleTest(mk3(a), mk3(b), mk3(c), t.org, t.dir, t.tnear, t.hit.t, tt, u, v)) {
             t.hit.t = tt;
@@ -227,16 +274,17 @@ __device__ __forceinline__ bool travPrimStep(const SceneView& sc, Trav& t, LaneS
 // One wave iteration for all traversing lanes: majority vote between node steps and primitive steps.
 // Returns (per lane) false when that lane's ray has just finished.  Lanes not voted for return true unchanged.
 template <bool COUNT>
-__device__ __forceinline__ bool travVote(const SceneView& sc, Trav& t, bool active, LaneStack& stack, TraceCounters& cnt) {
+__device__ __forceinline__ bool travVote(const SceneView& sc, const SceneMem& mem, Trav& t, bool active, LaneStack& stack,
+                                         TraceCounters& cnt) {
     const bool wantsPrim = active && travAtLeaf(t);
     const bool wantsNode = active && !travAtLeaf(t);
     const int nPrim = __popcll(__ballot(wantsPrim));
     const int nNode = __popcll(__ballot(wantsNode));
     bool more = true;
     if (nNode >= nPrim) {
-        if (wantsNode) more = travNodeStep<COUNT>(sc, t, stack, cnt);
+        if (wantsNode) more = travNodeStep<COUNT>(sc, mem, t, stack, cnt);
     } else {
-        if (wantsPrim) more = travPrimStep<COUNT>(sc, t, stack, cnt);
+        if (wantsPrim) more = travPrimStep<COUNT>(sc, mem, t, stack, cnt);
     }
     return more;
 }
@@ -246,11 +294,12 @@ __device__ __forceinline__ bool travVote(const SceneView& sc, Trav& t, bool acti
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ TraceHit traverse(const SceneView& sc, f3 org, f3 dir, float tnear, float tfar,
                                              LaneStack& stack, TraceCounters& cnt) {
+    const SceneMem mem = sceneMem(sc);
     Trav t;
     if (!travBegin(sc, t, org, dir, tnear, tfar, ANY, stack)) return t.hit;
     bool more = true;
     while (more) {
-        more = travAtLeaf(t) ? travPrimStep<COUNT>(sc, t, stack, cnt) : travNodeStep<COUNT>(sc, t, stack, cnt);
+        more = travAtLeaf(t) ? travPrimStep<COUNT>(sc, mem, t, stack, cnt) : travNodeStep<COUNT>(sc, mem, t, stack, cnt);
     }
     return t.hit;
 }

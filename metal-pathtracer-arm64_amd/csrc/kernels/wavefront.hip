@@ -391,13 +391,14 @@ __global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool p
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
-    stack.lds = ldsStack + threadIdx.x;
+    stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
     stack.spill = spill + gtid;
     stack.spillStride = spillStride;
     stack.sp = 0u;
     TraceCounters cnt{0u, 0u};
     uint32_t rays = 0u;
 
+    const SceneMem mem = sceneMem(sc);
     WaveFeeder feeder;
     feeder.init(workCounter, pool.slots);
     Trav t;
@@ -417,7 +418,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool p
             continue;
         }
         if (nActive == 0) break;
-        if (!travVote<COUNT>(sc, t, active, stack, cnt)) {
+        if (!travVote<COUNT>(sc, mem, t, active, stack, cnt)) {
             active = false;
             pool.hit[mySlot] = make_float4(t.hit.t, t.hit.u, t.hit.v, __uint_as_float(t.hit.prim));
         }
@@ -874,7 +875,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams rp, SceneV
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
-    stack.lds = ldsStack + threadIdx.x;
+    stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
     stack.spill = spill + gtid;
     stack.spillStride = spillStride;
     stack.sp = 0u;
@@ -884,6 +885,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams rp, SceneV
 
     // The work list is the slot pool itself: a lane takes a slot, reads its pending mask and resolves that
     // slot's records one after another (no compaction queue -> no hot atomic counter in k_shade).
+    const SceneMem mem = sceneMem(sc);
     WaveFeeder feeder;
     feeder.init(workCounter, pool.slots);
     Trav t;
@@ -921,7 +923,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams rp, SceneV
         {
             // counting build: nodes/prims of closest-hit (kind 1) rays are booked with the extend counters
             TraceCounters step{0u, 0u};
-            const bool more = travVote<COUNT>(sc, t, active, stack, step);
+            const bool more = travVote<COUNT>(sc, mem, t, active, stack, step);
             if (COUNT) {
                 TraceCounters& dst = t.anyHit ? cnt : cntClosest;
                 dst.nodes += step.nodes;
@@ -958,7 +960,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect_chain(RenderParams rp, 
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
-    stack.lds = ldsStack + threadIdx.x;
+    stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
     stack.spill = spill + gtid;
     stack.spillStride = spillStride;
     stack.sp = 0u;
@@ -1027,7 +1029,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace_rays(SceneView sc, const 
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
-    stack.lds = ldsStack + threadIdx.x;
+    stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
     stack.spill = spill + gtid;
     stack.spillStride = spillStride;
     TraceCounters cnt{0u, 0u};

@@ -226,6 +226,58 @@ def test_obj_and_ply_loaders(tmp_path):
     assert plane.indexCount == 6 and plane.localToWorld[0] == 2.0 and plane.localToWorld[10] == 4.0
 
 
+# --------------------------------------------------------------------------- BVH / leaf-order geometry (host side of ptr_scene_upload)
+def _geometry_ok(g, tris, spheres):
+    assert g["triangles"] == tris and g["spheres"] == spheres
+    assert g["triangles_referenced"] == tris and g["spheres_referenced"] == spheres
+    assert g["unreferenced"] == 0 and g["multiply_referenced"] == 0 and g["bad_refs"] == 0
+    assert g["box_violations"] == 0 and g["quant_violations"] == 0
+    assert g["max_depth"] < 48          # kTraversalStackDepth: the traversal stack can never overflow
+
+
+@pytest.mark.parametrize("leaf_max", [1, 2, 4, 8])
+def test_bvh_invariants_config2_mesh(leaf_max):
+    host = pt.HostScene.load(os.path.join(ROOT, "scenes", "cornell_mesh.scene"), os.path.join(ROOT, "scenes"))
+    g = pt.debug_scene_geometry(host.desc, leaf_max)
+    _geometry_ok(g, 70688 + 2 * 6, 0)
+    assert g["max_leaf_size"] <= leaf_max
+    assert g["nodes"] >= (70700 // leaf_max) - 1 and g["quantized_usable"] == 1
+    # SAH cost of the flattened tree (c_trav = c_int = 1): a regression guard, loose enough for builder tweaks
+    assert g["sah_cost_milli"] < 60_000 * (1 if leaf_max >= 2 else 2)
+
+
+def test_bvh_invariants_mixed_and_degenerate_scenes(tmp_path):
+    for name, tris, spheres in (("materials.scene", None, None), ("env_materials.scene", None, None)):
+        host = pt.HostScene.load(os.path.join(ROOT, "tests", "golden", name), os.path.join(ROOT, "scenes"))
+        d = host.desc
+        want_tris = 2 * d.rectCount + sum(d.meshes[i].indexCount // 3 for i in range(d.meshCount))
+        _geometry_ok(pt.debug_scene_geometry(d), want_tris, d.sphereCount)
+    # one primitive, an empty scene, coincident spheres (zero-extent centroids: the split must still terminate)
+    one = pt.HostScene.load(_write(tmp_path, "material type=lambert\nsphere center=0,0,0 radius=1 material=0\n"))
+    g = pt.debug_scene_geometry(one.desc)
+    _geometry_ok(g, 0, 1)
+    assert g["nodes"] == 1 and g["leaves"] == 1
+    empty = pt.HostScene.load(_write(tmp_path, "material type=lambert\n"))
+    g = pt.debug_scene_geometry(empty.desc)
+    assert g["nodes"] == 0 and g["triangles"] == 0 and g["spheres"] == 0
+    same = "material type=lambert\n" + "sphere center=1,2,3 radius=0.5 material=0\n" * 300
+    host = pt.HostScene.load(_write(tmp_path, same))     # keep the host scene alive: desc points into it
+    g = pt.debug_scene_geometry(host.desc)
+    _geometry_ok(g, 0, 300)
+    assert g["max_leaf_size"] <= 4
+
+
+def test_bvh_rejects_bad_mesh_indices(tmp_path):
+    host = pt.HostScene.load(_write(tmp_path, "material type=lambert\nmesh type=plane material=0\n"))
+    d = host.desc
+    idx = np.ctypeslib.as_array(d.meshes[0].indices, shape=(d.meshes[0].indexCount,))
+    keep = idx[0]
+    idx[0] = 1000
+    with pytest.raises(pt.PtrError, match="index out of range"):
+        pt.debug_scene_geometry(d)
+    idx[0] = keep
+
+
 # --------------------------------------------------------------------------- image output
 def test_pfm_roundtrip_and_layout(tmp_path):
     rng = np.random.default_rng(0)
