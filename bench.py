@@ -21,6 +21,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6.29 TB/s measured streaming copy
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+
+
+def measured_stream_gbs(torch, device):
+    """Achievable HBM bandwidth on this box: float4-wide device copy of 1 GiB (read + write bytes / time)."""
+    n = 1 << 28
+    src = torch.empty(n, dtype=torch.float32, device=device)
+    dst = torch.empty_like(src)
+    src.fill_(1.0)
+    for _ in range(2):
+        dst.copy_(src)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        dst.copy_(src)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    del src, dst
+    return 2.0 * 4.0 * n * reps / dt / 1e9
+
+
+def recorded_traffic(spp):
+    """HBM bytes per k_extend launch from the committed PMC passes (same command line, see profiles/README.md).
+    Returned only when the passes were taken at this spp; otherwise None (bench.py cannot run rocprofv3 on itself)."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            rec = json.load(f)
+        if int(rec.get("spp", -1)) != int(spp):
+            return None
+        return rec
+    except (OSError, ValueError):
+        return None
 
 
 def algorithmic_bytes(nodes, prims, shaded=0, tri_hits=0, samples=0):
@@ -146,6 +179,8 @@ def main():
         path_bytes = algorithmic_bytes(all_nodes, all_prims, shaded, tri_hits, total_samples)
         path_gbs = path_bytes * args.steps / elapsed / 1e9 / world
 
+        traffic = recorded_traffic(args.spp) if world == 1 else None
+        stream_gbs = measured_stream_gbs(torch, device)
         out = {
             "metric": "Msamples/sec (whole node) at 1920x1080, depth 8",
             "value": round(value, 3),
@@ -172,7 +207,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic["k_extend_hbm_bytes_per_launch"] if traffic else None,
+                "traffic_note": (traffic["note"] if traffic else "no PMC passes recorded for this spp"),
+                "peak_measured": round(stream_gbs, 1),
+                "frac_of_measured": round(achieved / stream_gbs, 4) if stream_gbs > 0 else None,
                 "avg_launch_ms": round(avg_launch_ms, 4),
                 "launches_per_render": round(launches_per_render, 1),
                 "alg_bytes_per_launch": round(ext_bytes_per_launch),
@@ -194,14 +232,14 @@ def main():
 
             osc = oracle_lib.OracleScene(host)
             threads = os.cpu_count() or 1
-            y0 = (args.height // 2 // 16) * 16
-            y1 = min(args.height, y0 + 64)
-            cpu_spp = 8
+            # bounded sample: the middle 640 rows of the same frame (covers walls, mesh and light like the whole
+            # frame does), spp scaled from a 1-spp calibration pass to about 15 s of CPU work (10-30 s window)
+            rows = min(args.height, 640)
+            y0 = max(0, ((args.height - rows) // 2 // 16) * 16)
+            y1 = min(args.height, y0 + rows)
+            _, secs1, _ = osc.render(settings, 1, threads=threads, rows=(y0, y1))
+            cpu_spp = int(min(args.spp, max(1, round(15.0 / max(secs1, 1e-3)))))
             _, secs, _ = osc.render(settings, cpu_spp, threads=threads, rows=(y0, y1))
-            # keep the sample in the 10-30 s window when the host is fast
-            if secs < 5.0:
-                cpu_spp = int(min(256, max(8, cpu_spp * 12.0 / max(secs, 1e-3))))
-                _, secs, _ = osc.render(settings, cpu_spp, threads=threads, rows=(y0, y1))
             cpu_samples = args.width * (y1 - y0) * cpu_spp
             out["cpu_baseline"] = {
                 "value": round(cpu_samples / secs / 1e6, 4),
