@@ -236,6 +236,39 @@ def test_environment_lit_image_parity():
     _image_parity(host, dev, osc, 64, 48, 4, 1, 16, 0.88, environmentRotation=2.1, environmentIntensity=0.5, enableSpecularNee=0)
 
 
+def test_config3_standin_glb_under_hdr_environment():
+    # BASELINE config 3 stand-in at reduced resolution: GLB import (3 PBR primitives incl. an emissive one),
+    # 2048x1024 RGBE environment with three suns of very different radiance (alias tables), envRotation 30 deg
+    host = pt.HostScene.load(os.path.join(SCENES, "helmet_env.scene"), SCENES)
+    dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
+    _image_parity(host, dev, osc, 192, 108, 8, 1, 32, 0.88)
+
+
+def test_config4_standin_glass_knot_depth16():
+    # BASELINE config 4 stand-in: 871,200-triangle dielectric torus knot in the Cornell box, depth 16, RR on
+    from scenes.gen_assets import ensure_large_asset
+    ensure_large_asset("torus_knot_871200.ply")
+    host = pt.HostScene.load(os.path.join(SCENES, "knot_glass.scene"), SCENES)
+    dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
+    info = dev.info()
+    assert info["triangles"] == 871200 + 12 and info["max_depth"] < 48
+    if os.environ.get("PTR_TEST_VERBOSE"):
+        print("knot scene", info)
+    _image_parity(host, dev, osc, 160, 90, 16, 1, 32, 0.85)
+    rays = _random_rays(200_000, -50.0, 600.0, 11)
+    hits = dev.trace_rays(rays, any_hit=False)[0]
+    ref = osc.trace_rays(rays, any_hit=False)
+    assert np.array_equal(hits["t"], ref["t"]) and (ref["t"] >= 0).mean() > 0.3   # bit-identical distances, 0.87 M triangles
+
+
+def test_config5_reduced_sss_and_carpaint_meshes():
+    from scenes.gen_assets import ensure_large_asset
+    ensure_large_asset("blob_125000.ply")
+    host = pt.HostScene.load(os.path.join(GOLDEN, "lucy_small.scene"), SCENES)
+    dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
+    _image_parity(host, dev, osc, 160, 90, 12, 1, 32, 0.88)
+
+
 def test_gradient_sky_and_thin_lens(materials_scene):
     host, dev, osc = materials_scene
     _image_parity(host, dev, osc, 64, 48, 5, 1, 16, 0.90, backgroundMode=0, cameraDefocusAngle=1.5, cameraFocusDistance=8.0)

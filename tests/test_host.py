@@ -226,6 +226,127 @@ def test_obj_and_ply_loaders(tmp_path):
     assert plane.indexCount == 6 and plane.localToWorld[0] == 2.0 and plane.localToWorld[10] == 4.0
 
 
+# --------------------------------------------------------------------------- glTF / GLB import
+def _tiny_gltf(tmp_path, name="t.gltf", with_normals=False, with_camera=True, materials=True, index_type="u16"):
+    """A two-triangle quad under root(scale 2) -> child(translation 1,0,0; rotation 90 deg about Y), data-URI buffer."""
+    import base64
+    import json
+    pos = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32)
+    idx = np.array([0, 1, 2, 0, 2, 3], {"u16": np.uint16, "u8": np.uint8, "u32": np.uint32}[index_type])
+    blob = pos.tobytes() + idx.tobytes()
+    pad = (4 - len(blob) % 4) % 4
+    blob += b"\0" * pad
+    views = [{"buffer": 0, "byteOffset": 0, "byteLength": pos.nbytes}, {"buffer": 0, "byteOffset": pos.nbytes, "byteLength": idx.nbytes}]
+    accessors = [{"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3"},
+                 {"bufferView": 1, "componentType": {"u16": 5123, "u8": 5121, "u32": 5125}[index_type], "count": 6, "type": "SCALAR"}]
+    attrs = {"POSITION": 0}
+    if with_normals:
+        nrm = np.tile(np.array([[0, 0, 1]], np.float32), (4, 1))
+        views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": nrm.nbytes})
+        accessors.append({"bufferView": 2, "componentType": 5126, "count": 4, "type": "VEC3"})
+        attrs["NORMAL"] = 2
+        blob += nrm.tobytes()
+    doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}],
+           "nodes": [{"name": "root", "scale": [2, 2, 2], "children": [1] + ([2] if with_camera else [])},
+                     {"name": "quad", "mesh": 0, "translation": [1, 0, 0], "rotation": [0, 0.70710678, 0, 0.70710678]}],
+           "meshes": [{"name": "m", "primitives": [{"attributes": attrs, "indices": 1, "material": 0},
+                                                   {"attributes": attrs, "indices": 1, "mode": 1}]}],
+           "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+           "bufferViews": views, "accessors": accessors}
+    if with_camera:
+        doc["nodes"].append({"name": "cam", "camera": 0, "translation": [0, 1, 5]})
+        doc["cameras"] = [{"type": "perspective", "perspective": {"yfov": 0.5, "znear": 0.1}}]
+    if materials:
+        doc["materials"] = [{"name": "Gold \u00e9", "doubleSided": True, "alphaMode": "MASK", "alphaCutoff": 0.3,
+                             "pbrMetallicRoughness": {"baseColorFactor": [1.0, 0.8, 0.3, 0.5], "metallicFactor": 1.5, "roughnessFactor": 0.25},
+                             "emissiveFactor": [1, 0.5, 0.25],
+                             "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 4.0},
+                                            "KHR_materials_ior": {"ior": 1.33},
+                                            "KHR_materials_volume": {"thicknessFactor": 0.2, "attenuationColor": [0.5, 1.0, 0.25], "attenuationDistance": 2.0}}}]
+    (tmp_path / "assets").mkdir(exist_ok=True)
+    (tmp_path / "assets" / name).write_text(json.dumps(doc))
+    return doc
+
+
+def test_gltf_hierarchy_materials_generated_normals_and_camera(tmp_path):
+    _tiny_gltf(tmp_path)
+    host = pt.HostScene.load(_write(tmp_path, "renderer gltfEmissiveScale=0.5\nmesh path=assets/t.gltf translate=0,10,0\n"))
+    d = host.desc
+    assert d.meshCount == 1 and d.materialCount == 1        # the LINES primitive (mode 1) is skipped
+    m = d.meshes[0]
+    assert m.vertexCount == 4 and m.indexCount == 6
+    # world = T(0,10,0) * S(2) * T(1,0,0) * Ry(90): local +x -> world -z (scaled by 2), origin -> (2,10,0)
+    xf = np.array(list(m.localToWorld), np.float64).reshape(4, 4).T
+    assert np.allclose(xf @ [0, 0, 0, 1], [2, 10, 0, 1], atol=1e-5)
+    assert np.allclose(xf @ [1, 0, 0, 0], [0, 0, -2, 0], atol=1e-5)
+    nrm = np.ctypeslib.as_array(m.normals, shape=(12,)).reshape(4, 3)
+    assert np.allclose(nrm, [0, 0, 1], atol=1e-6)           # no NORMAL accessor: area-weighted face normals
+    mat = d.materials[0]
+    assert int(mat.typeEta[0]) == 7 and np.isclose(mat.typeEta[1], 1.33) and mat.typeEta[2] == 1.0 and np.isclose(mat.typeEta[3], 0.2)
+    assert np.allclose(list(mat.baseColorRoughness), [1.0, 0.8, 0.3, 0.25])
+    assert np.allclose(list(mat.pbrParams), [1.0, 0.25, 1.0, 1.0])                     # metallic clamped to 1
+    assert np.allclose(list(mat.pbrExtras), [0.5, 0.3, 0.0, 1.0])                      # alpha, cutoff, transmission, MASK
+    assert np.allclose(list(mat.emission)[:3], np.array([1, 0.5, 0.25]) * 4.0 * 0.5)   # strength * renderer gltfEmissiveScale
+    assert np.allclose(list(mat.dielectricSigmaA)[:3], [np.log(2) / 2, 0.0, np.log(4) / 2], atol=1e-6)
+    assert all(t == 0xFFFFFFFF for t in list(mat.textureIndices0) + list(mat.textureIndices1))
+    # embedded perspective camera (no `camera` directive before the mesh): orbit parameters derived from its pose
+    s = host.settings
+    assert np.isclose(s.cameraVerticalFov, np.degrees(0.5), atol=1e-4) and s.cameraDefocusAngle == 0.0
+    eye = np.array(list(s.cameraTarget)) + s.cameraDistance * np.array(
+        [np.cos(s.cameraPitch) * np.cos(s.cameraYaw), np.sin(s.cameraPitch), np.cos(s.cameraPitch) * np.sin(s.cameraYaw)])
+    assert np.allclose(eye, [0, 2, 10], atol=1e-3)          # camera node (0,1,5) under the scale-2 root; mesh transform not applied
+
+
+def test_gltf_camera_directive_wins_and_variants(tmp_path):
+    _tiny_gltf(tmp_path, with_normals=True, materials=False, index_type="u8")
+    host = pt.HostScene.load(_write(tmp_path, "camera target=1,2,3 distance=4 vfov=33\nmesh path=assets/t.gltf\n"))
+    assert np.allclose(list(host.settings.cameraTarget), [1, 2, 3]) and host.settings.cameraVerticalFov == 33.0
+    d = host.desc
+    assert d.materialCount == 1                              # default material: white, metallic 1, roughness 1
+    assert np.allclose(list(d.materials[0].baseColorRoughness), [1, 1, 1, 1]) and d.materials[0].pbrParams[0] == 1.0
+    nrm = np.ctypeslib.as_array(d.meshes[0].normals, shape=(12,)).reshape(4, 3)
+    assert np.allclose(nrm, [0, 0, 1])
+    _tiny_gltf(tmp_path, name="u32.gltf", index_type="u32", with_camera=False)
+    host = pt.HostScene.load(_write(tmp_path, "mesh file=assets/u32.gltf\n"))
+    assert host.desc.meshes[0].indexCount == 6
+
+
+def test_glb_container_and_errors(tmp_path):
+    from scenes.gen_assets import helmet_glb
+    (tmp_path / "assets").mkdir()
+    tris = helmet_glb(str(tmp_path / "assets" / "h.glb"), n=12)
+    host = pt.HostScene.load(_write(tmp_path, "mesh path=assets/h.glb\n"))
+    d = host.desc
+    assert d.meshCount == 3 and d.materialCount == 3 and sum(d.meshes[i].indexCount // 3 for i in range(3)) == tris == 288
+    assert [d.meshes[i].materialIndex for i in range(3)] == [0, 2, 1]
+    assert np.allclose(list(d.materials[2].emission)[:3], [6.0, 2.7, 0.6], atol=1e-5)
+    g = pt.debug_scene_geometry(d)
+    assert g["triangles"] == 288 and g["unreferenced"] == 0 and g["box_violations"] == 0
+    raw = (tmp_path / "assets" / "h.glb").read_bytes()
+    cases = {"magic.glb": (b"XXXX" + raw[4:], "Invalid .glb magic"),
+             "version.glb": (raw[:4] + struct.pack("<I", 1) + raw[8:], "Unsupported .glb version"),
+             "short.glb": (raw[:8], "Invalid .glb header"),
+             "chunk.glb": (raw[:12] + struct.pack("<I", 10 ** 9) + raw[16:], "Invalid .glb chunk length"),
+             "nojson.glb": (raw[:12] + struct.pack("<II", 4, 0x004E4942) + b"abcd", "Missing JSON chunk"),
+             "bad.gltf": (b"{\"asset\": [1, 2,,]}", "Failed to parse glTF JSON"),
+             "nobuf.gltf": (b'{"buffers": [{"byteLength": 4}]}', "buffer missing uri"),
+             "nopos.gltf": (b'{"scenes":[{"nodes":[0]}],"nodes":[{"mesh":0}],"meshes":[{"primitives":[{"attributes":{}}]}]}', "missing POSITION")}
+    for name, (data, message) in cases.items():
+        (tmp_path / "assets" / name).write_bytes(data)
+        with pytest.raises(pt.PtrError, match=re.escape(message)):
+            pt.HostScene.load(_write(tmp_path, "mesh path=assets/%s\n" % name))
+    with pytest.raises(pt.PtrError, match="mesh file not found"):      # resolved (and rejected) before the loader runs
+        pt.HostScene.load(_write(tmp_path, "mesh path=assets/none.glb\n"))
+
+
+def test_config_scenes_parse():
+    host = pt.HostScene.load(os.path.join(ROOT, "scenes", "helmet_env.scene"), os.path.join(ROOT, "scenes"))
+    d = host.desc
+    assert d.meshCount == 3 and sum(d.meshes[i].indexCount // 3 for i in range(3)) == 46208
+    assert d.envWidth == 2048 and d.envHeight == 1024 and np.isclose(host.settings.environmentRotation, np.radians(30))
+    assert [int(d.materials[i].typeEta[0]) for i in range(d.materialCount)] == [0, 7, 7, 7]
+
+
 # --------------------------------------------------------------------------- BVH / leaf-order geometry (host side of ptr_scene_upload)
 def _geometry_ok(g, tris, spheres):
     assert g["triangles"] == tris and g["spheres"] == spheres
