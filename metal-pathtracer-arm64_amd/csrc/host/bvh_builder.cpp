@@ -3,6 +3,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -236,7 +239,8 @@ struct Flattener {
             uint32_t temp, device, depth;
         };
         const TempNode& root = b.nodes[0];
-        out.nodes.assign(16, 0.0f);
+        // one flat node per internal temp node: size the array once (upper bound: every allocated temp node)
+        out.nodes.assign(static_cast<size_t>(std::max(b.nextNode.load(), 1u)) * 16, 0.0f);
         out.nodeCount = 1;
         const uint32_t empty = ptrk::kRefEmpty;
         std::memcpy(out.nodes.data() + 3, &empty, 4);
@@ -264,7 +268,6 @@ struct Flattener {
                     out.maxDepth = std::max(out.maxDepth, it.depth + 2);
                 } else {
                     const uint32_t dev = out.nodeCount++;
-                    out.nodes.resize(static_cast<size_t>(out.nodeCount) * 16, 0.0f);
                     setChild(it.device, s, c.box, dev);
                     pendingDevice[s] = dev;
                     internal[s] = true;
@@ -294,7 +297,16 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
     b.nodes.resize(static_cast<size_t>(2) * n + 1);
     if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
     b.freeThreads = static_cast<int>(std::min(threads, 32u)) - 1;
+    const bool verbose = std::getenv("PTR_BUILD_VERBOSE") != nullptr;
+    auto tick = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (verbose) std::fprintf(stderr, "[bvh] %-10s %.2f s\n", what, std::chrono::duration<double>(now - tick).count());
+        tick = now;
+    };
+    lap("setup");
     b.build(0, 0, n, 0);
+    lap("sah build");
 
     Flattener f{b, out, {}, {}};
     f.primToTri.resize(n);
@@ -310,7 +322,9 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
     out.triOrder.reserve(tri);
     out.sphereOrder.reserve(sph);
     f.run(std::max(static_cast<double>(b.nodes[0].box.halfArea()), 1e-30));
+    out.nodes.resize(static_cast<size_t>(out.nodeCount) * 16);
     out.rootRef = 0u;
+    lap("flatten");
 
     // 16-bit grid version of the nodes.  lo is rounded down and hi up, plus one cell of padding on each
     // side, so a quantised box always contains the float box (the traversal stays conservative).
@@ -328,30 +342,44 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
         const double q = up ? std::ceil(g) + 1.0 : std::floor(g) - 1.0;
         return static_cast<uint32_t>(std::min(std::max(q, 0.0), 65535.0));
     };
-    for (uint32_t i = 0; i < out.nodeCount; ++i) {
-        const float* n = out.nodes.data() + static_cast<size_t>(i) * 16;
-        uint32_t* q = out.qnodes.data() + static_cast<size_t>(i) * 8;
-        for (int c = 0; c < 2; ++c) {
-            const float* lo = n + c * 8;
-            const float* hi = n + c * 8 + 4;
-            uint32_t ref;
-            std::memcpy(&ref, n + (c == 0 ? 3 : 7), 4);
-            uint32_t* w = q + c * 4;
-            if (ref == ptrk::kRefEmpty) {
-                w[0] = w[1] = w[2] = 0u;
-            } else {
-                w[0] = quant(lo[0], 0, false) | (quant(lo[1], 1, false) << 16);
-                w[1] = quant(lo[2], 2, false) | (quant(hi[0], 0, true) << 16);
-                w[2] = quant(hi[1], 1, true) | (quant(hi[2], 2, true) << 16);
+    auto quantiseRange = [&](uint32_t begin, uint32_t end) {
+        for (uint32_t i = begin; i < end; ++i) {
+            const float* n = out.nodes.data() + static_cast<size_t>(i) * 16;
+            uint32_t* q = out.qnodes.data() + static_cast<size_t>(i) * 8;
+            for (int c = 0; c < 2; ++c) {
+                const float* lo = n + c * 8;
+                const float* hi = n + c * 8 + 4;
+                uint32_t ref;
+                std::memcpy(&ref, n + (c == 0 ? 3 : 7), 4);
+                uint32_t* w = q + c * 4;
+                if (ref == ptrk::kRefEmpty) {
+                    w[0] = w[1] = w[2] = 0u;
+                } else {
+                    w[0] = quant(lo[0], 0, false) | (quant(lo[1], 1, false) << 16);
+                    w[1] = quant(lo[2], 2, false) | (quant(hi[0], 0, true) << 16);
+                    w[2] = quant(hi[1], 1, true) | (quant(hi[2], 2, true) << 16);
+                }
+                w[3] = ref;
             }
-            w[3] = ref;
         }
+    };
+    {
+        const uint32_t workers = out.nodeCount >= (1u << 16) ? std::min(threads, 32u) : 1u;
+        const uint32_t chunk = (out.nodeCount + workers - 1) / workers;
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < workers; ++t) {
+            const uint32_t lo = std::min(out.nodeCount, chunk * t), hi = std::min(out.nodeCount, chunk * (t + 1));
+            if (lo < hi) pool.emplace_back(quantiseRange, lo, hi);
+        }
+        quantiseRange(0, std::min(out.nodeCount, chunk));
+        for (auto& th : pool) th.join();
     }
     double extentSum = 0.0;
     for (const BuildPrim& p : prims) {
         extentSum += std::max(std::max(p.hi[0] - p.lo[0], p.hi[1] - p.lo[1]), p.hi[2] - p.lo[2]);
     }
     out.meanPrimExtent = static_cast<float>(extentSum / n);
+    lap("quantise");
 }
 
 }  // namespace ptr

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -235,6 +236,10 @@ bool BuildSceneGeometry(const PtrSceneDesc& desc, uint32_t leafMax, SceneGeometr
         out.sphereInfo.push_back(s.materialIndex[0]);
     }
     out.flattenSeconds = secondsSince(t0);
+    if (std::getenv("PTR_BUILD_VERBOSE")) {
+        std::fprintf(stderr, "[geometry] gather %.2f s, bvh %.2f s, leaf-order %.2f s (%u triangles, %u spheres)\n", out.gatherSeconds,
+                     out.buildSeconds, out.flattenSeconds, out.triCount, out.sphereCount);
+    }
     return true;
 }
 
