@@ -870,7 +870,7 @@ __device__ f3 mneeChain(const RenderParams& rp, const SceneView& sc, const Clamp
 }  // namespace
 
 template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride,
+__global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) k_connect(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride,
                                                           uint32_t* workCounter, int kRefillBelow) {
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
@@ -891,35 +891,39 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams rp, SceneV
     Trav t;
     t.cur = 0u;
     bool active = false;
-    uint32_t mySlot = 0u, myRec = 0u, bits = 0u;
+    uint32_t mySlot = 0u, bits = 0u;
+    // the record arrays are one allocation: field f of record slot k lives at recBase[(k*4 + f)*slots + slot]
+    float4* const recBase = pool.rec[0].org;
+    const uint32_t slots = pool.slots;
+    uint32_t myRecAt = 0u;   // (record*4)*slots + slot of the record this lane is resolving
     while (true) {
-        if (!active && bits != 0u) {
-            // next record of the slot this lane already holds
-            myRec = static_cast<uint32_t>(__ffs(static_cast<int>(bits))) - 1u;
-            bits &= bits - 1u;
-            const ShadowRecordView& r = pool.rec[myRec];
-            const float4 o4 = r.org[mySlot], d4 = r.dir[mySlot];
-            const uint32_t kind = __float_as_uint(d4.w);
-            if (kind != 2u) {   // kind 2 (MNEE chains) is resolved by k_connect_chain
-                if (COUNT) { if (kind == 0u) ++rays; else ++raysClosest; }
-                active = travBegin(sc, t, mk3(o4), mk3(d4), kEps, kind == 0u ? o4.w : INFINITY, kind == 0u, stack);
-                if (!active && kind != 0u) r.a[mySlot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-        }
         const int nActive = __popcll(__ballot(active));
-        const bool anyBits = __ballot(bits != 0u) != 0ull;
-        if (nActive < kRefillBelow && !feeder.exhausted) {
-            const uint32_t idx = feeder.take(!active && bits == 0u);
-            if (idx != WaveFeeder::kNone) {
-                mySlot = idx;
-                bits = pool.state[idx].w & ((1u << kRecSlots) - 1u);
+        const bool idleBits = __ballot(!active && bits != 0u) != 0ull;
+        if (nActive < kRefillBelow && (idleBits || !feeder.exhausted)) {
+            // batched refill (like k_extend): new slots for lanes that have nothing left, then the next record of
+            // every idle lane.  Starting records lane by lane as they finish stalled the whole wave on each load.
+            if (!feeder.exhausted) {
+                const uint32_t idx = feeder.take(!active && bits == 0u);
+                if (idx != WaveFeeder::kNone) {
+                    mySlot = idx;
+                    bits = pool.state[idx].w & ((1u << kRecSlots) - 1u);
+                }
+            }
+            if (!active && bits != 0u) {
+                const uint32_t rec = static_cast<uint32_t>(__ffs(static_cast<int>(bits))) - 1u;
+                bits &= bits - 1u;
+                myRecAt = rec * 4u * slots + mySlot;
+                const float4 o4 = recBase[myRecAt], d4 = recBase[myRecAt + slots];
+                const uint32_t kind = __float_as_uint(d4.w);
+                if (kind != 2u) {   // kind 2 (MNEE chains) is resolved by k_connect_chain
+                    if (COUNT) { if (kind == 0u) ++rays; else ++raysClosest; }
+                    active = travBegin(sc, t, mk3(o4), mk3(d4), kEps, kind == 0u ? o4.w : INFINITY, kind == 0u, stack);
+                    if (!active && kind != 0u) recBase[myRecAt + 2u * slots] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
             }
             continue;
         }
-        if (nActive == 0) {
-            if (!anyBits) break;
-            continue;
-        }
+        if (nActive == 0) break;
         {
             // counting build: nodes/prims of closest-hit (kind 1) rays are booked with the extend counters
             TraceCounters step{0u, 0u};
@@ -931,14 +935,14 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect(RenderParams rp, SceneV
             }
             if (!more) {
                 active = false;
-                const ShadowRecordView& r = pool.rec[myRec];
+                float4* const a = recBase + myRecAt + 2u * slots;
                 if (t.anyHit) {
                     if (COUNT) early += (t.hit.prim != kHitMiss) ? 1u : 0u;
-                    if (t.hit.prim != kHitMiss) r.a[mySlot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (t.hit.prim != kHitMiss) *a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 } else {
-                    const float4 a4 = r.a[mySlot];
-                    const f3 c = rectContribution(rp, sc, cc, t.org, t.dir, t.hit, mk3(a4), a4.w, mk3(r.b[mySlot]));
-                    r.a[mySlot] = mk4(c, 0.0f);
+                    const float4 a4 = *a;
+                    const f3 c = rectContribution(rp, sc, cc, t.org, t.dir, t.hit, mk3(a4), a4.w, mk3(recBase[myRecAt + 3u * slots]));
+                    *a = mk4(c, 0.0f);
                 }
             }
         }

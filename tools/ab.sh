@@ -1,11 +1,15 @@
 #!/bin/bash
-# A/B bench of library variants on the GPU box: tools/ab.sh <spp> <name...>   ("base" = the in-tree library)
-SPP=$1; shift
+# A/B bench of library variants on the GPU box: tools/ab.sh "<bench args>" <name...>   ("base" = the in-tree library)
+# e.g. tools/ab.sh "--spp 64" base head ; tools/ab.sh "--scene scenes/knot_glass.scene --depth 16 --spp 32" base head
+ARGS=$1; shift
+python3 -c "
+from scenes.gen_assets import ensure_assets, ensure_large_asset
+ensure_assets(); ensure_large_asset('torus_knot_871200.ply')"
 for n in "$@"; do
   if [ "$n" = base ]; then unset PTR_HIP_LIBRARY; else export PTR_HIP_LIBRARY=$PWD/variants/libptr_$n.so; fi
-  echo "== $n"
-  timeout -k 10 200 python bench.py --spp $SPP --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c "
+  echo "== $n  [$ARGS]"
+  timeout -k 10 300 python bench.py $ARGS --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(d['value'], d['kernel_ms_per_step'], d['roofline']['avg_launch_ms'], 'extend alg bytes/launch', d['roofline']['alg_bytes_per_launch'], 'B/sample', d['roofline']['bytes_per_sample'])"
+print(d['value'], d['kernel_ms_per_step'], 'extend launch ms', d['roofline']['avg_launch_ms'], 'B/sample', d['roofline']['bytes_per_sample'])"
 done
