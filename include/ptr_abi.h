@@ -240,12 +240,17 @@ void ptr_host_scene_free(PtrHostScene* scene);
 /* Pointers stay valid until ptr_host_scene_free. */
 int ptr_host_scene_desc(const PtrHostScene* scene, PtrSceneDesc* out_desc, PtrSettings* out_settings);
 
-/* format: "pfm" | "exr" | "ppm"; EXR = RGB (channels B,G,R) unless rgba != 0 (B,G,R,A + colorspace attr,
- * what the reference's Embree backend writes, main_headless.mm:568-583). */
+/* format: "pfm" | "exr" | "ppm" | "png" (src/renderer/ImageWriter.mm:164-214, 239-464, 480-565); EXR = RGB
+ * (channels B,G,R) unless rgba != 0 (B,G,R,A + colorspace attr, what the reference's Embree backend writes,
+ * main_headless.mm:568-583).  PNG/PPM are tonemapped 8-bit (PNG: RGBA, alpha 255, sRGB chunk). */
 int ptr_host_write_image(const char* path, const char* format, const float* linear_rgb,
                          uint32_t width, uint32_t height, int rgba_exr,
                          uint32_t tonemap_mode, uint32_t aces_variant, float exposure, float reinhard_white,
                          char* err, size_t err_cap);
+/* RGBA EXR plus a planar SAMPLES channel holding per-pixel sample counts (ImageWriter::WriteEXR_Multilayer,
+ * src/renderer/ImageWriter.mm:657-684).  sample_counts: width*height floats, or NULL for plain RGBA. */
+int ptr_host_write_exr_multilayer(const char* path, const float* linear_rgb, uint32_t width, uint32_t height,
+                                  const float* sample_counts, const char* colorspace, char* err, size_t err_cap);
 int ptr_host_read_pfm(const char* path, float* out_rgb, uint32_t cap_floats, uint32_t* width, uint32_t* height);
 
 const char* ptr_version(void);

@@ -188,7 +188,7 @@ assert C.sizeof(PtrHit) == HIT_DTYPE.itemsize == 40
 ABI_SYMBOLS = (
     "ptr_device_count", "ptr_scene_upload", "ptr_scene_release", "ptr_scene_info", "ptr_render",
     "ptr_render_bands_device", "ptr_part_band_count", "ptr_render_bands", "ptr_trace_rays",
-    "ptr_host_scene_load", "ptr_host_scene_free", "ptr_host_scene_desc", "ptr_host_write_image",
+    "ptr_host_scene_load", "ptr_host_scene_free", "ptr_host_scene_desc", "ptr_host_write_image", "ptr_host_write_exr_multilayer",
     "ptr_host_read_pfm", "ptr_version",
 )
 # include/ptr_debug.h (test-only device-function probes)
@@ -232,6 +232,7 @@ def load_library() -> C.CDLL:
     lib.ptr_host_scene_desc.argtypes = [vp, C.POINTER(PtrSceneDesc), C.POINTER(PtrSettings)]
     lib.ptr_host_write_image.argtypes = [cp, cp, C.POINTER(C.c_float), u32, u32, C.c_int, u32, u32, C.c_float,
                                          C.c_float, cp, sz]
+    lib.ptr_host_write_exr_multilayer.argtypes = [cp, C.POINTER(C.c_float), u32, u32, C.POINTER(C.c_float), cp, cp, sz]
     lib.ptr_host_read_pfm.argtypes = [cp, C.POINTER(C.c_float), u32, C.POINTER(u32), C.POINTER(u32)]
     lib.ptr_version.restype = cp
     fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
@@ -410,6 +411,20 @@ def write_image(path: str, rgb: np.ndarray, fmt: str = "pfm", rgba_exr: bool = F
     err = _err_buf()
     _check(lib.ptr_host_write_image(os.fsencode(path), fmt.encode(), _fptr(rgb), w, h, int(rgba_exr), tonemap,
                                     aces_variant, exposure, reinhard_white, err, len(err)), err)
+
+
+def write_exr_multilayer(path: str, rgb: np.ndarray, sample_counts: Optional[np.ndarray] = None,
+                         colorspace: str = "Linear sRGB") -> None:
+    """RGBA EXR with a planar SAMPLES channel (per-pixel sample counts), or plain RGBA when sample_counts is None."""
+    lib = load_library()
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w = rgb.shape[0], rgb.shape[1]
+    counts = None
+    if sample_counts is not None:
+        counts = np.ascontiguousarray(sample_counts, dtype=np.float32).reshape(h, w)
+    err = _err_buf()
+    _check(lib.ptr_host_write_exr_multilayer(os.fsencode(path), _fptr(rgb), w, h, _fptr(counts) if counts is not None else None,
+                                             colorspace.encode(), err, len(err)), err)
 
 
 def read_pfm(path: str) -> np.ndarray:

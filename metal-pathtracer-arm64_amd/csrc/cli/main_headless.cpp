@@ -260,9 +260,24 @@ int main(int argc, const char** argv) {
     ptr::SceneResources resources;
     ptr::RenderSettings settings{};
     std::string sceneError;
-    if (!sceneManager.loadSceneFromPath(options.scene, resources, settings, &sceneError)) {
+    // a value that looks like a path (or names an existing file) is loaded directly; anything else is a scene
+    // identifier looked up in the scene directory (main_headless.mm:389-396, 486-506)
+    bool sceneIsPath;
+    {
+        const std::filesystem::path scenePath(options.scene);
+        std::error_code ec;
+        sceneIsPath = scenePath.extension() == ".scene" || scenePath.has_parent_path() || scenePath.is_absolute() ||
+                      std::filesystem::exists(scenePath, ec);
+    }
+    const bool sceneLoaded = sceneIsPath ? sceneManager.loadSceneFromPath(options.scene, resources, settings, &sceneError)
+                                         : sceneManager.loadScene(options.scene, resources, settings, &sceneError);
+    if (!sceneLoaded) {
         std::cerr << "Failed to load scene: " << options.scene << std::endl;
         if (!sceneError.empty()) std::cerr << sceneError << std::endl;
+        if (!sceneManager.scenes().empty()) {
+            std::cerr << "Available scenes:" << std::endl;
+            for (const auto& info : sceneManager.scenes()) std::cerr << "  " << info.identifier << std::endl;
+        }
         return 1;
     }
 
@@ -282,7 +297,7 @@ int main(int argc, const char** argv) {
 
     ptr::HeadlessScene scene{};
     scene.source = options.scene;
-    scene.isPath = true;
+    scene.isPath = sceneIsPath;
     scene.resources = &resources;
     ptr::HeadlessCamera camera{};
     camera.target = settings.cameraTarget;

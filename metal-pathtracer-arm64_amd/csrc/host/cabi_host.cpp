@@ -98,6 +98,27 @@ int ptr_host_write_image(const char* path, const char* format, const float* line
     return 0;
 }
 
+int ptr_host_write_exr_multilayer(const char* path, const float* linear_rgb, uint32_t width, uint32_t height,
+                                  const float* sample_counts, const char* colorspace, char* err, size_t err_cap) {
+    if (!path || !linear_rgb || width == 0 || height == 0) {
+        setErr(err, err_cap, "ptr_host_write_exr_multilayer: bad argument");
+        return 1;
+    }
+    const size_t n = static_cast<size_t>(width) * height;
+    std::vector<float> rgba(n * 4u, 1.0f);
+    for (size_t i = 0; i < n; ++i) {
+        rgba[i * 4 + 0] = linear_rgb[i * 3 + 0];
+        rgba[i * 4 + 1] = linear_rgb[i * 3 + 1];
+        rgba[i * 4 + 2] = linear_rgb[i * 3 + 2];
+    }
+    std::string error;
+    if (!ptr::WriteExrMultilayer(path, rgba.data(), width, height, sample_counts, colorspace, &error)) {
+        setErr(err, err_cap, error);
+        return 1;
+    }
+    return 0;
+}
+
 int ptr_host_read_pfm(const char* path, float* out_rgb, uint32_t cap_floats, uint32_t* width, uint32_t* height) {
     FILE* f = std::fopen(path, "rb");
     if (!f) return 1;

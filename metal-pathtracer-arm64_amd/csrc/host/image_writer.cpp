@@ -120,7 +120,8 @@ struct ByteSink {
 
 struct ExrChannel {
     const char* name;
-    uint32_t component;  // index into the interleaved source pixel
+    uint32_t component;            // index into the interleaved source pixel
+    const float* planar = nullptr; // if set: a separate width*height plane instead (ImageWriter.mm "Planar" channels)
 };
 
 // Uncompressed scanline OpenEXR, FLOAT channels, INCREASING_Y; attribute order follows
@@ -185,8 +186,12 @@ bool writeScanlineExr(const std::string& path, const float* interleaved, uint32_
         const int32_t yy = static_cast<int32_t>(y);
         const uint32_t packed = static_cast<uint32_t>(line.size() * sizeof(float));
         for (size_t c = 0; c < nch; ++c) {  // channel-planar within a scanline
-            const float* src = interleaved + static_cast<size_t>(y) * w * stride + channels[c].component;
             float* dst = line.data() + c * w;
+            if (channels[c].planar) {
+                std::memcpy(dst, channels[c].planar + static_cast<size_t>(y) * w, static_cast<size_t>(w) * sizeof(float));
+                continue;
+            }
+            const float* src = interleaved + static_cast<size_t>(y) * w * stride + channels[c].component;
             for (uint32_t x = 0; x < w; ++x) dst[x] = src[static_cast<size_t>(x) * stride];
         }
         ok = fwrite(&yy, 4, 1, f) == 1 && fwrite(&packed, 4, 1, f) == 1 &&
@@ -194,6 +199,180 @@ bool writeScanlineExr(const std::string& path, const float* interleaved, uint32_
     }
     fclose(f);
     return ok ? true : fail(err, "Failed writing to EXR file");
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// PNG (the reference goes through Apple ImageIO, ImageWriter.mm:480-565: tonemapped 8-bit RGBA, alpha 255, sRGB
+// colour space).  Encoder written here: Sub filter per row, zlib stream of fixed-Huffman deflate blocks with a
+// hash-chain LZ77 matcher.  Pixel values are the reference's; the byte stream of another encoder can differ.
+uint32_t crc32Update(uint32_t crc, const uint8_t* data, size_t n) {
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+            table[i] = c;
+        }
+        ready = true;
+    }
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ data[i]) & 0xFFu] ^ (crc >> 8);
+    return crc;
+}
+
+struct BitSink {
+    std::vector<uint8_t> bytes;
+    uint32_t acc = 0;
+    int fill = 0;
+    void put(uint32_t value, int count) {   // LSB-first, as deflate packs everything except Huffman codes
+        acc |= value << fill;
+        fill += count;
+        while (fill >= 8) {
+            bytes.push_back(static_cast<uint8_t>(acc & 0xFFu));
+            acc >>= 8;
+            fill -= 8;
+        }
+    }
+    void putHuffman(uint32_t code, int length) {   // Huffman codes go in MSB-first
+        uint32_t reversed = 0;
+        for (int i = 0; i < length; ++i) reversed |= ((code >> i) & 1u) << (length - 1 - i);
+        put(reversed, length);
+    }
+    void flush() {
+        if (fill > 0) put(0, 8 - fill);
+    }
+};
+
+void fixedLiteral(BitSink& out, uint32_t symbol) {   // RFC 1951 section 3.2.6
+    if (symbol <= 143) out.putHuffman(0x30 + symbol, 8);
+    else if (symbol <= 255) out.putHuffman(0x190 + (symbol - 144), 9);
+    else if (symbol <= 279) out.putHuffman(symbol - 256, 7);
+    else out.putHuffman(0xC0 + (symbol - 280), 8);
+}
+
+void fixedMatch(BitSink& out, uint32_t length, uint32_t distance) {
+    static const uint16_t lenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t distBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t distExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    int li = 28;
+    while (lenBase[li] > length) --li;
+    fixedLiteral(out, 257u + static_cast<uint32_t>(li));
+    if (lenExtra[li]) out.put(length - lenBase[li], lenExtra[li]);
+    int di = 29;
+    while (distBase[di] > distance) --di;
+    out.putHuffman(static_cast<uint32_t>(di), 5);
+    if (distExtra[di]) out.put(distance - distBase[di], distExtra[di]);
+}
+
+std::vector<uint8_t> zlibCompress(const std::vector<uint8_t>& in) {
+    BitSink out;
+    out.put(0x78, 8);   // CMF: deflate, 32 K window
+    out.put(0x9C, 8);   // FLG: check bits, default compression
+    out.put(1, 1);      // BFINAL
+    out.put(1, 2);      // BTYPE = fixed Huffman
+    const size_t n = in.size();
+    constexpr uint32_t kHashSize = 1u << 15, kWindow = 32768u, kChain = 16u, kMinMatch = 3u, kMaxMatch = 258u;
+    std::vector<int64_t> head(kHashSize, -1), prev(n, -1);
+    auto hash3 = [&](size_t i) { return ((static_cast<uint32_t>(in[i]) << 10) ^ (static_cast<uint32_t>(in[i + 1]) << 5) ^ in[i + 2]) & (kHashSize - 1); };
+    size_t i = 0;
+    while (i < n) {
+        uint32_t bestLen = 0, bestDist = 0;
+        if (i + kMinMatch <= n) {
+            const uint32_t h = hash3(i);
+            int64_t cand = head[h];
+            for (uint32_t chain = 0; cand >= 0 && chain < kChain && i - static_cast<size_t>(cand) <= kWindow; ++chain) {
+                const size_t c = static_cast<size_t>(cand);
+                uint32_t len = 0;
+                const uint32_t limit = static_cast<uint32_t>(std::min<size_t>(kMaxMatch, n - i));
+                while (len < limit && in[c + len] == in[i + len]) ++len;
+                if (len > bestLen) {
+                    bestLen = len;
+                    bestDist = static_cast<uint32_t>(i - c);
+                    if (len == limit) break;
+                }
+                cand = prev[c];
+            }
+            prev[i] = head[h];
+            head[h] = static_cast<int64_t>(i);
+        }
+        if (bestLen >= kMinMatch) {
+            fixedMatch(out, bestLen, bestDist);
+            for (size_t k = 1; k < bestLen && i + k + kMinMatch <= n; ++k) {   // keep the hash chains current
+                const uint32_t h = hash3(i + k);
+                prev[i + k] = head[h];
+                head[h] = static_cast<int64_t>(i + k);
+            }
+            i += bestLen;
+        } else {
+            fixedLiteral(out, in[i]);
+            ++i;
+        }
+    }
+    fixedLiteral(out, 256);   // end of block
+    out.flush();
+    uint32_t a = 1, b = 0;    // Adler-32 of the uncompressed data, big-endian
+    for (uint8_t v : in) {
+        a = (a + v) % 65521u;
+        b = (b + a) % 65521u;
+    }
+    const uint32_t adler = (b << 16) | a;
+    for (int shift = 24; shift >= 0; shift -= 8) out.bytes.push_back(static_cast<uint8_t>((adler >> shift) & 0xFFu));
+    return out.bytes;
+}
+
+bool writePNG(const std::string& path, const float* rgb, uint32_t w, uint32_t h, const TonemapSettings& tm, std::string* err) {
+    // filtered scanlines: filter byte 1 (Sub) + RGBA8
+    const size_t rowBytes = static_cast<size_t>(w) * 4;
+    std::vector<uint8_t> raw((rowBytes + 1) * h);
+    std::vector<uint8_t> row(rowBytes);
+    for (uint32_t y = 0; y < h; ++y) {
+        for (uint32_t x = 0; x < w; ++x) {
+            const size_t i = static_cast<size_t>(y) * w + x;
+            const Rgb c = applyTonemap(Rgb{rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]}, tm);
+            row[4 * x + 0] = quantize(c.r);
+            row[4 * x + 1] = quantize(c.g);
+            row[4 * x + 2] = quantize(c.b);
+            row[4 * x + 3] = 255;
+        }
+        uint8_t* dst = raw.data() + static_cast<size_t>(y) * (rowBytes + 1);
+        dst[0] = 1;
+        for (size_t k = 0; k < rowBytes; ++k) dst[1 + k] = static_cast<uint8_t>(row[k] - (k >= 4 ? row[k - 4] : 0));
+    }
+    const std::vector<uint8_t> idat = zlibCompress(raw);
+
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return fail(err, "Failed to open output file: " + path);
+    bool ok = true;
+    auto be32 = [](uint32_t v, uint8_t* p) {
+        p[0] = static_cast<uint8_t>(v >> 24), p[1] = static_cast<uint8_t>(v >> 16), p[2] = static_cast<uint8_t>(v >> 8), p[3] = static_cast<uint8_t>(v);
+    };
+    auto chunk = [&](const char* type, const uint8_t* data, size_t n) {
+        uint8_t hdr[8];
+        be32(static_cast<uint32_t>(n), hdr);
+        std::memcpy(hdr + 4, type, 4);
+        uint32_t crc = crc32Update(0xFFFFFFFFu, hdr + 4, 4);
+        if (n) crc = crc32Update(crc, data, n);
+        uint8_t tail[4];
+        be32(crc ^ 0xFFFFFFFFu, tail);
+        ok = ok && fwrite(hdr, 1, 8, f) == 8 && (n == 0 || fwrite(data, 1, n, f) == n) && fwrite(tail, 1, 4, f) == 4;
+    };
+    static const uint8_t signature[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    ok = fwrite(signature, 1, 8, f) == 8;
+    uint8_t ihdr[13];
+    be32(w, ihdr);
+    be32(h, ihdr + 4);
+    ihdr[8] = 8;    // bit depth
+    ihdr[9] = 6;    // colour type RGBA
+    ihdr[10] = 0, ihdr[11] = 0, ihdr[12] = 0;
+    chunk("IHDR", ihdr, 13);
+    const uint8_t intent = 0;   // sRGB chunk, perceptual (kCGRenderingIntentDefault)
+    chunk("sRGB", &intent, 1);
+    chunk("IDAT", idat.data(), idat.size());
+    chunk("IEND", nullptr, 0);
+    fclose(f);
+    return ok ? true : fail(err, "Failed to finalize PNG file");
 }
 
 }  // namespace
@@ -233,9 +412,7 @@ bool WriteImage(const std::string& path, ImageFileFormat format, const float* li
             return writeScanlineExr(path, linearRGB, 3, width, height, {{"B", 2}, {"G", 1}, {"R", 0}}, nullptr, errorMessage);
         case ImageFileFormat::PFM: return writePFM(path, linearRGB, width, height, errorMessage);
         case ImageFileFormat::PPM: return writePPM(path, linearRGB, width, height, tonemap, errorMessage);
-        case ImageFileFormat::PNG:
-            // The reference encodes PNG through Apple ImageIO (ImageWriter.mm:480-565); SURVEY §8(f) rank 3.
-            return fail(errorMessage, "PNG output is not available in this build (use exr, pfm or ppm)");
+        case ImageFileFormat::PNG: return writePNG(path, linearRGB, width, height, tonemap, errorMessage);
     }
     return false;
 }
@@ -243,6 +420,13 @@ bool WriteImage(const std::string& path, ImageFileFormat format, const float* li
 bool WriteExrRgba(const std::string& path, const float* rgba, uint32_t width, uint32_t height,
                   const char* colorspace, std::string* errorMessage) {
     return writeScanlineExr(path, rgba, 4, width, height, {{"B", 2}, {"G", 1}, {"R", 0}, {"A", 3}}, colorspace, errorMessage);
+}
+
+bool WriteExrMultilayer(const std::string& path, const float* rgba, uint32_t width, uint32_t height, const float* sampleCount,
+                        const char* colorspace, std::string* errorMessage) {
+    if (!sampleCount) return WriteExrRgba(path, rgba, width, height, colorspace, errorMessage);
+    return writeScanlineExr(path, rgba, 4, width, height, {{"B", 2}, {"G", 1}, {"R", 0}, {"A", 3}, {"SAMPLES", 0, sampleCount}}, colorspace,
+                            errorMessage);
 }
 
 }  // namespace ptr

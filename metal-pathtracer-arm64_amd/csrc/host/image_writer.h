@@ -1,5 +1,5 @@
-// Image output for the headless CLI: PFM / PPM / scanline EXR, byte-compatible with the
-// reference's src/renderer/ImageWriter.mm (WritePPM 164-191, WritePFM 193-214, WriteScanlineEXR 239-464).
+// Image output for the headless CLI: PFM / PPM / scanline EXR (byte-compatible with the reference) and PNG;
+// reference: src/renderer/ImageWriter.mm (WritePPM 164-191, WritePFM 193-214, WriteScanlineEXR 239-464, WritePNG 480-565).
 #pragma once
 
 #include <cstdint>
@@ -26,6 +26,11 @@ bool WriteImage(const std::string& path, ImageFileFormat format, const float* li
 // RGBA EXR with optional colorspace string attribute (what main_headless.mm:568-583 writes for Embree).
 bool WriteExrRgba(const std::string& path, const float* rgba, uint32_t width, uint32_t height,
                   const char* colorspace, std::string* errorMessage = nullptr);
+
+// RGBA + a planar SAMPLES channel (per-pixel sample counts), ImageWriter.mm:657-684; falls back to WriteExrRgba
+// when sampleCount is null.
+bool WriteExrMultilayer(const std::string& path, const float* rgba, uint32_t width, uint32_t height, const float* sampleCount,
+                        const char* colorspace, std::string* errorMessage = nullptr);
 
 // 8-bit tonemapped RGB (shared by PPM writer and tests).
 void TonemapToLdr(const float* linearRGB, uint32_t pixelCount, const TonemapSettings& tonemap, uint8_t* outRgb8);

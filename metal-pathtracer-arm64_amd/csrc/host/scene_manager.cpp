@@ -142,6 +142,64 @@ SceneManager::SceneManager(std::string sceneDirectory) : m_sceneDirectory(std::m
             m_sceneDirectory = (cwd / "assets").string();
         }
     }
+    refresh(nullptr);
+}
+
+bool SceneManager::refresh(std::string* errorMessage) {
+    m_scenes.clear();
+    m_sceneIndexById.clear();
+    if (m_sceneDirectory.empty()) return true;
+    std::error_code ec;
+    const fs::path dir(m_sceneDirectory);
+    if (!fs::exists(dir, ec) || !fs::is_directory(dir, ec)) {
+        if (errorMessage) *errorMessage = "Scene directory is not accessible: " + m_sceneDirectory;
+        return false;
+    }
+    for (fs::directory_iterator it(dir, ec), end; !ec && it != end; it.increment(ec)) {
+        if (!it->is_regular_file() || it->path().extension() != ".scene") continue;
+        SceneInfo info;
+        std::error_code absEc;
+        const fs::path absolute = fs::absolute(it->path(), absEc);
+        info.filePath = absEc ? it->path().string() : absolute.string();
+        info.identifier = it->path().stem().string();
+        info.displayName = readDisplayName(info.filePath);
+        if (info.displayName.empty()) info.displayName = info.identifier;
+        m_scenes.push_back(std::move(info));
+    }
+    if (ec) {
+        if (errorMessage) *errorMessage = "Failed iterating scene directory: " + ec.message();
+        return false;
+    }
+    std::sort(m_scenes.begin(), m_scenes.end(), [](const SceneInfo& a, const SceneInfo& b) { return a.displayName < b.displayName; });
+    for (size_t i = 0; i < m_scenes.size(); ++i) m_sceneIndexById[m_scenes[i].identifier] = i;
+    return true;
+}
+
+std::string SceneManager::readDisplayName(const std::string& filePath) {
+    std::ifstream stream(filePath);
+    std::string line;
+    while (stream.is_open() && std::getline(stream, line)) {
+        std::string trimmed = trim(line);
+        if (trimmed.empty()) continue;
+        if (trimmed.front() == '#') return trim(trimmed.substr(1));
+        break;
+    }
+    return {};
+}
+
+const SceneManager::SceneInfo* SceneManager::findScene(const std::string& identifier) const {
+    const auto it = m_sceneIndexById.find(identifier);
+    return it == m_sceneIndexById.end() ? nullptr : &m_scenes[it->second];
+}
+
+bool SceneManager::loadScene(const std::string& identifier, SceneResources& resources, RenderSettings& inOutSettings,
+                             std::string* errorMessage) {
+    const SceneInfo* info = findScene(identifier);
+    if (!info) {
+        if (errorMessage) *errorMessage = "Unknown scene identifier: " + identifier;
+        return false;
+    }
+    return loadSceneFromPath(info->filePath, resources, inOutSettings, errorMessage);
 }
 
 bool SceneManager::loadSceneFromPath(const std::string& path, SceneResources& resources,

@@ -6,6 +6,7 @@
 #include <istream>
 #include <string>
 #include <unordered_map>
+#include <vector>
 
 #include "render_settings.h"
 #include "scene_resources.h"
@@ -18,6 +19,18 @@ public:
     // rule (<cwd>/assets when it exists, else the process CWD, SceneManager.mm:570-615, 2401-2407); files
     // not found there are additionally looked up next to the .scene file (convenience extension).
     explicit SceneManager(std::string sceneDirectory = {});
+
+    // Scene catalogue of the scene directory (SceneManager.mm:646-675, 724-789, 2635-2663): every *.scene file,
+    // identifier = file stem, display name = text of a leading `#` comment line (else the identifier), sorted
+    // by display name.
+    struct SceneInfo {
+        std::string identifier, displayName, filePath;
+    };
+    bool refresh(std::string* errorMessage = nullptr);
+    const std::vector<SceneInfo>& scenes() const { return m_scenes; }
+    const SceneInfo* findScene(const std::string& identifier) const;
+    bool loadScene(const std::string& identifier, SceneResources& resources, RenderSettings& inOutSettings,
+                   std::string* errorMessage = nullptr);
 
     bool loadSceneFromPath(const std::string& path, SceneResources& resources, RenderSettings& inOutSettings,
                            std::string* errorMessage = nullptr);
@@ -49,8 +62,12 @@ private:
                    const std::unordered_map<std::string, uint32_t>& materialIndicesByName) const;
     bool resolveAssetPath(const std::string& value, bool hdrSubdir, std::string& outPath) const;
 
+    static std::string readDisplayName(const std::string& filePath);
+
     std::string m_sceneDirectory;
     mutable std::string m_sceneFileDirectory;
+    std::vector<SceneInfo> m_scenes;
+    std::unordered_map<std::string, size_t> m_sceneIndexById;
 };
 
 }  // namespace ptr

@@ -439,8 +439,45 @@ def test_ppm_tonemap_and_exr_layout(tmp_path):
     assert np.array_equal(planes[0], img[0, :, 2]) and np.array_equal(planes[2], img[0, :, 0])    # B, G, R planar
     pt.write_image(e, img, "exr", rgba_exr=True)
     assert b"colorspace\x00string\x00" in open(e, "rb").read()
-    with pytest.raises(pt.PtrError, match="PNG output is not available"):
-        pt.write_image(str(tmp_path / "a.png"), img, "png")
+    # PNG: tonemapped RGBA8 + sRGB chunk; decode with zlib and undo the Sub filter
+    import zlib
+    pt.write_image(str(tmp_path / "a.png"), img, "png", tonemap=2, exposure=0.5)
+    raw = (tmp_path / "a.png").read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    chunks, at = [], 8
+    while at < len(raw):
+        n = struct.unpack(">I", raw[at:at + 4])[0]
+        kind, data = raw[at + 4:at + 8], raw[at + 8:at + 8 + n]
+        assert struct.unpack(">I", raw[at + 8 + n:at + 12 + n])[0] == zlib.crc32(kind + data)
+        chunks.append((kind, data))
+        at += 12 + n
+    assert [k for k, _ in chunks] == [b"IHDR", b"sRGB", b"IDAT", b"IEND"]
+    w_, h_, depth, ctype = struct.unpack(">IIBB", chunks[0][1][:10])
+    assert (w_, h_, depth, ctype) == (img.shape[1], img.shape[0], 8, 6)
+    rows = np.frombuffer(zlib.decompress(chunks[2][1]), np.uint8).reshape(h_, 1 + 4 * w_)
+    assert (rows[:, 0] == 1).all()
+    px = np.cumsum(rows[:, 1:].reshape(h_, w_, 4).astype(np.uint32), axis=1).astype(np.uint8)     # Sub filter: prefix sums mod 256
+    pt.write_image(str(tmp_path / "b.ppm"), img, "ppm", tonemap=2, exposure=0.5)
+    ppm = (tmp_path / "b.ppm").read_bytes()
+    ldr = np.frombuffer(ppm[ppm.index(b"255\n") + 4:], np.uint8).reshape(h_, w_, 3)
+    assert np.array_equal(px[..., :3], ldr) and (px[..., 3] == 255).all()
+    # a large smooth image compresses (LZ77 + fixed Huffman), and still round-trips
+    big = np.linspace(0, 1, 256 * 192 * 3, dtype=np.float32).reshape(192, 256, 3) ** 3
+    pt.write_image(str(tmp_path / "big.png"), big, "png")
+    rawb = (tmp_path / "big.png").read_bytes()
+    assert len(rawb) < 0.5 * 192 * 256 * 4
+    idat = rawb[rawb.index(b"IDAT") + 4:rawb.index(b"IEND") - 8]
+    assert len(zlib.decompress(idat)) == 192 * (1 + 4 * 256)
+    # multilayer EXR: B,G,R,A + planar SAMPLES
+    counts = np.arange(img.shape[0] * img.shape[1], dtype=np.float32).reshape(img.shape[:2])
+    pt.write_exr_multilayer(str(tmp_path / "m.exr"), img, counts)
+    data = (tmp_path / "m.exr").read_bytes()
+    names = [n for n in (b"A\x00", b"B\x00", b"G\x00", b"R\x00", b"SAMPLES\x00") if n in data[:400]]
+    assert len(names) == 5
+    h0, w0 = img.shape[:2]
+    body = np.frombuffer(data[-(h0 * (8 + 5 * w0 * 4)):], np.uint8).reshape(h0, 8 + 5 * w0 * 4)
+    planes = body[:, 8:].copy().view(np.float32).reshape(h0, 5, w0)
+    assert np.array_equal(planes[:, 4], counts) and np.array_equal(planes[:, 2], img[..., 0]) and (planes[:, 3] == 1.0).all()
 
 
 # --------------------------------------------------------------------------- CLI surface
@@ -458,6 +495,25 @@ def test_cli_flag_surface():
     assert r.returncode == 1 and "Failed to load scene" in r.stderr
     if pt.device_count() == 0:
         r = subprocess.run([exe, "--scene", os.path.join(GOLDEN, "smoke.scene"), "--sppTotal=1"], capture_output=True, text=True)
+        assert r.returncode == 1 and "Render failed" in r.stderr
+
+
+def test_cli_scene_identifiers_and_catalogue(tmp_path):
+    # `--scene=<identifier>` is looked up among the *.scene files of <cwd>/assets; failures list the catalogue
+    # sorted by display name (first `#` comment line, else the file stem)
+    exe = pt.CLI_PATH
+    assets = tmp_path / "assets"
+    assets.mkdir()
+    (assets / "alpha.scene").write_text("# Zebra room\nmaterial type=lambert\nsphere center=0,0,0 radius=1 material=0\n")
+    (assets / "beta.scene").write_text("material type=lambert\n")
+    (assets / "notes.txt").write_text("ignored")
+    r = subprocess.run([exe, "--scene=gamma"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 1 and "Unknown scene identifier: gamma" in r.stderr
+    listing = r.stderr[r.stderr.index("Available scenes:"):].split()
+    assert listing[2:4] == ["alpha", "beta"]          # by display name: "Zebra room" < "beta" (byte order)
+    r = subprocess.run([exe, "--scene=alpha", "--sppTotal=1", "--output", str(tmp_path / "o.pfm")], capture_output=True, text=True, cwd=tmp_path)
+    assert "Unknown scene identifier" not in r.stderr and "Failed to load scene" not in r.stderr
+    if pt.device_count() == 0:
         assert r.returncode == 1 and "Render failed" in r.stderr
 
 
