@@ -211,7 +211,8 @@ int ptr_render(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t 
  * ptr_part_band_count(height, part_index, part_count)*16*width*3 floats.
  * `stream` is a hipStream_t (NULL = default stream).  Asynchronous unless
  * stats != NULL (stats need a stream sync to read event timers / counters).
- * count_traversal != 0 selects the counting build of the same kernels.
+ * count_traversal: bit 0 selects the counting build of the same kernels; bit 1 runs the path-slot pool as a single
+ * group on the caller's stream (no concurrent kernels: clean per-kernel timings for profiling).
  */
 int ptr_render_bands_device(PtrDeviceScene* scene, const PtrSettings* settings, uint32_t spp,
                             uint32_t part_index, uint32_t part_count, void* d_out_rgb, void* stream,

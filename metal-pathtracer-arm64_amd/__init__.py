@@ -358,13 +358,15 @@ class DeviceScene:
         return out[: settings.height], stats
 
     def render_device(self, settings: PtrSettings, spp: int, d_out_ptr: int, stream: int = 0, part: int = 0,
-                      parts: int = 1, count: bool = False, want_stats: bool = True) -> Optional[PtrRenderStats]:
-        """Render into a caller-owned DEVICE buffer (e.g. a torch tensor's data_ptr()) on `stream`."""
+                      parts: int = 1, count: bool = False, want_stats: bool = True, solo: bool = False
+                      ) -> Optional[PtrRenderStats]:
+        """Render into a caller-owned DEVICE buffer (e.g. a torch tensor's data_ptr()) on `stream`.
+        solo=True runs the pool as one group (no concurrent kernels) so per-kernel timings are clean."""
         lib = load_library()
         stats = PtrRenderStats()
         err = _err_buf()
         _check(lib.ptr_render_bands_device(self._h, C.byref(settings), spp, part, parts, C.c_void_p(d_out_ptr),
-                                           C.c_void_p(stream), int(count), C.byref(stats) if want_stats else None,
+                                           C.c_void_p(stream), int(count) | (2 if solo else 0), C.byref(stats) if want_stats else None,
                                            err, len(err)), err)
         return stats if want_stats else None
 

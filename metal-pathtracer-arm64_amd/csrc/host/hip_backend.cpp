@@ -103,7 +103,10 @@ struct PtrDeviceScene {
 
     // render-time resources, grown on demand and kept across calls
     DeviceBuffer<float4> rayOrg, rayDir, hit, throughput, accum, recBuf, itemAccum;
-    uint64_t poolSlots = 8ull << 20;
+    uint64_t poolSlots = 16ull << 20;
+    uint32_t poolGroups = 4;   // the pool is split into this many independent groups, one HIP stream each
+    std::vector<hipStream_t> groupStreams;   // streams of groups 1.. (group 0 runs on the caller's stream)
+    std::vector<hipEvent_t> groupEvents;
     int refillBelow = 40;
     DeviceBuffer<uint4> state;
     DeviceBuffer<uint32_t> scalars, pixelOfLocal, spill;
@@ -119,6 +122,8 @@ struct PtrDeviceScene {
 
     ~PtrDeviceScene() {
         if (pinnedAlive) (void)hipHostFree(pinnedAlive);
+        for (hipStream_t st : groupStreams) (void)hipStreamDestroy(st);
+        for (hipEvent_t e : groupEvents) (void)hipEventDestroy(e);
     }
 };
 
@@ -130,6 +135,7 @@ constexpr uint32_t kAliveRing = 16;
 constexpr uint32_t kAliveBase = 4;
 constexpr uint32_t kNextItemIndex = kAliveBase + kAliveRing;
 constexpr uint32_t kScalarCount = kNextItemIndex + 1;
+constexpr uint32_t kMaxPoolGroups = 8;   // one block of scalars / one spill area per group
 
 // 576 B MaterialData -> the 12 float4 the integrator reads (kernels/device_types.h MaterialSlot).
 void compactMaterial(const PtrMaterial& m, std::vector<float>& out) {
@@ -264,10 +270,14 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
         const unsigned long long v = std::strtoull(e, nullptr, 10);
         if (v >= 1024) ds.poolSlots = v;
     }
-    ds.spill.ensure(static_cast<size_t>(kTraversalStackDepth - kLdsStackLevels) * ds.traceGrid * kTraceBlock);
-    ds.scalars.ensure(kScalarCount);
+    if (const char* e = std::getenv("PTR_POOL_GROUPS")) {   // tuning knob: concurrent pool groups (1 = single stream)
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= static_cast<int>(kMaxPoolGroups)) ds.poolGroups = static_cast<uint32_t>(v);
+    }
+    ds.spill.ensure(static_cast<size_t>(kTraversalStackDepth - kLdsStackLevels) * ds.traceGrid * kTraceBlock * kMaxPoolGroups);
+    ds.scalars.ensure(static_cast<size_t>(kScalarCount) * kMaxPoolGroups);
     ds.counters.ensure(kCounterSlots);
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ds.pinnedAlive), sizeof(uint32_t) * 4, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ds.pinnedAlive), sizeof(uint32_t) * 8, hipHostMallocDefault));
     ds.uploadSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
@@ -369,7 +379,9 @@ struct EventTimer {
 };
 
 void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, uint32_t part, uint32_t parts, float* dOut,
-                 hipStream_t stream, bool count, PtrRenderStats* stats) {
+                 hipStream_t stream, int mode, PtrRenderStats* stats) {
+    const bool count = (mode & 1) != 0;         // counting instantiation of the kernels
+    const bool soloGroup = (mode & 2) != 0;     // one pool group: kernels run alone, for clean per-kernel timings
     if (settings.width == 0 || settings.height == 0) throw HipError{"render size must be non-zero"};
     if (parts == 0 || part >= parts) throw HipError{"bad partition"};
     HIP_CHECK(hipSetDevice(ds.device));
@@ -440,8 +452,59 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     pool.pixelOfLocal = ds.pixelOfLocal.ptr;
     pool.counters = ds.counters.ptr;
     pool.slots = slots;
+    pool.recStride = slots;
 
-    LaunchConfig cfg{ds.traceGrid, ds.spill.ptr, ds.scalars.ptr + 1, ds.refillBelow};
+    // The pool is cut into independent groups, each driven through extend -> shade -> connect on its own HIP
+    // stream.  Every launch of the persistent traversal kernels ends with a drain phase (the last rays of the
+    // last chunks, few lanes busy); with two groups in flight the other group's kernels fill the CUs a draining
+    // kernel leaves idle.  Groups share only the work-item head (one atomic per 64 items), so results do not
+    // depend on how they interleave.
+    struct Group {
+        PathPool pool;
+        LaunchConfig cfg;
+        hipStream_t stream;
+        uint32_t* scalars;
+        bool done;
+    };
+    uint32_t groupCount = std::min<uint32_t>(soloGroup ? 1u : ds.poolGroups, std::max<uint32_t>(1u, slots >> 20));   // >= 1 Mi slots per group
+    const uint32_t groupSlots = ((slots + groupCount - 1u) / groupCount + 255u) & ~255u;
+    groupCount = (slots + groupSlots - 1u) / groupSlots;
+    while (ds.groupStreams.size() + 1 < groupCount) {
+        hipStream_t st;
+        HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        ds.groupStreams.push_back(st);
+    }
+    while (ds.groupEvents.size() < groupCount + 1) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ds.groupEvents.push_back(e);
+    }
+    const size_t spillWords = static_cast<size_t>(kTraversalStackDepth - kLdsStackLevels) * ds.traceGrid * kTraceBlock;
+    std::vector<Group> groups(groupCount);
+    for (uint32_t g = 0; g < groupCount; ++g) {
+        Group& gr = groups[g];
+        const uint32_t first = g * groupSlots;
+        gr.pool = pool;
+        gr.pool.rayOrg += first;
+        gr.pool.rayDir += first;
+        gr.pool.hit += first;
+        gr.pool.throughput += first;
+        gr.pool.accum += first;
+        gr.pool.state += first;
+        for (uint32_t k = 0; k < kRecSlots; ++k) {
+            gr.pool.rec[k].org += first;
+            gr.pool.rec[k].dir += first;
+            gr.pool.rec[k].a += first;
+            gr.pool.rec[k].b += first;
+        }
+        gr.pool.itemReserve += first / 64u;
+        gr.pool.slots = std::min(groupSlots, slots - first);
+        gr.scalars = ds.scalars.ptr + static_cast<size_t>(g) * kScalarCount;
+        gr.pool.aliveCount = gr.scalars + kAliveBase;
+        gr.cfg = LaunchConfig{ds.traceGrid, ds.spill.ptr + g * spillWords, gr.scalars + 1, ds.refillBelow};
+        gr.stream = g == 0 ? stream : ds.groupStreams[g - 1];
+        gr.done = false;
+    }
 
     const bool timed = stats != nullptr;
     EventTimer timer;
@@ -450,12 +513,12 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
         int kind;
     };
     std::vector<Span> spans;
-    auto timedLaunch = [&](int kind, auto&& fn) {
+    auto timedLaunch = [&](int kind, hipStream_t st, auto&& fn) {
         if (timed) {
             const hipEvent_t a = timer.next(), b = timer.next();
-            HIP_CHECK(hipEventRecord(a, stream));
+            HIP_CHECK(hipEventRecord(a, st));
             fn();
-            HIP_CHECK(hipEventRecord(b, stream));
+            HIP_CHECK(hipEventRecord(b, st));
             spans.push_back({a, b, kind});
         } else {
             fn();
@@ -463,39 +526,61 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     };
 
     if (count) HIP_CHECK(hipMemsetAsync(ds.counters.ptr, 0, sizeof(uint64_t) * kCounterSlots, stream));
-    HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * kScalarCount, stream));
+    HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * kScalarCount * kMaxPoolGroups, stream));
     HIP_CHECK(hipMemcpyAsync(pool.nextItem, &slots, sizeof(uint32_t), hipMemcpyHostToDevice, stream));   // items 0..slots-1 are pre-assigned
     HIP_CHECK(hipMemsetAsync(ds.itemReserve.ptr, 0, sizeof(uint2) * ((slots + 63u) / 64u), stream));
     if (rp.maxDepth == 0) HIP_CHECK(hipMemsetAsync(ds.itemAccum.ptr, 0, sizeof(float4) * rp.itemCount, stream));
 
     const auto wall0 = std::chrono::steady_clock::now();
     launchGenerate(rp, pool, stream);
+    HIP_CHECK(hipEventRecord(ds.groupEvents[0], stream));
+    for (uint32_t g = 1; g < groupCount; ++g) HIP_CHECK(hipStreamWaitEvent(groups[g].stream, ds.groupEvents[0], 0));
     uint64_t iterations = 0;
     // Worst case: every sample runs maxDepth bounces in sequence on its slot.
     const uint64_t maxIterations = static_cast<uint64_t>(rp.maxDepth) * ((itemCount64 + slots - 1) / slots + 1) * chunkSize + 8;
     const uint32_t checkEvery = 4;
     // Phase 1: while unclaimed work items remain nobody needs to count survivors; the host only peeks at the
-    // item head every few bounces.  Phase 2 (queue dry): k_shade counts live slots so the loop can stop.
+    // item head every few bounces.  Phase 2 (queue dry): k_shade counts live slots so each group can stop.
     bool queueDry = false;
     while (rp.maxDepth > 0) {
         const uint32_t ring = static_cast<uint32_t>(iterations % kAliveRing);
-        uint32_t* aliveSlot = ds.scalars.ptr + kAliveBase + ring;
-        HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * 3, stream));  // work heads of k_extend / k_connect
-        if (queueDry) HIP_CHECK(hipMemsetAsync(aliveSlot, 0, sizeof(uint32_t), stream));
-        timedLaunch(0, [&] { launchExtend(ds.view, pool, cfg, count, stream); });
-        timedLaunch(1, [&] { launchShade(rp, ds.view, pool, aliveSlot, queueDry, count, stream); });
-        timedLaunch(2, [&] { launchConnect(rp, ds.view, pool, cfg, count, stream); });
+        for (Group& gr : groups) {
+            if (gr.done) continue;
+            uint32_t* aliveSlot = gr.scalars + kAliveBase + ring;
+            HIP_CHECK(hipMemsetAsync(gr.scalars, 0, sizeof(uint32_t) * 3, gr.stream));  // work heads of k_extend / k_connect
+            if (queueDry) HIP_CHECK(hipMemsetAsync(aliveSlot, 0, sizeof(uint32_t), gr.stream));
+            timedLaunch(0, gr.stream, [&] { launchExtend(ds.view, gr.pool, gr.cfg, count, gr.stream); });
+            timedLaunch(1, gr.stream, [&] { launchShade(rp, ds.view, gr.pool, aliveSlot, queueDry, count, gr.stream); });
+            timedLaunch(2, gr.stream, [&] { launchConnect(rp, ds.view, gr.pool, gr.cfg, count, gr.stream); });
+        }
         ++iterations;
         if (iterations % checkEvery == 0 || iterations >= maxIterations) {
-            HIP_CHECK(hipMemcpyAsync(ds.pinnedAlive, queueDry ? aliveSlot : pool.nextItem, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
-            if (queueDry) {
-                if (ds.pinnedAlive[0] == 0u) break;
-            } else if (ds.pinnedAlive[0] >= rp.itemCount) {
-                queueDry = true;
+            for (uint32_t g = 0; g < groupCount; ++g) {
+                Group& gr = groups[g];
+                if (gr.done) continue;
+                const uint32_t* src = queueDry ? gr.scalars + kAliveBase + ring : pool.nextItem;
+                HIP_CHECK(hipMemcpyAsync(ds.pinnedAlive + g, src, sizeof(uint32_t), hipMemcpyDeviceToHost, gr.stream));
             }
+            bool allDone = true, nowDry = false;
+            for (uint32_t g = 0; g < groupCount; ++g) {
+                Group& gr = groups[g];
+                if (gr.done) continue;
+                HIP_CHECK(hipStreamSynchronize(gr.stream));
+                if (queueDry) {
+                    if (ds.pinnedAlive[g] == 0u) gr.done = true;
+                } else if (ds.pinnedAlive[g] >= rp.itemCount) {
+                    nowDry = true;
+                }
+                allDone = allDone && gr.done;
+            }
+            if (allDone) break;
+            if (nowDry) queueDry = true;
             if (iterations >= maxIterations) throw HipError{"wavefront loop did not terminate"};
         }
+    }
+    for (uint32_t g = 1; g < groupCount; ++g) {
+        HIP_CHECK(hipEventRecord(ds.groupEvents[g], groups[g].stream));
+        HIP_CHECK(hipStreamWaitEvent(stream, ds.groupEvents[g], 0));
     }
     launchResolve(rp, pool, parts, dOut, stream);
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -594,7 +679,7 @@ int ptr_render_bands_device(PtrDeviceScene* scene, const PtrSettings* settings, 
     }
     try {
         renderBands(*scene, *settings, spp, part_index, part_count, static_cast<float*>(d_out_rgb),
-                    static_cast<hipStream_t>(stream), count_traversal != 0, stats);
+                    static_cast<hipStream_t>(stream), count_traversal, stats);
         return 0;
     } catch (const HipError& e) {
         setErr(err, err_cap, e.message);
@@ -613,7 +698,7 @@ int ptr_render_bands(PtrDeviceScene* scene, const PtrSettings* settings, uint32_
         const size_t floats = static_cast<size_t>(ptr_part_band_count(settings->height, part_index, part_count)) * 16u * settings->width * 3u;
         HIP_CHECK(hipSetDevice(scene->device));
         scene->outBands.ensure(floats);
-        renderBands(*scene, *settings, spp, part_index, part_count, scene->outBands.ptr, nullptr, count_traversal != 0, stats);
+        renderBands(*scene, *settings, spp, part_index, part_count, scene->outBands.ptr, nullptr, count_traversal, stats);
         HIP_CHECK(hipMemcpy(out_rgb_bands, scene->outBands.ptr, floats * sizeof(float), hipMemcpyDeviceToHost));
         return 0;
     } catch (const HipError& e) {

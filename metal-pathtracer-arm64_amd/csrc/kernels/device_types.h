@@ -122,7 +122,8 @@ struct PathPool {
     uint32_t* aliveCount;      // ring of alive counters (host termination check)
     const uint32_t* pixelOfLocal;  // local pixel -> y*width + x
     uint64_t* counters;        // kCounterSlots
-    uint32_t slots;
+    uint32_t slots;            // slots of this pool (or of this group of the pool)
+    uint32_t recStride;        // slots of the WHOLE pool: distance between the fields / record slots of `rec`
 };
 
 // flags word

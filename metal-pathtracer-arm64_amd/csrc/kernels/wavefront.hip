@@ -433,8 +433,14 @@ __global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool p
 // =====================================================================================================
 // k_shade
 // =====================================================================================================
+// 5 waves/SIMD (<= 96 VGPRs, a handful of spills in the cold material branches) measured best: the compiler's own
+// choice of 121 VGPRs / 4 waves was 10 % slower, 6 and 8 waves spill into the hot path (132 / 167 ms vs 105 ms).
+#ifndef PTR_SHADE_WAVES
+#define PTR_SHADE_WAVES 5
+#endif
+#define PTR_SHADE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PTR_SHADE_WAVES, PTR_SHADE_WAVES)))
 template <bool COUNT>
-__global__ void __launch_bounds__(kShadeBlock) k_shade(RenderParams rp, SceneView sc, PathPool pool, uint32_t* aliveSlot, uint32_t countAlive) {
+__global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(RenderParams rp, SceneView sc, PathPool pool, uint32_t* aliveSlot, uint32_t countAlive) {
     const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x;
     const bool inRange = slot < pool.slots;
     uint4 st = inRange ? pool.state[slot] : make_uint4(0u, 0u, 0u, 0u);
@@ -894,7 +900,7 @@ __global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_e
     uint32_t mySlot = 0u, bits = 0u;
     // the record arrays are one allocation: field f of record slot k lives at recBase[(k*4 + f)*slots + slot]
     float4* const recBase = pool.rec[0].org;
-    const uint32_t slots = pool.slots;
+    const uint32_t slots = pool.recStride;   // field stride (whole pool), not the slot count of this group
     uint32_t myRecAt = 0u;   // (record*4)*slots + slot of the record this lane is resolving
     while (true) {
         const int nActive = __popcll(__ballot(active));
