@@ -410,7 +410,22 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
 
     // Work items = (pixel, chunk of C consecutive samples).  Slots claim items from a global counter, so the
     // pool stays full until the last chunks regardless of how path length varies over the image.
-    const uint32_t chunkSize = rp.spp >= 128 ? 4u : (rp.spp >= 16 ? 2u : 1u);
+    // Chunk size 1 keeps the end-of-frame tail short (once the item queue is dry every slot still finishes its item:
+    // C samples x up to maxDepth bounces at falling occupancy; C = 4 cost 12 % on config 2).  Each item owns a 16 B
+    // accumulator, so C grows only when one accumulator per sample would not fit: at most a quarter of the free
+    // device memory and never more than 16 GiB.
+    uint32_t chunkSize = 1u;
+    {
+        size_t freeBytes = 0, totalBytes = 0;
+        HIP_CHECK(hipMemGetInfo(&freeBytes, &totalBytes));
+        const uint64_t resident = ds.itemAccum.count * sizeof(float4);   // our own previous allocation is reusable
+        const uint64_t budget = std::max<uint64_t>(64ull << 20, std::min<uint64_t>(16ull << 30, (freeBytes + resident) / 4u));
+        const uint64_t perSample = static_cast<uint64_t>(localPixels) * rp.spp;
+        const uint64_t maxItems = std::min<uint64_t>(budget / sizeof(float4), 0xFFFFFFF0ull);
+        chunkSize = static_cast<uint32_t>(std::max<uint64_t>(1u, (perSample + maxItems - 1u) / maxItems));
+        chunkSize = std::min(chunkSize, 255u);   // sample-in-chunk lives in 8 bits of the slot state
+    }
+    if (const char* e = std::getenv("PTR_CHUNK_SIZE")) chunkSize = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 255));   // tuning knob
     rp.chunkSize = chunkSize;
     rp.chunkCount = (rp.spp + chunkSize - 1) / chunkSize;
     rp.localPixels = localPixels;
@@ -538,9 +553,14 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     uint64_t iterations = 0;
     // Worst case: every sample runs maxDepth bounces in sequence on its slot.
     const uint64_t maxIterations = static_cast<uint64_t>(rp.maxDepth) * ((itemCount64 + slots - 1) / slots + 1) * chunkSize + 8;
-    const uint32_t checkEvery = 4;
-    // Phase 1: while unclaimed work items remain nobody needs to count survivors; the host only peeks at the
-    // item head every few bounces.  Phase 2 (queue dry): k_shade counts live slots so each group can stop.
+    // Phase 1: while unclaimed work items remain nobody needs to count survivors; the host looks at the item head
+    // only when it expects it to be nearly exhausted (items are claimed at a steady rate, so after the first look the
+    // next one is scheduled at 3/4 of the predicted remaining iterations).  Phase 2 (queue dry): k_shade counts live
+    // slots and every group is polled every 4 iterations until it has none left.  A poll joins all streams, which
+    // costs the overlap between groups once; polling every 4 iterations throughout was 5 % slower.  (Polling through
+    // events without joining was tried: the host then runs up to a dozen empty iterations past the end - no gain.)
+    constexpr uint64_t kPollEvery = 4;
+    uint64_t nextCheck = kPollEvery;
     bool queueDry = false;
     while (rp.maxDepth > 0) {
         const uint32_t ring = static_cast<uint32_t>(iterations % kAliveRing);
@@ -554,27 +574,37 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
             timedLaunch(2, gr.stream, [&] { launchConnect(rp, ds.view, gr.pool, gr.cfg, count, gr.stream); });
         }
         ++iterations;
-        if (iterations % checkEvery == 0 || iterations >= maxIterations) {
+        if (iterations >= nextCheck || iterations >= maxIterations) {
             for (uint32_t g = 0; g < groupCount; ++g) {
                 Group& gr = groups[g];
                 if (gr.done) continue;
                 const uint32_t* src = queueDry ? gr.scalars + kAliveBase + ring : pool.nextItem;
                 HIP_CHECK(hipMemcpyAsync(ds.pinnedAlive + g, src, sizeof(uint32_t), hipMemcpyDeviceToHost, gr.stream));
             }
-            bool allDone = true, nowDry = false;
+            bool allDone = true;
+            uint32_t head = 0;
             for (uint32_t g = 0; g < groupCount; ++g) {
                 Group& gr = groups[g];
                 if (gr.done) continue;
                 HIP_CHECK(hipStreamSynchronize(gr.stream));
                 if (queueDry) {
                     if (ds.pinnedAlive[g] == 0u) gr.done = true;
-                } else if (ds.pinnedAlive[g] >= rp.itemCount) {
-                    nowDry = true;
+                } else {
+                    head = std::max(head, ds.pinnedAlive[g]);
                 }
                 allDone = allDone && gr.done;
             }
             if (allDone) break;
-            if (nowDry) queueDry = true;
+            nextCheck = iterations + kPollEvery;
+            if (!queueDry) {
+                if (head >= rp.itemCount) {
+                    queueDry = true;
+                } else if (head > slots) {
+                    const double perIteration = static_cast<double>(head - slots) / static_cast<double>(iterations);
+                    const double left = static_cast<double>(rp.itemCount - head) / std::max(perIteration, 1.0);
+                    nextCheck = iterations + std::max<uint64_t>(kPollEvery, static_cast<uint64_t>(left * 0.75));
+                }
+            }
             if (iterations >= maxIterations) throw HipError{"wavefront loop did not terminate"};
         }
     }
