@@ -104,13 +104,15 @@ struct PtrDeviceScene {
     // render-time resources, grown on demand and kept across calls
     DeviceBuffer<float4> rayOrg, rayDir, hit, throughput, accum, recBuf, itemAccum;
     uint64_t poolSlots = 16ull << 20;
-    uint32_t poolGroups = 4;   // the pool is split into this many independent groups, one HIP stream each
+    uint32_t poolGroups = 4;
+    uint32_t feederChunk = 256, feederChunkSparse = 2048;   // slots per work-head atomic: full pool / mostly dead pool   // the pool is split into this many independent groups, one HIP stream each
     std::vector<hipStream_t> groupStreams;   // streams of groups 1.. (group 0 runs on the caller's stream)
     std::vector<hipEvent_t> groupEvents;
     int refillBelow = 40;
     DeviceBuffer<uint4> state;
     DeviceBuffer<uint32_t> scalars, pixelOfLocal, spill;
     DeviceBuffer<uint2> itemReserve;
+    DeviceBuffer<uint32_t> itemHeads;
     DeviceBuffer<uint64_t> counters;
     DeviceBuffer<float> outBands;
     DeviceBuffer<float4> rayBatch;
@@ -135,7 +137,8 @@ constexpr uint32_t kAliveRing = 16;
 constexpr uint32_t kAliveBase = 4;
 constexpr uint32_t kNextItemIndex = kAliveBase + kAliveRing;
 constexpr uint32_t kScalarCount = kNextItemIndex + 1;
-constexpr uint32_t kMaxPoolGroups = 8;   // one block of scalars / one spill area per group
+constexpr uint32_t kMaxPoolGroups = 8;
+constexpr uint32_t kPinnedHeadsOffset = 16;   // pinned staging: [0..15] per-group alive counts, then kItemHeads range heads   // one block of scalars / one spill area per group
 
 // 576 B MaterialData -> the 12 float4 the integrator reads (kernels/device_types.h MaterialSlot).
 void compactMaterial(const PtrMaterial& m, std::vector<float>& out) {
@@ -270,6 +273,8 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
         const unsigned long long v = std::strtoull(e, nullptr, 10);
         if (v >= 1024) ds.poolSlots = v;
     }
+    if (const char* e = std::getenv("PTR_FEEDER_CHUNK")) ds.feederChunk = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 64), 1 << 16));
+    if (const char* e = std::getenv("PTR_FEEDER_CHUNK_SPARSE")) ds.feederChunkSparse = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 64), 1 << 16));
     if (const char* e = std::getenv("PTR_POOL_GROUPS")) {   // tuning knob: concurrent pool groups (1 = single stream)
         const int v = std::atoi(e);
         if (v >= 1 && v <= static_cast<int>(kMaxPoolGroups)) ds.poolGroups = static_cast<uint32_t>(v);
@@ -277,7 +282,7 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     ds.spill.ensure(static_cast<size_t>(kTraversalStackDepth - kLdsStackLevels) * ds.traceGrid * kTraceBlock * kMaxPoolGroups);
     ds.scalars.ensure(static_cast<size_t>(kScalarCount) * kMaxPoolGroups);
     ds.counters.ensure(kCounterSlots);
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ds.pinnedAlive), sizeof(uint32_t) * 8, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ds.pinnedAlive), sizeof(uint32_t) * (kPinnedHeadsOffset + kItemHeads), hipHostMallocDefault));
     ds.uploadSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
@@ -430,10 +435,14 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     rp.chunkCount = (rp.spp + chunkSize - 1) / chunkSize;
     rp.localPixels = localPixels;
     const uint64_t itemCount64 = static_cast<uint64_t>(localPixels) * rp.chunkCount;
-    if (itemCount64 > 0xFFFFFFF0ull) throw HipError{"too many work items (reduce spp or resolution)"};
+    if (itemCount64 > 0xFFFF0000ull) throw HipError{"too many work items (reduce spp or resolution)"};
     rp.itemCount = static_cast<uint32_t>(itemCount64);
     const uint64_t targetSlots = ds.poolSlots;   // enough to keep every CU's wave slots full several times over
-    const uint32_t slots = static_cast<uint32_t>(std::min<uint64_t>(targetSlots, itemCount64));
+    uint32_t slots = static_cast<uint32_t>(std::min<uint64_t>(targetSlots, itemCount64));
+    if (slots < itemCount64) slots &= ~255u;   // item ranges start right after the pre-assigned items: keep them 64-aligned
+    // items [0, slots) are pre-assigned by k_generate; the rest is split into kItemHeads ranges with one head each
+    rp.itemHeadFirst = slots;
+    rp.itemsPerHead = static_cast<uint32_t>(((itemCount64 - slots + kItemHeads - 1u) / kItemHeads + 63u) & ~63ull);
 
     ds.rayOrg.ensure(slots);
     ds.rayDir.ensure(slots);
@@ -454,7 +463,8 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     pool.accum = ds.accum.ptr;
     pool.state = ds.state.ptr;
     pool.itemAccum = ds.itemAccum.ptr;
-    pool.nextItem = ds.scalars.ptr + kNextItemIndex;
+    ds.itemHeads.ensure(kItemHeadWords);
+    pool.nextItem = ds.itemHeads.ptr;
     for (uint32_t k = 0; k < kRecSlots; ++k) {
         float4* base = ds.recBuf.ptr + static_cast<size_t>(k) * 4u * slots;
         pool.rec[k].org = base;
@@ -480,6 +490,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
         hipStream_t stream;
         uint32_t* scalars;
         bool done;
+        bool sparse;   // few live slots left (end of the frame)
     };
     uint32_t groupCount = std::min<uint32_t>(soloGroup ? 1u : ds.poolGroups, std::max<uint32_t>(1u, slots >> 20));   // >= 1 Mi slots per group
     const uint32_t groupSlots = ((slots + groupCount - 1u) / groupCount + 255u) & ~255u;
@@ -519,6 +530,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
         gr.cfg = LaunchConfig{ds.traceGrid, ds.spill.ptr + g * spillWords, gr.scalars + 1, ds.refillBelow};
         gr.stream = g == 0 ? stream : ds.groupStreams[g - 1];
         gr.done = false;
+        gr.sparse = false;
     }
 
     const bool timed = stats != nullptr;
@@ -542,7 +554,16 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
 
     if (count) HIP_CHECK(hipMemsetAsync(ds.counters.ptr, 0, sizeof(uint64_t) * kCounterSlots, stream));
     HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * kScalarCount * kMaxPoolGroups, stream));
-    HIP_CHECK(hipMemcpyAsync(pool.nextItem, &slots, sizeof(uint32_t), hipMemcpyHostToDevice, stream));   // items 0..slots-1 are pre-assigned
+    {
+        uint32_t* heads = ds.pinnedAlive + kPinnedHeadsOffset;
+        for (uint32_t k = 0; k < kItemHeads; ++k) {
+            heads[k] = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(rp.itemHeadFirst) + static_cast<uint64_t>(k) * rp.itemsPerHead, rp.itemCount));
+        }
+        HIP_CHECK(hipMemsetAsync(pool.nextItem, 0, sizeof(uint32_t) * kItemHeadWords, stream));
+        HIP_CHECK(hipMemcpy2DAsync(pool.nextItem, sizeof(uint32_t) * kItemHeadStride, heads, sizeof(uint32_t), sizeof(uint32_t), kItemHeads,
+                                   hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));   // the pinned staging area is reused by the polls below
+    }
     HIP_CHECK(hipMemsetAsync(ds.itemReserve.ptr, 0, sizeof(uint2) * ((slots + 63u) / 64u), stream));
     if (rp.maxDepth == 0) HIP_CHECK(hipMemsetAsync(ds.itemAccum.ptr, 0, sizeof(float4) * rp.itemCount, stream));
 
@@ -567,6 +588,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
         for (Group& gr : groups) {
             if (gr.done) continue;
             uint32_t* aliveSlot = gr.scalars + kAliveBase + ring;
+            gr.cfg.feederChunk = gr.sparse ? ds.feederChunkSparse : ds.feederChunk;
             HIP_CHECK(hipMemsetAsync(gr.scalars, 0, sizeof(uint32_t) * 3, gr.stream));  // work heads of k_extend / k_connect
             if (queueDry) HIP_CHECK(hipMemsetAsync(aliveSlot, 0, sizeof(uint32_t), gr.stream));
             timedLaunch(0, gr.stream, [&] { launchExtend(ds.view, gr.pool, gr.cfg, count, gr.stream); });
@@ -575,24 +597,38 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
         }
         ++iterations;
         if (iterations >= nextCheck || iterations >= maxIterations) {
+            bool headsCopied = false;
             for (uint32_t g = 0; g < groupCount; ++g) {
                 Group& gr = groups[g];
                 if (gr.done) continue;
-                const uint32_t* src = queueDry ? gr.scalars + kAliveBase + ring : pool.nextItem;
-                HIP_CHECK(hipMemcpyAsync(ds.pinnedAlive + g, src, sizeof(uint32_t), hipMemcpyDeviceToHost, gr.stream));
+                if (queueDry) {
+                    HIP_CHECK(hipMemcpyAsync(ds.pinnedAlive + g, gr.scalars + kAliveBase + ring, sizeof(uint32_t), hipMemcpyDeviceToHost, gr.stream));
+                } else if (!headsCopied) {
+                    HIP_CHECK(hipMemcpy2DAsync(ds.pinnedAlive + kPinnedHeadsOffset, sizeof(uint32_t), pool.nextItem,
+                                               sizeof(uint32_t) * kItemHeadStride, sizeof(uint32_t), kItemHeads, hipMemcpyDeviceToHost, gr.stream));
+                    headsCopied = true;
+                }
             }
             bool allDone = true;
-            uint32_t head = 0;
             for (uint32_t g = 0; g < groupCount; ++g) {
                 Group& gr = groups[g];
                 if (gr.done) continue;
                 HIP_CHECK(hipStreamSynchronize(gr.stream));
                 if (queueDry) {
                     if (ds.pinnedAlive[g] == 0u) gr.done = true;
-                } else {
-                    head = std::max(head, ds.pinnedAlive[g]);
+                    // fewer than 1 live slot in 8: claim the work list in bigger chunks (see WaveFeeder)
+                    gr.sparse = ds.pinnedAlive[g] < gr.pool.slots / 8u;
                 }
                 allDone = allDone && gr.done;
+            }
+            uint64_t head = slots;   // items claimed so far = pre-assigned + what every range head has handed out
+            if (!queueDry) {
+                const uint32_t* heads = ds.pinnedAlive + kPinnedHeadsOffset;
+                for (uint32_t k = 0; k < kItemHeads; ++k) {
+                    const uint64_t lo = std::min<uint64_t>(static_cast<uint64_t>(rp.itemHeadFirst) + static_cast<uint64_t>(k) * rp.itemsPerHead, rp.itemCount);
+                    const uint64_t hi = std::min<uint64_t>(lo + rp.itemsPerHead, rp.itemCount);
+                    head += std::min<uint64_t>(std::max<uint64_t>(heads[k], lo), hi) - lo;
+                }
             }
             if (allDone) break;
             nextCheck = iterations + kPollEvery;
@@ -622,6 +658,14 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
         stats->avgMsPerSample = seconds * 1000.0 / rp.spp;
         stats->uploadSeconds = ds.uploadSeconds;
         stats->samples = static_cast<uint64_t>(localPixels) * rp.spp;
+        if (std::getenv("PTR_TRACE_ITERATIONS") && !spans.empty()) {   // debugging aid: when each launch ran (ms from the first)
+            for (const Span& s : spans) {
+                float t0 = 0.0f, t1 = 0.0f;
+                HIP_CHECK(hipEventElapsedTime(&t0, spans.front().a, s.a));
+                HIP_CHECK(hipEventElapsedTime(&t1, spans.front().a, s.b));
+                std::fprintf(stderr, "[launch] kind %d  start %.3f  end %.3f  (%.3f ms)\n", s.kind, t0, t1, t1 - t0);
+            }
+        }
         for (const Span& s : spans) {
             float ms = 0.0f;
             HIP_CHECK(hipEventElapsedTime(&ms, s.a, s.b));

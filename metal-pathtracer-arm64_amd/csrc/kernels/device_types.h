@@ -82,6 +82,8 @@ struct RenderParams {
     uint32_t chunkCount;           // ceil(spp / C)
     uint32_t itemCount;            // localPixels * chunkCount; item w = chunk * localPixels + localPixel
     uint32_t localPixels;          // pixels owned by this partition
+    uint32_t itemHeadFirst;        // items below this are pre-assigned to the slots by k_generate
+    uint32_t itemsPerHead;         // the remaining items are split into kItemHeads ranges of this size (multiple of 64)
     uint32_t enableRussianRoulette, enableSpecularNee, enableMnee, enableMneeSecondary;
     uint32_t backgroundMode;
     float backgroundColor[3];
@@ -104,6 +106,13 @@ struct ShadowRecordView {
     float4* b;
 };
 
+// The unclaimed work items are split into kItemHeads contiguous ranges, each with its own head counter, so the
+// per-wave reservations of k_shade spread over 64 addresses (same-address atomics retire at ~88/us chip-wide; with
+// one-sample items a single head was good for 0.76 ms of every k_shade launch).
+constexpr uint32_t kItemHeads = 64u;
+constexpr uint32_t kItemHeadStride = 64u;   // words between two heads (256 B): one cache line / L2 channel each
+constexpr uint32_t kItemHeadWords = kItemHeads * kItemHeadStride + 1u;   // + the "every range is dry" word
+
 // Record slots per path: 0 rect-light NEE, 1 environment NEE, 2 specular-NEE environment,
 // 3 specular-NEE rectangle lights, 4 MNEE two-bounce chain.
 constexpr uint32_t kRecSlots = 5u;
@@ -116,7 +125,7 @@ struct PathPool {
     float4* accum;         // xyz radiance sum of the slot's current work item; w = bits(item to flush)
     uint4* state;          // x rng, y work item, z flags, w = pending mask (bits 0..4) | sample-in-chunk << 8
     float4* itemAccum;     // [itemCount] finished work items (summed per pixel, in chunk order, by k_resolve)
-    uint32_t* nextItem;    // [1] next unclaimed work item
+    uint32_t* nextItem;    // [kItemHeadWords] head k at [k * kItemHeadStride]: next unclaimed item of range k (k_shade)
     ShadowRecordView rec[kRecSlots];
     uint2* itemReserve;        // [slots/64] per-wave reservation {next, end} of work items (one atomic per 64 items)
     uint32_t* aliveCount;      // ring of alive counters (host termination check)

@@ -13,6 +13,7 @@ struct LaunchConfig {
     uint32_t* spill;         // traversal stack spill area: (kTraversalStackDepth-kLdsStackLevels) * traceGrid*kTraceBlock words
     uint32_t* workCounters;  // [2] work-queue heads of k_extend / k_connect, zeroed by the host before each launch
     int refillBelow;         // persistent waves hand out new rays once fewer than this many lanes are traversing
+    uint32_t feederChunk = 256;   // slots a wave claims per atomic on the work head
 };
 
 void launchGenerate(const RenderParams& rp, const PathPool& pool, hipStream_t stream);

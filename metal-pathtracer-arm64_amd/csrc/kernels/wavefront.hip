@@ -74,17 +74,20 @@ __device__ __forceinline__ void addCounter(uint64_t* counters, uint32_t slot, ui
 }
 
 // Hands out work indices [0, total) to the idle lanes of a persistent wave.  The wave owns a chunk of
-// kChunk consecutive indices at a time (one global atomic per chunk); inside a chunk, idle lanes take
+// `chunk` consecutive indices at a time (one global atomic per chunk); inside a chunk, idle lanes take
 // consecutive indices by rank, so neighbouring lanes still load neighbouring path slots.
 struct WaveFeeder {
-    static constexpr uint32_t kChunk = 256u;
     static constexpr uint32_t kNone = 0xFFFFFFFFu;
     uint32_t* counter;
-    uint32_t total, next, end;
+    uint32_t total, next, end, chunk;
     bool exhausted;
-    __device__ __forceinline__ void init(uint32_t* c, uint32_t n) {
+    // chunkSize: 256 while the pool is full; the host passes a larger one once most slots are dead (end of the frame),
+    // because same-address atomics retire at ~88 per microsecond and a 16 Mi-slot pool in 256-slot chunks costs
+    // 0.75 ms per launch in atomics alone, however little work is left
+    __device__ __forceinline__ void init(uint32_t* c, uint32_t n, uint32_t chunkSize) {
         counter = c;
         total = n;
+        chunk = chunkSize;
         next = 0u;
         end = 0u;
         exhausted = (n == 0u);
@@ -95,14 +98,14 @@ struct WaveFeeder {
         if (mask == 0ull || exhausted) return kNone;
         if (next >= end) {
             uint32_t base = 0u;
-            if (laneId() == 0u) base = atomicAdd(counter, kChunk);
+            if (laneId() == 0u) base = atomicAdd(counter, chunk);
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= total) {
                 exhausted = true;
                 return kNone;
             }
             next = base;
-            end = min(base + kChunk, total);
+            end = min(base + chunk, total);
         }
         const uint32_t avail = end - next;
         const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << laneId()) - 1ull)));
@@ -387,7 +390,7 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams rp, PathPool pool
 // =====================================================================================================
 template <bool COUNT>
 __global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride, uint32_t* workCounter,
-                                                         int kRefillBelow) {
+                                                         int kRefillBelow, uint32_t feederChunk) {
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
@@ -400,7 +403,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool p
 
     const SceneMem mem = sceneMem(sc);
     WaveFeeder feeder;
-    feeder.init(workCounter, pool.slots);
+    feeder.init(workCounter, pool.slots, feederChunk);
     Trav t;
     t.cur = 0u;
     bool active = false;
@@ -713,26 +716,56 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
     }
 
     // ---- claim new work items ----
-    // Each wave holds a reservation of kItemReserve consecutive items in HBM and refills it with ONE atomic on
-    // the global head (a per-lane or even per-wave-per-bounce atomic on one address caps at ~88 ops/us chip-wide).
+    // Each wave holds a reservation of kItemReserve consecutive items in HBM and refills it with ONE atomic on one of
+    // kItemHeads range heads (a per-lane or even per-wave-per-bounce atomic on one address caps at ~88 ops/us
+    // chip-wide; so does one shared head once items are single samples).
     {
         const unsigned long long mask = __ballot(needItem);
         if (mask != 0ull) {
             const uint32_t waveId = slot / 64u;     // slot >= pool.slots lanes never need items
             const uint32_t firstLane = static_cast<uint32_t>(__ffsll(static_cast<long long>(mask))) - 1u;
             uint2 res = pool.itemReserve[__builtin_amdgcn_readfirstlane(waveId)];
+            const uint32_t resOld = res.x;
             const uint32_t n = static_cast<uint32_t>(__popcll(mask));
             const uint32_t avail = res.y - res.x;
-            uint32_t newBase = 0u;
+            uint32_t newBase = rp.itemCount, newEnd = rp.itemCount;   // "no items": ids >= itemCount are rejected below
             if (avail < n) {
-                if (laneId() == firstLane) newBase = atomicAdd(pool.nextItem, kItemReserve);
-                newBase = __shfl(newBase, static_cast<int>(firstLane), 64);
+                // The wave keeps drawing from the range of its last reservation (initially range waveId % kItemHeads)
+                // and moves on to the next range when that one is exhausted; a wave that finds all of them exhausted
+                // raises the "dry" word so nobody else has to go round again.  Heads sit kItemHeadStride words apart:
+                // same-LINE atomics serialise just like same-address ones.
+                const uint32_t wid = __builtin_amdgcn_readfirstlane(waveId);
+                uint32_t head = (res.y > rp.itemHeadFirst && rp.itemsPerHead > 0u) ? (res.y - 1u - rp.itemHeadFirst) / rp.itemsPerHead : wid % kItemHeads;
+                head = min(head, kItemHeads - 1u);
+                uint32_t* const dry = pool.nextItem + kItemHeads * kItemHeadStride;
+                bool found = false;
+                if (rp.itemsPerHead > 0u && __builtin_amdgcn_readfirstlane(*dry) == 0u) {
+                    for (uint32_t tries = 0; tries < kItemHeads && !found; ++tries) {
+                        const uint32_t headEnd = min(rp.itemHeadFirst + (head + 1u) * rp.itemsPerHead, rp.itemCount);
+                        uint32_t* const counter = pool.nextItem + head * kItemHeadStride;
+                        uint32_t base = headEnd;
+                        if (laneId() == firstLane && *counter < headEnd) base = atomicAdd(counter, kItemReserve);
+                        base = __shfl(base, static_cast<int>(firstLane), 64);
+                        if (base < headEnd) {
+                            newBase = base;
+                            newEnd = min(base + kItemReserve, headEnd);
+                            found = true;
+                        } else {
+                            head = (head + 1u) % kItemHeads;
+                        }
+                    }
+                    if (!found && laneId() == firstLane) *dry = 1u;
+                }
             }
             const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << laneId()) - 1ull)));
-            const uint32_t item = (rank < avail) ? (res.x + rank) : (newBase + (rank - avail));
+            // lanes beyond the old reservation and the fresh one get no item (id = itemCount): only when every range is
+            // exhausted, or for the last few items of the frame (ranges are multiples of kItemReserve, only the final
+            // one is clipped)
+            const uint32_t fresh = newEnd - newBase;   // 0 when every range is exhausted
+            const uint32_t item = (rank < avail) ? (resOld + rank) : ((rank - avail < fresh) ? newBase + (rank - avail) : rp.itemCount);
             if (avail < n) {
-                res.x = newBase + (n - avail);
-                res.y = newBase + kItemReserve;
+                res.x = newBase + min(n - avail, fresh);
+                res.y = newEnd;
             } else {
                 res.x += n;
             }
@@ -877,7 +910,7 @@ __device__ f3 mneeChain(const RenderParams& rp, const SceneView& sc, const Clamp
 
 template <bool COUNT>
 __global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) k_connect(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride,
-                                                          uint32_t* workCounter, int kRefillBelow) {
+                                                          uint32_t* workCounter, int kRefillBelow, uint32_t feederChunk) {
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
@@ -893,7 +926,7 @@ __global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_e
     // slot's records one after another (no compaction queue -> no hot atomic counter in k_shade).
     const SceneMem mem = sceneMem(sc);
     WaveFeeder feeder;
-    feeder.init(workCounter, pool.slots);
+    feeder.init(workCounter, pool.slots, feederChunk);
     Trav t;
     t.cur = 0u;
     bool active = false;
@@ -1145,9 +1178,9 @@ void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig&
     const uint32_t stride = cfg.traceGrid * kTraceBlock;
     const uint32_t grid = std::min(cfg.traceGrid, ceilDiv(pool.slots, kTraceBlock));
     if (count) {
-        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters, cfg.refillBelow);
+        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters, cfg.refillBelow, cfg.feederChunk);
     } else {
-        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters, cfg.refillBelow);
+        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters, cfg.refillBelow, cfg.feederChunk);
     }
 }
 
@@ -1165,9 +1198,9 @@ void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& po
 void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count, hipStream_t stream) {
     const uint32_t stride = cfg.traceGrid * kTraceBlock;
     if (count) {
-        hipLaunchKernelGGL(k_connect<true>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1, cfg.refillBelow);
+        hipLaunchKernelGGL(k_connect<true>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1, cfg.refillBelow, cfg.feederChunk);
     } else {
-        hipLaunchKernelGGL(k_connect<false>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1, cfg.refillBelow);
+        hipLaunchKernelGGL(k_connect<false>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1, cfg.refillBelow, cfg.feederChunk);
     }
     if (rp.enableMnee && rp.enableMneeSecondary) {
         if (count) {
