@@ -577,7 +577,8 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     // Phase 1: while unclaimed work items remain nobody needs to count survivors; the host looks at the item head
     // only when it expects it to be nearly exhausted (items are claimed at a steady rate, so after the first look the
     // next one is scheduled at 3/4 of the predicted remaining iterations).  Phase 2 (queue dry): k_shade counts live
-    // slots and every group is polled every 4 iterations until it has none left.  A poll joins all streams, which
+    // slots and every group is polled every 4 iterations until it has none left (k_extend reports how many live
+    // slots it traced: one atomic per persistent wave).  A poll joins all streams, which
     // costs the overlap between groups once; polling every 4 iterations throughout was 5 % slower.  (Polling through
     // events without joining was tried: the host then runs up to a dozen empty iterations past the end - no gain.)
     constexpr uint64_t kPollEvery = 4;
@@ -591,8 +592,8 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
             gr.cfg.feederChunk = gr.sparse ? ds.feederChunkSparse : ds.feederChunk;
             HIP_CHECK(hipMemsetAsync(gr.scalars, 0, sizeof(uint32_t) * 3, gr.stream));  // work heads of k_extend / k_connect
             if (queueDry) HIP_CHECK(hipMemsetAsync(aliveSlot, 0, sizeof(uint32_t), gr.stream));
-            timedLaunch(0, gr.stream, [&] { launchExtend(ds.view, gr.pool, gr.cfg, count, gr.stream); });
-            timedLaunch(1, gr.stream, [&] { launchShade(rp, ds.view, gr.pool, aliveSlot, queueDry, count, gr.stream); });
+            timedLaunch(0, gr.stream, [&] { launchExtend(ds.view, gr.pool, gr.cfg, queueDry ? aliveSlot : nullptr, count, gr.stream); });
+            timedLaunch(1, gr.stream, [&] { launchShade(rp, ds.view, gr.pool, aliveSlot, false, count, gr.stream); });
             timedLaunch(2, gr.stream, [&] { launchConnect(rp, ds.view, gr.pool, gr.cfg, count, gr.stream); });
         }
         ++iterations;

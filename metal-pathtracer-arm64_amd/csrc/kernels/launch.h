@@ -17,7 +17,8 @@ struct LaunchConfig {
 };
 
 void launchGenerate(const RenderParams& rp, const PathPool& pool, hipStream_t stream);
-void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count, hipStream_t stream);
+// aliveOut (nullable): += number of live slots the launch traced (host termination check)
+void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, uint32_t* aliveOut, bool count, hipStream_t stream);
 void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, uint32_t* aliveSlot, bool countAlive,
                  bool count, hipStream_t stream);
 void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count,

@@ -29,14 +29,19 @@ typedef __attribute__((address_space(3))) uint32_t LdsWord;
 
 struct LaneStack {
     LdsWord* lds;         // &ldsStack[threadIdx.x]; stride kTraceBlock
-    uint32_t* spill;      // &spill[globalThread]; stride spillStride
+    uint32_t* spill;      // spill area of this launch (wave-uniform: stays in SGPRs); lane column = global thread id
     uint32_t spillStride;
     uint32_t sp;
+    // the lane's column is recomputed on the (rare) spill path instead of keeping a 64-bit pointer alive per lane
+    __device__ __forceinline__ uint32_t* spillSlot(uint32_t level) const {
+        const uint32_t column = blockIdx.x * kTraceBlock + threadIdx.x;
+        return spill + static_cast<size_t>(level - kLdsStackLevels) * spillStride + column;
+    }
     __device__ __forceinline__ void push(uint32_t v) {
         if (sp < kLdsStackLevels) {
             lds[sp * kTraceBlock] = v;
         } else if (sp < kTraversalStackDepth) {
-            spill[static_cast<size_t>(sp - kLdsStackLevels) * spillStride] = v;
+            *spillSlot(sp) = v;
         } else {
             return;  // cannot happen: the builder bounds tree depth below kTraversalStackDepth
         }
@@ -44,8 +49,7 @@ struct LaneStack {
     }
     __device__ __forceinline__ uint32_t pop() {
         --sp;
-        return (sp < kLdsStackLevels) ? lds[sp * kTraceBlock]
-                                      : spill[static_cast<size_t>(sp - kLdsStackLevels) * spillStride];
+        return (sp < kLdsStackLevels) ? lds[sp * kTraceBlock] : *spillSlot(sp);
     }
 };
 

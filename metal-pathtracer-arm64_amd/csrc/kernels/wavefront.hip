@@ -388,18 +388,19 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams rp, PathPool pool
 // =====================================================================================================
 // k_extend: closest hit for every live slot
 // =====================================================================================================
-template <bool COUNT>
+template <bool COUNT, bool ALIVE>
 __global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride, uint32_t* workCounter,
-                                                         int kRefillBelow, uint32_t feederChunk) {
+                                                         int kRefillBelow, uint32_t feederChunk, uint32_t* aliveOut) {
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
     stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
-    stack.spill = spill + gtid;
+    stack.spill = spill;
     stack.spillStride = spillStride;
     stack.sp = 0u;
     TraceCounters cnt{0u, 0u};
     uint32_t rays = 0u;
+    uint32_t aliveSeen = 0u;   // live slots this wave picked up (host termination check, end of the frame only)
 
     const SceneMem mem = sceneMem(sc);
     WaveFeeder feeder;
@@ -412,7 +413,9 @@ __global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool p
         const int nActive = __popcll(__ballot(active));
         if (nActive < kRefillBelow && !feeder.exhausted) {
             const uint32_t idx = feeder.take(!active);
-            if (idx != WaveFeeder::kNone && (pool.state[idx].z & kFlagAlive)) {
+            const bool live = idx != WaveFeeder::kNone && (pool.state[idx].z & kFlagAlive);
+            if (ALIVE) aliveSeen += static_cast<uint32_t>(__popcll(__ballot(live)));   // wave-uniform: stays in an SGPR
+            if (live) {
                 mySlot = idx;
                 if (COUNT) ++rays;
                 active = travBegin(sc, t, mk3(pool.rayOrg[idx]), mk3(pool.rayDir[idx]), kEps, INFINITY, false, stack);
@@ -425,6 +428,11 @@ __global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool p
             active = false;
             pool.hit[mySlot] = make_float4(t.hit.t, t.hit.u, t.hit.v, __uint_as_float(t.hit.prim));
         }
+    }
+    if (ALIVE) {
+        // one atomic per persistent wave (8192 per launch).  Counting in k_shade took one per 64 slots: 262 k atomics on
+        // one address for a 16 Mi-slot pool = 3 ms per launch, exactly when the frame is draining.
+        if (laneId() == 0 && aliveSeen != 0u) atomicAdd(aliveOut, aliveSeen);
     }
     if (COUNT) {
         addCounter(pool.counters, kCntExtendRays, rays);
@@ -915,7 +923,7 @@ __global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_e
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
     stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
-    stack.spill = spill + gtid;
+    stack.spill = spill;
     stack.spillStride = spillStride;
     stack.sp = 0u;
     TraceCounters cnt{0u, 0u}, cntClosest{0u, 0u};
@@ -1004,7 +1012,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect_chain(RenderParams rp, 
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
     stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
-    stack.spill = spill + gtid;
+    stack.spill = spill;
     stack.spillStride = spillStride;
     stack.sp = 0u;
     TraceCounters cnt{0u, 0u}, cntClosest{0u, 0u};
@@ -1073,7 +1081,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace_rays(SceneView sc, const 
     const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
     stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
-    stack.spill = spill + gtid;
+    stack.spill = spill;
     stack.spillStride = spillStride;
     TraceCounters cnt{0u, 0u};
     for (uint64_t i = gtid; i < n; i += static_cast<uint64_t>(gridDim.x) * kTraceBlock) {
@@ -1174,13 +1182,18 @@ void launchGenerate(const RenderParams& rp, const PathPool& pool, hipStream_t st
     hipLaunchKernelGGL(k_generate, dim3(ceilDiv(pool.slots, 256)), dim3(256), 0, stream, rp, pool);
 }
 
-void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count, hipStream_t stream) {
+void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, uint32_t* aliveOut, bool count, hipStream_t stream) {
     const uint32_t stride = cfg.traceGrid * kTraceBlock;
     const uint32_t grid = std::min(cfg.traceGrid, ceilDiv(pool.slots, kTraceBlock));
+    // the live-slot count is a separate instantiation so the common launch carries no extra register
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters, cfg.refillBelow,
+                           cfg.feederChunk, aliveOut);
+    };
     if (count) {
-        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters, cfg.refillBelow, cfg.feederChunk);
+        if (aliveOut) launch(k_extend<true, true>); else launch(k_extend<true, false>);
     } else {
-        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters, cfg.refillBelow, cfg.feederChunk);
+        if (aliveOut) launch(k_extend<false, true>); else launch(k_extend<false, false>);
     }
 }
 
