@@ -151,7 +151,17 @@ typedef struct PtrSettings {
     float minSpecularPdf;
     float fireflyClampMaxContribution;
     float emissionScale;                /* PATH_TRACER_EMBREE_EMISSION_SCALE analogue; 1 = off */
+    /* Metal-only integrator semantics the Embree oracle path does not have; 0 = the
+     * Embree-parity integrator.  Bit 0 (PTR_METAL_MEDIA): Beer-Lambert absorption inside refractive dielectrics with
+     * the 8-deep medium stack of shaders/pathtrace.metal:5768-5773, 5869-5876, 6694-6709.  Bit 1 (PTR_METAL_THIN):
+     * thin-walled dielectrics (typeEta.w > 0.5) keep etaI = 1 on both faces and never enter a medium (:4589-4592,
+     * 5649-5659, 5683).  Bit 2 (PTR_METAL_FACE_NORMAL): dielectrics are shaded with the geometric normal turned
+     * towards the incoming ray (set_face_normal, :1187-1191); the Embree backend passes the unflipped normal
+     * (EmbreeHeadlessRenderer.mm:2333-2339, 2641-2644), which sends a ray that tries to leave a glass body back inside. */
+    uint32_t metalSemantics;
 } PtrSettings;
+
+enum { PTR_METAL_MEDIA = 1u, PTR_METAL_THIN = 2u, PTR_METAL_FACE_NORMAL = 4u };
 
 typedef struct PtrRenderStats {
     double totalSeconds;                /* integrate phase only (reference: out.totalSeconds) */

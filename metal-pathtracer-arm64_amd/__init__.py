@@ -129,6 +129,7 @@ class PtrSettings(C.Structure):
         ("minSpecularPdf", C.c_float),
         ("fireflyClampMaxContribution", C.c_float),
         ("emissionScale", C.c_float),
+        ("metalSemantics", C.c_uint32),
     ]
 
     def copy(self) -> "PtrSettings":

@@ -45,6 +45,7 @@ struct CliOptions {
     bool exposureSet = false;
     bool enableSoftwareRayTracing = false, enableSoftwareRayTracingSet = false;
     bool enableMnee = false, enableMneeSet = false;
+    uint32_t metalSemantics = 0;
     std::string formatString = "exr";
     ptr::ImageFileFormat format = ptr::ImageFileFormat::EXR;
     bool rgbaExr = false;
@@ -69,6 +70,8 @@ void printUsage(const char* exe) {
               << "  --envIntensity=<float>        Environment intensity multiplier\n\n"
               << "Backend selection:\n"
               << "  --backend=<hip|metal>          Headless backend (default hip; metal = alias)\n"
+              << "  --semantics=<embree|metal>     Integrator semantics: embree = parity with the reference's Embree backend\n"
+              << "                                 (default); metal = plus absorbing dielectric media, thin-walled glass, ray-facing glass normals\n"
               << "  --assets=<dir>                 Directory for relative mesh/env paths\n\n"
               << "Tonemapping overrides (for LDR outputs):\n"
               << "  --tonemap=<1|2|3|4>           1=Linear, 2=ACES, 3=Reinhard, 4=Hable\n"
@@ -211,6 +214,16 @@ bool parseOptions(int argc, const char** argv, CliOptions& o, std::string& error
         } else if (arg == "--format") {
             if (!need("--format")) return false;
             o.formatString = value;
+        } else if (arg == "--semantics") {
+            if (!need("--semantics")) return false;
+            if (value == "metal") {
+                o.metalSemantics = 7u;   // PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL
+            } else if (value == "embree") {
+                o.metalSemantics = 0u;
+            } else {
+                error = "Invalid value for --semantics (expected embree or metal)";
+                return false;
+            }
         } else if (arg == "--backend") {
             if (!need("--backend")) return false;
             std::string l;
@@ -292,6 +305,7 @@ int main(int argc, const char** argv) {
     if (options.envIntensitySet) settings.environmentIntensity = std::max(options.envIntensity, 0.0f);
     if (options.enableSoftwareRayTracingSet) settings.enableSoftwareRayTracing = options.enableSoftwareRayTracing;
     if (options.enableMneeSet) settings.enableMnee = options.enableMnee;
+    settings.metalSemantics = options.metalSemantics;
     if (settings.renderWidth == 0) settings.renderWidth = 1280u;
     if (settings.renderHeight == 0) settings.renderHeight = 720u;
 

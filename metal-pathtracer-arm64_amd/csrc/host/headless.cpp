@@ -38,6 +38,7 @@ void FillPtrSettings(const RenderSettings& s, PtrSettings& o) {
     o.minSpecularPdf = s.minSpecularPdf;
     o.fireflyClampMaxContribution = s.fireflyClampMaxContribution;
     o.emissionScale = 1.0f;
+    o.metalSemantics = s.metalSemantics;
 }
 
 bool HipHeadlessRenderer::render(const HeadlessScene& scene, const HeadlessCamera&, const RenderSettings& settings,

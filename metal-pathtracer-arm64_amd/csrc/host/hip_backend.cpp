@@ -109,7 +109,7 @@ struct PtrDeviceScene {
     std::vector<hipStream_t> groupStreams;   // streams of groups 1.. (group 0 runs on the caller's stream)
     std::vector<hipEvent_t> groupEvents;
     int refillBelow = 40;
-    DeviceBuffer<uint4> state;
+    DeviceBuffer<uint4> state, medium;
     DeviceBuffer<uint32_t> scalars, pixelOfLocal, spill;
     DeviceBuffer<uint2> itemReserve;
     DeviceBuffer<uint32_t> itemHeads;
@@ -140,11 +140,12 @@ constexpr uint32_t kScalarCount = kNextItemIndex + 1;
 constexpr uint32_t kMaxPoolGroups = 8;
 constexpr uint32_t kPinnedHeadsOffset = 16;   // pinned staging: [0..15] per-group alive counts, then kItemHeads range heads   // one block of scalars / one spill area per group
 
-// 576 B MaterialData -> the 12 float4 the integrator reads (kernels/device_types.h MaterialSlot).
+// 576 B MaterialData -> the 13 float4 the integrator reads (kernels/device_types.h MaterialSlot).
 void compactMaterial(const PtrMaterial& m, std::vector<float>& out) {
     const float* rows[kMaterialVec4] = {m.baseColorRoughness, m.typeEta,        m.emission,           m.conductorEta,
                                         m.conductorK,         m.coatParams,     m.coatTint,           m.coatAbsorption,
-                                        m.carpaintBaseParams, m.carpaintFlakeParams, m.carpaintBaseEta, m.carpaintBaseK};
+                                        m.carpaintBaseParams, m.carpaintFlakeParams, m.carpaintBaseEta, m.carpaintBaseK,
+                                        m.dielectricSigmaA};
     for (uint32_t r = 0; r < kMaterialVec4; ++r) {
         float v[4] = {rows[r][0], rows[r][1], rows[r][2], rows[r][3]};
         if (r == kMatCoatTint) v[3] = m.pbrParams[0];   // PBR metallic rides in the free w lane
@@ -348,6 +349,7 @@ void fillRenderParams(const PtrSettings& s, uint32_t spp, RenderParams& rp) {
     rp.minSpecularPdf = std::max(s.minSpecularPdf, 1.0e-8f);
     rp.clampEnabled = s.fireflyClampEnabled ? 1.0f : 0.0f;
     rp.emissionScale = (s.emissionScale > 0.0f && std::isfinite(s.emissionScale)) ? s.emissionScale : 1.0f;
+    rp.mediaMode = s.metalSemantics & (PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL);
 }
 
 // Local pixel order of a partition: its 16-row bands top to bottom, each walked in 8x8 blocks so the
@@ -453,6 +455,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     ds.itemAccum.ensure(rp.itemCount);
     ds.recBuf.ensure(static_cast<size_t>(slots) * kRecSlots * 4u);
     ds.itemReserve.ensure((slots + 63u) / 64u);
+    if (rp.mediaMode & PTR_METAL_MEDIA) ds.medium.ensure(slots);
 
     PathPool pool;
     std::memset(&pool, 0, sizeof(pool));
@@ -462,6 +465,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     pool.throughput = ds.throughput.ptr;
     pool.accum = ds.accum.ptr;
     pool.state = ds.state.ptr;
+    pool.medium = (rp.mediaMode & PTR_METAL_MEDIA) ? ds.medium.ptr : nullptr;
     pool.itemAccum = ds.itemAccum.ptr;
     ds.itemHeads.ensure(kItemHeadWords);
     pool.nextItem = ds.itemHeads.ptr;
@@ -517,6 +521,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
         gr.pool.throughput += first;
         gr.pool.accum += first;
         gr.pool.state += first;
+        if (gr.pool.medium) gr.pool.medium += first;
         for (uint32_t k = 0; k < kRecSlots; ++k) {
             gr.pool.rec[k].org += first;
             gr.pool.rec[k].dir += first;

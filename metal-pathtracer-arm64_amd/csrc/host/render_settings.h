@@ -25,6 +25,10 @@ struct RenderSettings {
     uint32_t sssMaxSteps = 32;
     bool enableSpecularNee = true;
     bool enableMnee = false;
+    // Not in the reference's RenderSettings: which integrator semantics the HIP backend follows.  0 = the Embree
+    // backend's (the parity oracle); PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL add what only the Metal kernel does
+    // (absorbing dielectric interiors, thin-walled glass, ray-facing glass normals).
+    uint32_t metalSemantics = 0;
     bool enableMneeSecondary = true;
 
     uint32_t tonemapMode = 1;  // 1=Linear, 2=ACES, 3=Reinhard, 4=Hable

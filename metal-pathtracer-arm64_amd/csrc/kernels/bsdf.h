@@ -14,6 +14,7 @@ namespace ptrk {
 struct ClampCfg {
     float factor, floorLum, throughput, tailBase, tailRoughScale, minSpecPdf;
     bool enabled;
+    bool thinDielectrics;   // PTR_METAL_THIN: honour the thin-walled flag of dielectrics (Metal semantics)
 };
 
 __device__ __forceinline__ uint32_t rngHash(uint32_t x) {  // lowbias32
@@ -32,7 +33,7 @@ __device__ __forceinline__ float rngNext(uint32_t& state) {
 
 __device__ __forceinline__ float luminance(f3 c) { return (0.2126f * c.x + 0.7152f * c.y) + 0.0722f * c.z; }
 
-// Material record view: 12 float4, fetched on demand (most branches need 2-4 of them).
+// Material record view: 13 float4, fetched on demand (most branches need 2-4 of them).
 struct Mat {
     const float4* p;
     __device__ __forceinline__ float4 v(uint32_t slot) const { return p[slot]; }
@@ -40,6 +41,8 @@ struct Mat {
     __device__ __forceinline__ f3 baseColor() const { return vclamp(mk3(p[kMatBaseColorRoughness]), 0.0f, 1.0f); }
     __device__ __forceinline__ float roughness01() const { return clampf(p[kMatBaseColorRoughness].w, 0.0f, 1.0f); }
     __device__ __forceinline__ float ior() const { return p[kMatTypeEta].y; }
+    __device__ __forceinline__ bool thinFlag() const { return p[kMatTypeEta].w > 0.5f; }   // material_is_thin_dielectric
+    __device__ __forceinline__ f3 sigmaA() const { return vmax0(mk3(p[kMatDielectricSigmaA])); }
 };
 
 // ------------------------------------------------------------------ clamps
@@ -584,11 +587,12 @@ struct BsdfSampleResult {
     f3 dir, weight;
     float pdf;
     bool isDelta;
+    int mediumEvent;   // +1: refracted into a dielectric through its front face, -1: out through a back face, else 0
 };
 
 __device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 incident, bool frontFace,
                                        uint32_t& rng, const ClampCfg& cc) {
-    BsdfSampleResult r{mk3(0.0f), mk3(0.0f), 0.0f, false};
+    BsdfSampleResult r{mk3(0.0f), mk3(0.0f), 0.0f, false, 0};
     const uint32_t type = m.type();
     switch (type) {
         case 7u: {
@@ -748,8 +752,11 @@ __device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f
         case 2u: {  // smooth dielectric: Fresnel-weighted pick between mirror reflection and refraction
             r.isDelta = true;
             const float refIdx = smax(m.ior(), 1.0f);
-            const float etaI = frontFace ? 1.0f : refIdx;
-            const float etaT = frontFace ? refIdx : 1.0f;
+            // thin-walled glass (Metal semantics only, pathtrace.metal:5649-5659): both faces see air -> glass
+            const bool thin = cc.thinDielectrics && m.thinFlag();
+            const bool entering = frontFace || thin;
+            const float etaI = entering ? 1.0f : refIdx;
+            const float etaT = entering ? refIdx : 1.0f;
             const float cosO = clampf(dot(-incident, n), -1.0f, 1.0f);
             float cosT = 0.0f;
             const float Fr = fresnelDielectric(cosO, etaI, etaT, cosT);
@@ -769,6 +776,7 @@ __device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f
                         const float etaScale = (etaT * etaT) / (etaI * etaI);
                         const float dirScale = etaScale * (fabsf(cosT) / smax(fabsf(cosO), 1.0e-6f));
                         weight = mk3(smax(1.0f - Fr, 0.0f) * dirScale);
+                        if (!thin) r.mediumEvent = frontFace ? 1 : -1;   // pathtrace.metal:5683
                     }
                 }
             }

@@ -51,7 +51,7 @@ struct SceneView {
 };
 
 // Compact material record: the MaterialData fields the Embree-semantics integrator reads.
-constexpr uint32_t kMaterialVec4 = 12u;
+constexpr uint32_t kMaterialVec4 = 13u;
 enum MaterialSlot : uint32_t {
     kMatBaseColorRoughness = 0,
     kMatTypeEta = 1,
@@ -65,6 +65,7 @@ enum MaterialSlot : uint32_t {
     kMatCarpaintFlake = 9,
     kMatCarpaintBaseEta = 10,
     kMatCarpaintBaseK = 11,
+    kMatDielectricSigmaA = 12,   // xyz absorption coefficient of a dielectric's interior (Metal media semantics)
 };
 
 struct CameraParams {
@@ -82,6 +83,7 @@ struct RenderParams {
     uint32_t chunkCount;           // ceil(spp / C)
     uint32_t itemCount;            // localPixels * chunkCount; item w = chunk * localPixels + localPixel
     uint32_t localPixels;          // pixels owned by this partition
+    uint32_t mediaMode;            // PTR_METAL_MEDIA | PTR_METAL_THIN (0 = Embree-parity integrator)
     uint32_t itemHeadFirst;        // items below this are pre-assigned to the slots by k_generate
     uint32_t itemsPerHead;         // the remaining items are split into kItemHeads ranges of this size (multiple of 64)
     uint32_t enableRussianRoulette, enableSpecularNee, enableMnee, enableMneeSecondary;
@@ -124,6 +126,7 @@ struct PathPool {
     float4* throughput;    // xyz throughput, w lastBsdfPdf
     float4* accum;         // xyz radiance sum of the slot's current work item; w = bits(item to flush)
     uint4* state;          // x rng, y work item, z flags, w = pending mask (bits 0..4) | sample-in-chunk << 8
+    uint4* medium;         // media mode only: stack of up to 8 dielectric material ids (16 bit each), depth in the flags
     float4* itemAccum;     // [itemCount] finished work items (summed per pixel, in chunk order, by k_resolve)
     uint32_t* nextItem;    // [kItemHeadWords] head k at [k * kItemHeadStride]: next unclaimed item of range k (k_shade)
     ShadowRecordView rec[kRecSlots];
@@ -139,6 +142,8 @@ struct PathPool {
 constexpr uint32_t kFlagAlive = 1u << 0;
 constexpr uint32_t kFlagLastDelta = 1u << 1;
 constexpr uint32_t kFlagFlush = 1u << 2;        // accumulator belongs to a finished item: store it, then zero
+constexpr uint32_t kFlagMediumShift = 3u;       // 4 bits: depth of the medium stack (0..8)
+constexpr uint32_t kMaxMediumStack = 8u;
 constexpr uint32_t kFlagDepthShift = 8u;        // 12 bits
 constexpr uint32_t kFlagSpecDepthShift = 20u;   // 12 bits
 constexpr uint32_t kFlagFieldMask = 0xFFFu;

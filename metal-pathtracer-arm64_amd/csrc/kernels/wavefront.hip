@@ -43,6 +43,7 @@ __device__ __forceinline__ ClampCfg clampCfg(const RenderParams& rp) {
     c.tailRoughScale = rp.tailClampRoughnessScale;
     c.minSpecPdf = rp.minSpecularPdf;
     c.enabled = rp.clampEnabled >= 0.5f;
+    c.thinDielectrics = (rp.mediaMode & PTR_METAL_THIN) != 0u;
     return c;
 }
 
@@ -441,6 +442,22 @@ __global__ void __launch_bounds__(kTraceBlock) k_extend(SceneView sc, PathPool p
     }
 }
 
+// ---- medium stack of the Metal media semantics: 8 dielectric material ids, 16 bits each, in one uint4 ----
+__device__ __forceinline__ uint32_t mediumEntry(uint4 ms, uint32_t i) {
+    const uint32_t w = i < 2u ? ms.x : (i < 4u ? ms.y : (i < 6u ? ms.z : ms.w));
+    return (w >> ((i & 1u) * 16u)) & 0xFFFFu;
+}
+
+__device__ __forceinline__ uint4 mediumWithEntry(uint4 ms, uint32_t i, uint32_t id) {
+    const uint32_t shift = (i & 1u) * 16u;
+    const uint32_t keep = ~(0xFFFFu << shift), put = (id & 0xFFFFu) << shift;
+    if (i < 2u) ms.x = (ms.x & keep) | put;
+    else if (i < 4u) ms.y = (ms.y & keep) | put;
+    else if (i < 6u) ms.z = (ms.z & keep) | put;
+    else ms.w = (ms.w & keep) | put;
+    return ms;
+}
+
 // =====================================================================================================
 // k_shade
 // =====================================================================================================
@@ -463,7 +480,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
     uint32_t shadedHit = 0u, triHit = 0u, primary = 0u;
     uint32_t sampleInChunk = (st.w >> 8) & 0xFFu;
     uint32_t rng = st.x;
-    uint32_t depth = 0u, specDepth = 0u;
+    uint32_t depth = 0u, specDepth = 0u, mediumDepth = 0u;
     bool lastDelta = true, flushNext = false;
     f3 acc = mk3(0.0f), thr = mk3(1.0f), nextO = mk3(0.0f), nextD = mk3(0.0f);
     float lastPdf = 1.0f;
@@ -487,6 +504,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
         if (active) {
             depth = (st.z >> kFlagDepthShift) & kFlagFieldMask;
             specDepth = (st.z >> kFlagSpecDepthShift) & kFlagFieldMask;
+            mediumDepth = (st.z >> kFlagMediumShift) & 0xFu;
             lastDelta = (st.z & kFlagLastDelta) != 0u;
             const f3 rayO = mk3(pool.rayOrg[slot]);
             const f3 rayD = mk3(pool.rayDir[slot]);
@@ -529,13 +547,26 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
                     shadedHit = 1u;
                     triHit = sf.primType == 0u ? 1u : 0u;
                 }
+                if ((rp.mediaMode & PTR_METAL_MEDIA) && mediumDepth > 0u) {
+                    // Beer-Lambert over the segment just travelled inside the innermost medium (pathtrace.metal:5869-5876)
+                    const uint32_t inside = mediumEntry(pool.medium[slot], mediumDepth - 1u);
+                    const Mat mm{sc.materials + static_cast<size_t>(min(inside, sc.materialCount - 1u)) * kMaterialVec4};
+                    const f3 sigma = mm.sigmaA();
+                    if (sigma.x > 0.0f || sigma.y > 0.0f || sigma.z > 0.0f) {
+                        const float segment = smax(hitv.x, 0.0f);
+                        thr *= mk3(expf(-sigma.x * segment), expf(-sigma.y * segment), expf(-sigma.z * segment));
+                    }
+                }
                 const Mat mat{sc.materials + static_cast<size_t>(min(sf.material, sc.materialCount - 1u)) * kMaterialVec4};
                 const uint32_t type = mat.type();
                 const f3 incident = normalize(rayD);
                 const f3 wo = -incident;
                 f3 n = sf.hitShadingNormal;
                 if (dot(n, n) <= 0.0f) n = sf.normal;
-                if (type == 2u) n = sf.normal;      // dielectrics shade with the geometric normal
+                if (type == 2u) {                   // dielectrics shade with the geometric normal
+                    n = sf.normal;                  // (as stored: the Embree backend does not turn it towards the ray)
+                    if ((rp.mediaMode & PTR_METAL_FACE_NORMAL) && !sf.frontFace) n = -n;   // set_face_normal, pathtrace.metal:1187-1191
+                }
                 n = normalize(n);
 
                 if (type == 3u) {
@@ -635,6 +666,16 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
                     if (bs.pdf <= 0.0f || dot(bs.dir, bs.dir) <= 0.0f || !finite3(bs.weight)) {
                         endPath = true;
                     } else {
+                        if ((rp.mediaMode & PTR_METAL_MEDIA) && bs.mediumEvent != 0) {
+                            // refraction into / out of a dielectric: push its material, or pop (pathtrace.metal:6694-6709)
+                            if (bs.mediumEvent > 0) {
+                                const uint32_t at = min(mediumDepth, kMaxMediumStack - 1u);   // a full stack overwrites its top
+                                pool.medium[slot] = mediumWithEntry(pool.medium[slot], at, min(sf.material, sc.materialCount - 1u));
+                                mediumDepth = min(mediumDepth + 1u, kMaxMediumStack);
+                            } else if (mediumDepth > 0u) {
+                                --mediumDepth;
+                            }
+                        }
                         const uint32_t nextSpecDepth = bs.isDelta ? (specDepth + 1u) : 0u;
                         specDepth = nextSpecDepth;
                         const bool dirValid = finite3(bs.dir);
@@ -709,6 +750,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
                 lastDelta = true;
                 depth = 0u;
                 specDepth = 0u;
+                mediumDepth = 0u;
                 if (sampleInChunk < rp.chunkSize && s < rp.spp) {
                     beginSample(rp, pool.pixelOfLocal[st.y % rp.localPixels], s, rng, nextO, nextD);
                     stillAlive = true;
@@ -796,7 +838,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
     if (touched) {
         st.x = rng;
         st.z = (stillAlive ? kFlagAlive : 0u) | (lastDelta ? kFlagLastDelta : 0u) | (flushNext ? kFlagFlush : 0u) |
-               (depth << kFlagDepthShift) | (specDepth << kFlagSpecDepthShift);
+               (depth << kFlagDepthShift) | (specDepth << kFlagSpecDepthShift) | (mediumDepth << kFlagMediumShift);
         st.w = pendingMask | (sampleInChunk << 8);
         pool.state[slot] = st;
         pool.accum[slot] = mk4(acc, __uint_as_float(flushItem));

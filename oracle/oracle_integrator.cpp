@@ -696,6 +696,7 @@ ClampParams makeClampParams(const PtrSettings& s) {  // E:381-391
     p.specularTailClampRoughnessScale = std::max(s.specularTailClampRoughnessScale, 0.0f);
     p.minSpecularPdf = std::max(s.minSpecularPdf, 1.0e-8f);
     p.enabled = s.fireflyClampEnabled ? 1.0f : 0.0f;
+    p.thinDielectrics = (s.metalSemantics & PTR_METAL_THIN) != 0u;   // Metal-only semantics, off on the Embree path
     return p;
 }
 
@@ -1035,7 +1036,9 @@ BsdfSample sampleBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 in
         const float refIdx = std::max(m.typeEta[1], 1.0f);
         float etaI = 1.0f, etaT = refIdx;
         const float cosO = clampf(dot(-incidentDir, normal), -1.0f, 1.0f);
-        if (!frontFace) {
+        // thin-walled glass is a Metal-only notion (typeEta.w > 0.5): both faces see air -> glass, no medium event
+        const bool thin = cp.thinDielectrics && m.typeEta[3] > 0.5f;
+        if (!thin && !frontFace) {
             etaI = refIdx;
             etaT = 1.0f;
         }
@@ -1056,6 +1059,7 @@ BsdfSample sampleBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 in
             const float etaScale = (etaT * etaT) / (etaI * etaI);
             const float directionScale = etaScale * (std::fabs(cosT) / std::max(std::fabs(cosO), 1.0e-6f));
             weight = splat(std::max(1.0f - Fr, 0.0f) * directionScale);
+            if (!thin) r.mediumEvent = frontFace ? 1 : -1;
         }
         r.direction = normalize(direction);
         r.weight = weight;
@@ -1338,6 +1342,12 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
             float lastBsdfPdf = 1.0f;
             bool lastScatterWasDelta = true;
             uint32_t specularDepth = 0;
+            // Metal-only media semantics (settings.metalSemantics & PTR_METAL_MEDIA): stack of the dielectrics the path
+            // is inside of, shaders/pathtrace.metal:5768-5773
+            constexpr uint32_t kMaxMediumStack = 8;
+            uint32_t mediumStack[kMaxMediumStack] = {0};
+            uint32_t mediumDepth = 0;
+            const bool media = (settings.metalSemantics & PTR_METAL_MEDIA) != 0u;
 
             for (uint32_t depth = 0; depth < settings.maxDepth; ++depth) {
                 HitInfo hit;
@@ -1359,6 +1369,14 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
                     ++rc.shadedHits;
                     if (hit.primitiveType == GeomType::Mesh) ++rc.triangleHits;
                 }
+                if (media && mediumDepth > 0) {  // Beer-Lambert over the segment inside the innermost medium, M:5869-5876
+                    const PtrMaterial& inside = materials[std::min(mediumStack[mediumDepth - 1], materialCount - 1)];
+                    const V3 sigma = vmax(V3(inside.dielectricSigmaA), V3());
+                    if (sigma.x > 0.0f || sigma.y > 0.0f || sigma.z > 0.0f) {
+                        const float segment = std::max(hit.t, 0.0f);
+                        throughput *= V3(std::exp(-sigma.x * segment), std::exp(-sigma.y * segment), std::exp(-sigma.z * segment));
+                    }
+                }
 
                 const PtrMaterial& material = materials[std::min(hit.materialIndex, materialCount - 1)];
                 const uint32_t type = matType(material);
@@ -1366,7 +1384,11 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
                 const V3 wo = -incidentDir;
                 V3 shadingNormal = hit.shadingNormal;
                 if (dot(shadingNormal, shadingNormal) <= 0.0f) shadingNormal = hit.normal;
-                if (type == PTR_MAT_DIELECTRIC) shadingNormal = hit.normal;  // dielectrics shade with the geometric normal
+                if (type == PTR_MAT_DIELECTRIC) {
+                    shadingNormal = hit.normal;  // dielectrics shade with the geometric normal, as stored (E:2641-2644)
+                    // Metal-only: the normal faces the incoming ray (set_face_normal, shaders/pathtrace.metal:1187-1191)
+                    if ((settings.metalSemantics & PTR_METAL_FACE_NORMAL) && !hit.frontFace) shadingNormal = -shadingNormal;
+                }
                 shadingNormal = normalize(shadingNormal);
 
                 if (type == PTR_MAT_DIFFUSE_LIGHT) {  // E:2660-2706
@@ -1434,6 +1456,19 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
 
                 const BsdfSample bs = sampleBsdf(material, hit.position, shadingNormal, wo, incidentDir, hit.frontFace, rng, cp);
                 if (bs.pdf <= 0.0f || dot(bs.direction, bs.direction) <= 0.0f || !finite3(bs.weight)) break;
+
+                if (media && bs.mediumEvent != 0) {  // M:6694-6709
+                    if (bs.mediumEvent > 0) {
+                        const uint32_t entered = std::min(hit.materialIndex, materialCount - 1);
+                        if (mediumDepth < kMaxMediumStack) {
+                            mediumStack[mediumDepth++] = entered;
+                        } else {
+                            mediumStack[kMaxMediumStack - 1] = entered;
+                        }
+                    } else if (mediumDepth > 0) {
+                        --mediumDepth;
+                    }
+                }
 
                 const uint32_t nextSpecularDepth = bs.isDelta ? (specularDepth + 1u) : 0u;
                 specularDepth = nextSpecularDepth;

@@ -73,6 +73,7 @@ struct ClampParams {  // FireflyClampParams, :136-144
     float clampFactor = 0.0f, clampFloor = 0.0f, throughputClamp = 0.0f;
     float specularTailClampBase = 0.0f, specularTailClampRoughnessScale = 0.0f;
     float minSpecularPdf = 1.0e-8f, enabled = 0.0f;
+    bool thinDielectrics = false;   // PTR_METAL_THIN (Metal-only semantics, shaders/pathtrace.metal:4589-4592, 5649-5659)
 };
 
 struct BsdfEval {
@@ -85,6 +86,7 @@ struct BsdfSample {
     V3 direction, weight;
     float pdf = 0.0f;
     bool isDelta = false;
+    int mediumEvent = 0;   // Metal-only: +1 refracted in through a front face, -1 out through a back face (pathtrace.metal:5683)
 };
 
 struct HitInfo {  // :97-107

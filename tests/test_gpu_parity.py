@@ -269,6 +269,49 @@ def test_config5_reduced_sss_and_carpaint_meshes():
     _image_parity(host, dev, osc, 160, 90, 12, 1, 32, 0.88)
 
 
+def test_metal_media_semantics(tmp_path):
+    # Metal-only integrator semantics (PtrSettings.metalSemantics): Beer-Lambert media with the 8-deep stack, thin-walled
+    # glass, ray-facing glass normals.  Checked against the oracle's restatement of shaders/pathtrace.metal:1187-1191,
+    # 5649-5683, 5869-5876, 6694-6709 and against the closed form for a slab.
+    text = ("camera target=0,1,0 distance=9 yaw=1.1 pitch=0.3 vfov=38\nrenderer maxDepth=12 seed=9\nbackground solid=0.6,0.7,0.9\n"
+            "material type=lambert albedo=0.7,0.7,0.7\n"
+            "material type=dielectric ior=1.5 sigmaA=0.9,0.25,0.05 name=amber\n"
+            "material type=dielectric ior=1.33 sigmaA=0.05,0.3,0.6 name=water\n"
+            "material type=dielectric ior=1.5 sigmaA=2,2,2 thin=1 name=pane\n"
+            "material type=light emit=12,11,10\n"
+            "rectangle x=-8,8 y=0 z=-8,8 normal=1 material=0\n"
+            "sphere center=-1.6,1,0 radius=1 material=1\n"
+            "sphere center=-1.6,1,0 radius=0.55 material=2\n"          # nested media: water inside amber glass
+            "box min=0.4,0,-0.8 max=2.0,1.6,0.8 material=1\n"
+            "rectangle x=-3,3 y=0,3 z=2.2 normal=-1 material=3 twoSided=1\n"     # thin pane between the camera... and
+            "rectangle x=-1,1 y=6 z=-1,1 normal=-1 material=4\n")
+    p = tmp_path / "media.scene"
+    p.write_text(text)
+    host = pt.HostScene.load(str(p))
+    dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
+    for sem in (7, 5, 4):
+        _image_parity(host, dev, osc, 96, 64, 12, 1, 32, 0.88, metalSemantics=sem, enableRussianRoulette=0)
+    # the modes really differ from the Embree-parity image and from each other
+    s0 = host.settings_for(width=96, height=64, max_depth=12, seed=9)
+    base, _ = dev.render_image(s0, 16)
+    imgs = []
+    for sem in (4, 5, 7):
+        s = s0.copy()
+        s.metalSemantics = sem
+        imgs.append(dev.render_image(s, 16)[0])
+    assert _rmse(base, imgs[0]) > 0.01 and _rmse(imgs[0], imgs[1]) > 0.005 and _rmse(imgs[1], imgs[2]) > 0.002
+    # closed form: straight through a 2-unit slab, radiance = (1-Fr)^4 exp(-2 sigma) + Fr^2
+    slab = tmp_path / "slab.scene"
+    slab.write_text("camera target=0,0,0 distance=10 yaw=1.5708 pitch=0 vfov=2\nrenderer width=16 height=16 maxDepth=12 seed=5 russianRoulette=0\n"
+                    "background solid=1,1,1\nmaterial type=dielectric ior=1.5 sigmaA=0.30,0.10,0.02\nbox min=-4,-4,-1 max=4,4,1 material=0\n")
+    sh = pt.HostScene.load(str(slab))
+    sdev = pt.DeviceScene(sh.desc, 0, keepalive=sh)
+    ss = sh.settings_for(seed=5, metalSemantics=5, fireflyClampEnabled=0)
+    centre = sdev.render_image(ss, 256)[0][6:10, 6:10].reshape(-1, 3).mean(axis=0)
+    fr = 0.04
+    assert np.allclose(centre, (1 - fr) ** 4 * np.exp(-2.0 * np.array([0.30, 0.10, 0.02])) + fr * fr, rtol=0.02), centre
+
+
 def test_gradient_sky_and_thin_lens(materials_scene):
     host, dev, osc = materials_scene
     _image_parity(host, dev, osc, 64, 48, 5, 1, 16, 0.90, backgroundMode=0, cameraDefocusAngle=1.5, cameraFocusDistance=8.0)
