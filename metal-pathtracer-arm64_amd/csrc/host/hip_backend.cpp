@@ -595,10 +595,10 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
             if (gr.done) continue;
             uint32_t* aliveSlot = gr.scalars + kAliveBase + ring;
             gr.cfg.feederChunk = gr.sparse ? ds.feederChunkSparse : ds.feederChunk;
-            HIP_CHECK(hipMemsetAsync(gr.scalars, 0, sizeof(uint32_t) * 3, gr.stream));  // work heads of k_extend / k_connect
-            if (queueDry) HIP_CHECK(hipMemsetAsync(aliveSlot, 0, sizeof(uint32_t), gr.stream));
+            // work heads and the next live-slot counter are cleared by k_shade (all zero at the start of the frame)
+            const ShadeResets resets{gr.scalars + 1, gr.scalars + 2, gr.scalars + kAliveBase + (ring + 1u) % kAliveRing};
             timedLaunch(0, gr.stream, [&] { launchExtend(ds.view, gr.pool, gr.cfg, queueDry ? aliveSlot : nullptr, count, gr.stream); });
-            timedLaunch(1, gr.stream, [&] { launchShade(rp, ds.view, gr.pool, aliveSlot, false, count, gr.stream); });
+            timedLaunch(1, gr.stream, [&] { launchShade(rp, ds.view, gr.pool, resets, count, gr.stream); });
             timedLaunch(2, gr.stream, [&] { launchConnect(rp, ds.view, gr.pool, gr.cfg, count, gr.stream); });
         }
         ++iterations;

@@ -19,8 +19,14 @@ struct LaunchConfig {
 void launchGenerate(const RenderParams& rp, const PathPool& pool, hipStream_t stream);
 // aliveOut (nullable): += number of live slots the launch traced (host termination check)
 void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, uint32_t* aliveOut, bool count, hipStream_t stream);
-void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, uint32_t* aliveSlot, bool countAlive,
-                 bool count, hipStream_t stream);
+// words k_shade sets to zero for the launches that follow it (each may be null)
+struct ShadeResets {
+    uint32_t* extendHead;    // work head of the next k_extend
+    uint32_t* connectHead;   // work head of this iteration's k_connect
+    uint32_t* nextAlive;     // live-slot counter of the next k_extend
+};
+void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, bool count,
+                 hipStream_t stream);
 void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count,
                    hipStream_t stream);
 // Adds outstanding light connections, reduces the slots of each pixel in fixed order and writes

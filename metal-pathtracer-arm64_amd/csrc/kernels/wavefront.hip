@@ -468,8 +468,15 @@ __device__ __forceinline__ uint4 mediumWithEntry(uint4 ms, uint32_t i, uint32_t 
 #endif
 #define PTR_SHADE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PTR_SHADE_WAVES, PTR_SHADE_WAVES)))
 template <bool COUNT>
-__global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(RenderParams rp, SceneView sc, PathPool pool, uint32_t* aliveSlot, uint32_t countAlive) {
+__global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(RenderParams rp, SceneView sc, PathPool pool, ShadeResets resets) {
     const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x;
+    if (slot == 0u) {
+        // k_shade runs between this iteration's k_extend and k_connect: it clears the work heads they will claim from
+        // next (and the live-slot counter of the next k_extend), which saves two fill dispatches per iteration
+        if (resets.extendHead) *resets.extendHead = 0u;
+        if (resets.connectHead) *resets.connectHead = 0u;
+        if (resets.nextAlive) *resets.nextAlive = 0u;
+    }
     const bool inRange = slot < pool.slots;
     uint4 st = inRange ? pool.state[slot] : make_uint4(0u, 0u, 0u, 0u);
     const bool active = inRange && (st.z & kFlagAlive);
@@ -848,10 +855,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
             pool.throughput[slot] = mk4(thr, lastPdf);
         }
     }
-    if (countAlive) {   // only requested once the item queue has run dry (host termination check)
-        const uint32_t aliveInWave = static_cast<uint32_t>(__popcll(__ballot(stillAlive)));
-        if (laneId() == 0 && aliveInWave != 0u) atomicAdd(aliveSlot, aliveInWave);
-    }
+
     if (COUNT) {
         addCounter(pool.counters, kCntShadedHits, shadedHit);
         addCounter(pool.counters, kCntTriangleHits, triHit);
@@ -1239,14 +1243,13 @@ void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig&
     }
 }
 
-void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, uint32_t* aliveSlot, bool countAlive, bool count,
+void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, bool count,
                  hipStream_t stream) {
     const uint32_t grid = ceilDiv(pool.slots, kShadeBlock);
-    const uint32_t ca = countAlive ? 1u : 0u;
     if (count) {
-        hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, aliveSlot, ca);
+        hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, resets);
     } else {
-        hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, aliveSlot, ca);
+        hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, resets);
     }
 }
 
