@@ -112,7 +112,7 @@ struct PtrDeviceScene {
     DeviceBuffer<uint4> state, medium;
     DeviceBuffer<uint32_t> scalars, pixelOfLocal, spill;
     DeviceBuffer<uint2> itemReserve;
-    DeviceBuffer<uint32_t> itemHeads;
+    DeviceBuffer<uint32_t> itemHeads, zeros;
     DeviceBuffer<uint64_t> counters;
     DeviceBuffer<float> outBands;
     DeviceBuffer<float4> rayBatch;
@@ -283,6 +283,8 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     ds.spill.ensure(static_cast<size_t>(kTraversalStackDepth - kLdsStackLevels) * ds.traceGrid * kTraceBlock * kMaxPoolGroups);
     ds.scalars.ensure(static_cast<size_t>(kScalarCount) * kMaxPoolGroups);
     ds.counters.ensure(kCounterSlots);
+    ds.zeros.ensure(16);
+    HIP_CHECK(hipMemset(ds.zeros.ptr, 0, 16 * sizeof(uint32_t)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ds.pinnedAlive), sizeof(uint32_t) * (kPinnedHeadsOffset + kItemHeads), hipHostMallocDefault));
     ds.uploadSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -480,6 +482,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     pool.aliveCount = ds.scalars.ptr + kAliveBase;
     pool.pixelOfLocal = ds.pixelOfLocal.ptr;
     pool.counters = ds.counters.ptr;
+    pool.zero = reinterpret_cast<const float4*>(ds.zeros.ptr);
     pool.slots = slots;
     pool.recStride = slots;
 

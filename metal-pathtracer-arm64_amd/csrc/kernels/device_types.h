@@ -133,6 +133,7 @@ struct PathPool {
     uint2* itemReserve;        // [slots/64] per-wave reservation {next, end} of work items (one atomic per 64 items)
     uint32_t* aliveCount;      // ring of alive counters (host termination check)
     const uint32_t* pixelOfLocal;  // local pixel -> y*width + x
+    const float4* zero;        // one float4 of zeros: where k_shade points the loads of records that are not pending
     uint64_t* counters;        // kCounterSlots
     uint32_t slots;            // slots of this pool (or of this group of the pool)
     uint32_t recStride;        // slots of the WHOLE pool: distance between the fields / record slots of `rec`

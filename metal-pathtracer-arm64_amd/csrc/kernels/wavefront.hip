@@ -263,7 +263,10 @@ __device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 d
         return s;
     }
     const float4* tp = sc.tris + static_cast<size_t>(prim) * 3u;
+    const float4* np = sc.triNormals + static_cast<size_t>(prim) * 3u;
     const float4 a = tp[0], b = tp[1], c = tp[2];
+    const float4 n0 = np[0], n1 = np[1], n2 = np[2];   // all six loads of the hit in flight together
+    asm volatile("" ::"v"(a.x), "v"(b.x), "v"(c.x), "v"(n0.x), "v"(n1.x), "v"(n2.x));
     const f3 ng = cross(mk3(c), mk3(b));
     if (dot(ng, ng) > 0.0f) s.normal = normalize(ng);
     s.frontFace = dot(dir, s.normal) < 0.0f;
@@ -271,12 +274,11 @@ __device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 d
     f3 shading = adjusted;
     const uint32_t meta = __float_as_uint(b.w);
     s.material = __float_as_uint(a.w);
-    const float4* np = sc.triNormals + static_cast<size_t>(prim) * 3u;
     if ((meta >> 30) == 0u) {
         s.primType = 0u;
         s.primIndex = __float_as_uint(c.w);
         const float w = 1.0f - u - v;
-        const f3 interp = (w * mk3(np[0]) + u * mk3(np[1])) + v * mk3(np[2]);
+        const f3 interp = (w * mk3(n0) + u * mk3(n1)) + v * mk3(n2);
         if (dot(interp, interp) > 0.0f) {
             shading = normalize(interp);
             if (dot(shading, adjusted) < 0.0f) shading = -shading;
@@ -284,7 +286,7 @@ __device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 d
     } else {
         s.primType = 2u;
         s.primIndex = meta & 0x3FFFFFFFu;
-        shading = mk3(np[0]);
+        shading = mk3(n0);
         if (dot(shading, adjusted) < 0.0f) shading = -shading;
         s.twoSided = __float_as_uint(sc.rects[static_cast<size_t>(s.primIndex) * 5u + 4u].y) != 0u;
     }
@@ -478,7 +480,24 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
         if (resets.nextAlive) *resets.nextAlive = 0u;
     }
     const bool inRange = slot < pool.slots;
-    uint4 st = inRange ? pool.state[slot] : make_uint4(0u, 0u, 0u, 0u);
+    // Everything that depends only on the slot index is requested up front, and the record loads are pointed at a
+    // zero word when the record is not pending, so the kernel has ~11 loads in flight per lane after ONE dependent
+    // step (the state word) instead of walking a chain of ten load-wait pairs at 5 waves per SIMD.
+    const uint32_t at = inRange ? slot : 0u;
+    uint4 st = pool.state[at];
+    const float4 acc4 = pool.accum[at];
+    const float4 rayO4 = pool.rayOrg[at], rayD4 = pool.rayDir[at];
+    const float4 hitv = pool.hit[at];
+    const float4 thr4 = pool.throughput[at];
+    if (!inRange) st = make_uint4(0u, 0u, 0u, 0u);
+    float4 landed[kRecSlots];
+#pragma unroll
+    for (uint32_t k = 0; k < kRecSlots; ++k) {
+        const float4* src = (st.w & (1u << k)) ? pool.rec[k].a + at : pool.zero;
+        landed[k] = *src;
+    }
+    asm volatile("" ::"v"(acc4.x), "v"(rayO4.x), "v"(rayD4.x), "v"(hitv.x), "v"(thr4.x), "v"(landed[0].x), "v"(landed[1].x), "v"(landed[2].x),
+                 "v"(landed[3].x), "v"(landed[4].x));   // keep the loads here: the compiler would sink each one next to its use
     const bool active = inRange && (st.z & kFlagAlive);
     const bool touched = inRange && (active || (st.w & 0xFFu) != 0u || (st.z & kFlagFlush));   // state/accum rewritten
 
@@ -495,12 +514,11 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
 
     if (touched) {
         const ClampCfg cc = clampCfg(rp);
-        const float4 acc4 = pool.accum[slot];
         acc = mk3(acc4);
         // light connections queued last bounce have been resolved by k_connect: add them in slot order
 #pragma unroll
         for (uint32_t k = 0; k < kRecSlots; ++k) {
-            if (st.w & (1u << k)) acc += mk3(pool.rec[k].a[slot]);
+            if (st.w & (1u << k)) acc += mk3(landed[k]);
         }
         if (st.z & kFlagFlush) {
             // the previous work item of this slot is complete (its last connections just landed): publish it
@@ -513,10 +531,8 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
             specDepth = (st.z >> kFlagSpecDepthShift) & kFlagFieldMask;
             mediumDepth = (st.z >> kFlagMediumShift) & 0xFu;
             lastDelta = (st.z & kFlagLastDelta) != 0u;
-            const f3 rayO = mk3(pool.rayOrg[slot]);
-            const f3 rayD = mk3(pool.rayDir[slot]);
-            const float4 hitv = pool.hit[slot];
-            const float4 thr4 = pool.throughput[slot];
+            const f3 rayO = mk3(rayO4);
+            const f3 rayD = mk3(rayD4);
             thr = mk3(thr4);
             lastPdf = thr4.w;
             const uint32_t prim = __float_as_uint(hitv.w);
