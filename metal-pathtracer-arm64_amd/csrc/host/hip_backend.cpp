@@ -131,14 +131,13 @@ struct PtrDeviceScene {
 
 namespace {
 
-// scalars: [0] shadow-queue length, [1] k_extend work head, [2] k_connect work head, [3] pad,
-//          [4..19] ring of alive counters, [20] next unclaimed work item
+// per-group scalars: [0] unused, [1] k_extend work head, [2] k_connect work head, [3] pad,
+//                    [4..19] ring of live-slot counters (one per iteration, written by k_extend at the end of a frame)
 constexpr uint32_t kAliveRing = 16;
 constexpr uint32_t kAliveBase = 4;
-constexpr uint32_t kNextItemIndex = kAliveBase + kAliveRing;
-constexpr uint32_t kScalarCount = kNextItemIndex + 1;
-constexpr uint32_t kMaxPoolGroups = 8;
-constexpr uint32_t kPinnedHeadsOffset = 16;   // pinned staging: [0..15] per-group alive counts, then kItemHeads range heads   // one block of scalars / one spill area per group
+constexpr uint32_t kScalarCount = kAliveBase + kAliveRing;
+constexpr uint32_t kMaxPoolGroups = 8;        // one block of scalars / one spill area per group
+constexpr uint32_t kPinnedHeadsOffset = 16;   // pinned staging: [0..15] per-group live-slot counts, then kItemHeads range heads
 
 // 576 B MaterialData -> the 13 float4 the integrator reads (kernels/device_types.h MaterialSlot).
 void compactMaterial(const PtrMaterial& m, std::vector<float>& out) {
@@ -479,7 +478,6 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
         pool.rec[k].b = base + 3ull * slots;
     }
     pool.itemReserve = ds.itemReserve.ptr;
-    pool.aliveCount = ds.scalars.ptr + kAliveBase;
     pool.pixelOfLocal = ds.pixelOfLocal.ptr;
     pool.counters = ds.counters.ptr;
     pool.zero = reinterpret_cast<const float4*>(ds.zeros.ptr);
@@ -534,7 +532,6 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
         gr.pool.itemReserve += first / 64u;
         gr.pool.slots = std::min(groupSlots, slots - first);
         gr.scalars = ds.scalars.ptr + static_cast<size_t>(g) * kScalarCount;
-        gr.pool.aliveCount = gr.scalars + kAliveBase;
         gr.cfg = LaunchConfig{ds.traceGrid, ds.spill.ptr + g * spillWords, gr.scalars + 1, ds.refillBelow};
         gr.stream = g == 0 ? stream : ds.groupStreams[g - 1];
         gr.done = false;

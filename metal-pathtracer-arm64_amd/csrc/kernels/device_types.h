@@ -131,7 +131,6 @@ struct PathPool {
     uint32_t* nextItem;    // [kItemHeadWords] head k at [k * kItemHeadStride]: next unclaimed item of range k (k_shade)
     ShadowRecordView rec[kRecSlots];
     uint2* itemReserve;        // [slots/64] per-wave reservation {next, end} of work items (one atomic per 64 items)
-    uint32_t* aliveCount;      // ring of alive counters (host termination check)
     const uint32_t* pixelOfLocal;  // local pixel -> y*width + x
     const float4* zero;        // one float4 of zeros: where k_shade points the loads of records that are not pending
     uint64_t* counters;        // kCounterSlots

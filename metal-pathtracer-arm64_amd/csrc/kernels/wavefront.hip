@@ -1,12 +1,14 @@
 // Wavefront path tracer kernels for MI355X (gfx950).
 //
-// One bounce = three launches over a pool of resident path slots:
-//   k_extend   closest-hit BVH traversal for every live slot                (HBM/L2 latency bound; dominant)
-//   k_shade    hit reconstruction, emission/background, light sampling, BSDF sampling, next ray or
-//              regeneration of the slot with its next sample                (ALU bound)
-//   k_connect  any-hit / light-hit rays queued by k_shade, compacted        (traversal again)
-// A slot owns pixel `lp` and the samples j, j+S, j+2S...; it accumulates into its own float4, and
-// k_resolve sums the S slots of a pixel in a fixed order — results do not depend on scheduling.
+// One bounce = three launches over a group of resident path slots (the pool is cut into groups that run concurrently
+// on separate HIP streams, csrc/host/hip_backend.cpp):
+//   k_extend   closest-hit BVH traversal for every live slot     (persistent waves; cache latency + VALU issue)
+//   k_shade    hit reconstruction, emission/background, light sampling, BSDF sampling, next ray or a new work
+//              item for the slot                                 (one thread per slot; HBM stream of the path state)
+//   k_connect  the light-connection records k_shade attached to the slots: any-hit, or closest hit + rectangle-light
+//              evaluation (specular NEE / MNEE)                  (persistent waves, like k_extend)
+// A slot renders work items (one pixel sample, or a chunk of them); every item has its own accumulator and k_resolve
+// sums a pixel's items in a fixed order — results do not depend on scheduling, pool size or partition.
 //
 // Integrator semantics and RNG consumption order follow the reference's Embree backend
 // (src/headless/EmbreeHeadlessRenderer.mm:2573-3130); the Metal twin is
