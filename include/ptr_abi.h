@@ -25,6 +25,7 @@
  *                                      SoftwareBvhAccel::rebuild (src/renderer/SceneResources.mm:2055-2259,
  *                                      src/renderer/SceneAccel.mm:23-325)
  *   ptr_trace_rays                  <- trace_scene_software closest/any hit
+ *   ptr_render_aovs                 <- first-hit albedo / normal outputs of pathtraceIntegrateKernel (denoiser inputs)
  *                                      (shaders/pathtrace.metal:2266-2382) == rtcIntersect1/rtcOccluded1
  *                                      call sites (EmbreeHeadlessRenderer.mm:2302-2433)
  *   ptr_host_*                      <- SceneManager::loadSceneFromPath (src/renderer/SceneManager.mm:677-722),
@@ -233,6 +234,14 @@ uint32_t ptr_part_band_count(uint32_t height, uint32_t part_index, uint32_t part
 int ptr_render_bands(PtrDeviceScene* scene, const PtrSettings* settings, uint32_t spp,
                      uint32_t part_index, uint32_t part_count, float* out_rgb_bands,
                      int count_traversal, PtrRenderStats* stats, char* err, size_t err_cap);
+
+/* First-hit feature buffers ("AOVs") of the whole frame, the inputs the reference gives its denoiser
+ * (shaders/pathtrace.metal:6424-6435, 9813-9815; src/renderer/Accumulation.mm:130): for every pixel the camera ray of
+ * sample `sample_index` (same jitter stream as the path tracer) is traced to its closest hit.
+ * out_albedo: width*height*4 floats {base colour rgb, 1 if hit else 0}; out_normal: width*height*4 floats
+ * {shading normal * 0.5 + 0.5, hit distance (0 on a miss)}; either may be NULL.  Row 0 = top. */
+int ptr_render_aovs(PtrDeviceScene* scene, const PtrSettings* settings, uint32_t sample_index, float* out_albedo,
+                    float* out_normal, char* err, size_t err_cap);
 
 /* Closest-hit (any_hit = 0) or occlusion (any_hit = 1) queries for a ray batch.
  * rays: n * 8 floats {ox,oy,oz,tmin,dx,dy,dz,tmax}; out: n PtrHit (any-hit: t>=0 means occluded). */

@@ -188,7 +188,7 @@ assert C.sizeof(PtrHit) == HIT_DTYPE.itemsize == 40
 # Every symbol include/ptr_abi.h declares.
 ABI_SYMBOLS = (
     "ptr_device_count", "ptr_scene_upload", "ptr_scene_release", "ptr_scene_info", "ptr_render",
-    "ptr_render_bands_device", "ptr_part_band_count", "ptr_render_bands", "ptr_trace_rays",
+    "ptr_render_bands_device", "ptr_part_band_count", "ptr_render_bands", "ptr_trace_rays", "ptr_render_aovs",
     "ptr_host_scene_load", "ptr_host_scene_free", "ptr_host_scene_desc", "ptr_host_write_image", "ptr_host_write_exr_multilayer",
     "ptr_host_read_pfm", "ptr_version",
 )
@@ -226,6 +226,7 @@ def load_library() -> C.CDLL:
     lib.ptr_part_band_count.restype = u32
     lib.ptr_render_bands.argtypes = [vp, C.POINTER(PtrSettings), u32, u32, u32, C.POINTER(C.c_float), C.c_int,
                                      C.POINTER(PtrRenderStats), cp, sz]
+    lib.ptr_render_aovs.argtypes = [vp, C.POINTER(PtrSettings), u32, C.POINTER(C.c_float), C.POINTER(C.c_float), cp, sz]
     lib.ptr_trace_rays.argtypes = [vp, C.POINTER(C.c_float), u64, C.c_int, vp, C.POINTER(PtrRenderStats), cp, sz]
     lib.ptr_host_scene_load.argtypes = [cp, cp, C.POINTER(vp), cp, sz]
     lib.ptr_host_scene_free.argtypes = [vp]
@@ -370,6 +371,14 @@ class DeviceScene:
                                            C.c_void_p(stream), int(count) | (2 if solo else 0), C.byref(stats) if want_stats else None,
                                            err, len(err)), err)
         return stats if want_stats else None
+
+    def render_aovs(self, settings: PtrSettings, sample_index: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+        """First-hit feature buffers: ([H, W, 4] albedo rgb | hit flag, [H, W, 4] encoded normal | distance)."""
+        albedo = np.zeros((settings.height, settings.width, 4), dtype=np.float32)
+        normal = np.zeros((settings.height, settings.width, 4), dtype=np.float32)
+        err = _err_buf()
+        _check(load_library().ptr_render_aovs(self._h, C.byref(settings), sample_index, _fptr(albedo), _fptr(normal), err, len(err)), err)
+        return albedo, normal
 
     def trace_rays(self, rays: np.ndarray, any_hit: bool = False) -> Tuple[np.ndarray, PtrRenderStats]:
         """rays: [n, 8] float32 {ox,oy,oz,tmin,dx,dy,dz,tmax}; returns a structured array of PtrHit."""

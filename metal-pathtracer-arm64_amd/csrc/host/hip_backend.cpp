@@ -848,6 +848,34 @@ int ptr_trace_rays(PtrDeviceScene* scene, const float* rays, uint64_t n, int any
     }
 }
 
+int ptr_render_aovs(PtrDeviceScene* scene, const PtrSettings* settings, uint32_t sample_index, float* out_albedo, float* out_normal,
+                    char* err, size_t err_cap) {
+    if (!scene || !settings) {
+        setErr(err, err_cap, "ptr_render_aovs: null argument");
+        return 1;
+    }
+    try {
+        if (settings->width == 0 || settings->height == 0) throw HipError{"render size must be non-zero"};
+        HIP_CHECK(hipSetDevice(scene->device));
+        RenderParams rp;
+        fillRenderParams(*settings, 1u, rp);
+        const size_t pixels = static_cast<size_t>(settings->width) * settings->height;
+        DeviceBuffer<float4> albedo, normal;
+        albedo.ensure(pixels);
+        normal.ensure(pixels);
+        LaunchConfig cfg{scene->traceGrid, scene->spill.ptr, scene->scalars.ptr + 1, scene->refillBelow};
+        launchAovs(rp, scene->view, sample_index, albedo.ptr, normal.ptr, cfg, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        if (out_albedo) HIP_CHECK(hipMemcpy(out_albedo, albedo.ptr, pixels * sizeof(float4), hipMemcpyDeviceToHost));
+        if (out_normal) HIP_CHECK(hipMemcpy(out_normal, normal.ptr, pixels * sizeof(float4), hipMemcpyDeviceToHost));
+        return 0;
+    } catch (const HipError& e) {
+        setErr(err, err_cap, e.message);
+        return 1;
+    }
+}
+
 // ---- test-only entry points (include/ptr_debug.h) ----
 
 int ptr_debug_eval_bsdf(const PtrMaterial* material, const PtrSettings* settings, const float* in, uint64_t n, float* out,

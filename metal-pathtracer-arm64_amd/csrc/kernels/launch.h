@@ -36,6 +36,10 @@ void launchResolve(const RenderParams& rp, const PathPool& pool, uint32_t partCo
 void launchTraceRays(const SceneView& sc, const float4* dRays, uint64_t n, bool anyHit, PtrHit* dOut, const LaunchConfig& cfg,
                      uint64_t* dCounters, hipStream_t stream);
 
+// First-hit feature buffers for every pixel of the frame (row 0 = top): albedo rgb|hit flag, encoded normal|distance.
+void launchAovs(const RenderParams& rp, const SceneView& sc, uint32_t sample, float4* dAlbedo, float4* dNormal, const LaunchConfig& cfg,
+                hipStream_t stream);
+
 // Debug / known-answer kernels (tests only): evaluate and sample a material for a batch of inputs.
 void launchDebugEvalBsdf(const float4* dMaterial, const RenderParams& rp, const float* dIn, uint64_t n, float* dOut,
                          hipStream_t stream);

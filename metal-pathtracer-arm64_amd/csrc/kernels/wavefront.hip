@@ -1139,6 +1139,43 @@ __global__ void __launch_bounds__(256) k_resolve(RenderParams rp, PathPool pool,
 }
 
 // =====================================================================================================
+// k_aovs: first-hit feature buffers (what the reference hands to its denoiser: shaders/pathtrace.metal:6424-6435 sets
+// albedo = material base colour and normal = shading normal at the first hit; 9813-9815 writes albedo and
+// normal*0.5+0.5 per pixel).  One camera ray per pixel, the one sample `sample` of the path tracer starts with.
+// albedo.w = 1 on a hit, 0 on a miss; normal.w = hit distance (0 on a miss).
+// =====================================================================================================
+__global__ void __launch_bounds__(kTraceBlock) k_aovs(RenderParams rp, SceneView sc, uint32_t sample, float4* albedo, float4* normal, uint32_t* spill,
+                                                       uint32_t spillStride) {
+    __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
+    const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
+    LaneStack stack;
+    stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
+    stack.spill = spill;
+    stack.spillStride = spillStride;
+    TraceCounters cnt{0u, 0u};
+    const uint32_t pixels = rp.width * rp.height;
+    for (uint32_t pixel = gtid; pixel < pixels; pixel += gridDim.x * kTraceBlock) {
+        uint32_t rng;
+        f3 org, dir;
+        beginSample(rp, pixel, sample, rng, org, dir);
+        const TraceHit h = traverse<false, false>(sc, org, dir, kEps, INFINITY, stack, cnt);
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n = make_float4(0.5f, 0.5f, 0.5f, 0.0f);
+        if (h.prim != kHitMiss && sc.materialCount > 0u) {
+            const Surface sf = reconstruct(sc, org, dir, h.t, h.u, h.v, h.prim);
+            const Mat mat{sc.materials + static_cast<size_t>(min(sf.material, sc.materialCount - 1u)) * kMaterialVec4};
+            f3 sn = sf.hitShadingNormal;
+            if (dot(sn, sn) <= 0.0f) sn = sf.normal;
+            if (mat.type() == 2u) sn = sf.normal;
+            sn = normalize(sn);
+            a = mk4(mat.baseColor(), 1.0f);
+            n = mk4(sn * 0.5f + mk3(0.5f), h.t);
+        }
+        albedo[pixel] = a;
+        normal[pixel] = n;
+    }
+}
+
+// =====================================================================================================
 // k_trace_rays: ray-batch queries for ptr_trace_rays (parity tests against the oracle ray caster)
 // =====================================================================================================
 template <bool ANY>
@@ -1304,6 +1341,14 @@ void launchTraceRays(const SceneView& sc, const float4* dRays, uint64_t n, bool 
     } else {
         hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid), dim3(kTraceBlock), 0, stream, sc, dRays, n, dOut, cfg.spill, stride, dCounters);
     }
+}
+
+void launchAovs(const RenderParams& rp, const SceneView& sc, uint32_t sample, float4* dAlbedo, float4* dNormal, const LaunchConfig& cfg,
+                hipStream_t stream) {
+    const uint32_t pixels = rp.width * rp.height;
+    const uint32_t stride = cfg.traceGrid * kTraceBlock;
+    const uint32_t grid = std::min(cfg.traceGrid, std::max(1u, ceilDiv(pixels, kTraceBlock)));
+    hipLaunchKernelGGL(k_aovs, dim3(grid), dim3(kTraceBlock), 0, stream, rp, sc, sample, dAlbedo, dNormal, cfg.spill, stride);
 }
 
 void launchDebugEvalBsdf(const float4* dMaterial, const RenderParams& rp, const float* dIn, uint64_t n, float* dOut, hipStream_t stream) {

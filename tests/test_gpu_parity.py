@@ -312,6 +312,29 @@ def test_metal_media_semantics(tmp_path):
     assert np.allclose(centre, (1 - fr) ** 4 * np.exp(-2.0 * np.array([0.30, 0.10, 0.02])) + fr * fr, rtol=0.02), centre
 
 
+def test_first_hit_aovs(materials_scene):
+    # denoiser inputs: albedo = base colour of the first hit, normal = shading normal * 0.5 + 0.5, distance in normal.w
+    host, dev, osc = materials_scene
+    s = host.settings_for(width=96, height=64, max_depth=4, seed=1337, cameraDefocusAngle=0.0)
+    albedo, normal = dev.render_aovs(s, 0)
+    xs, ys = np.meshgrid(np.arange(96, dtype=np.uint32), np.arange(64, dtype=np.uint32))
+    xys = np.stack([xs.ravel(), ys.ravel(), np.zeros(96 * 64, np.uint32)], axis=1)
+    rays, _ = pt.debug_camera_rays(s, xys)                       # the same jittered camera rays, sample 0
+    batch = np.concatenate([rays[:, :3], np.full((len(rays), 1), 1e-4, np.float32), rays[:, 3:], np.full((len(rays), 1), np.inf, np.float32)], axis=1)
+    hits = osc.trace_rays(batch.astype(np.float32), any_hit=False)
+    hit = (hits["t"] >= 0).reshape(64, 96)
+    assert np.array_equal(albedo[..., 3] > 0.5, hit) and hit.mean() > 0.5
+    assert np.array_equal(normal[..., 3][hit], hits["t"].reshape(64, 96)[hit])        # same closest hit, bit for bit
+    assert np.allclose(normal[..., :3][~hit], 0.5) and (albedo[..., :3][~hit] == 0).all()
+    n = normal[..., :3][hit] * 2.0 - 1.0
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-4)
+    # every albedo is the base colour of one of the scene's materials
+    d = host.desc
+    table = np.array([list(d.materials[i].baseColorRoughness)[:3] for i in range(d.materialCount)], np.float32).clip(0, 1)
+    dist = np.abs(albedo[..., :3][hit][:, None, :] - table[None]).max(axis=2).min(axis=1)
+    assert dist.max() < 1e-6
+
+
 def test_gradient_sky_and_thin_lens(materials_scene):
     host, dev, osc = materials_scene
     _image_parity(host, dev, osc, 64, 48, 5, 1, 16, 0.90, backgroundMode=0, cameraDefocusAngle=1.5, cameraFocusDistance=8.0)
