@@ -105,7 +105,7 @@ struct PtrDeviceScene {
     DeviceBuffer<float4> rayOrg, rayDir, hit, throughput, accum, recBuf, itemAccum;
     uint64_t poolSlots = 16ull << 20;
     uint32_t poolGroups = 4;
-    uint32_t feederChunk = 256, feederChunkSparse = 2048;   // slots per work-head atomic: full pool / mostly dead pool   // the pool is split into this many independent groups, one HIP stream each
+    uint32_t feederChunk = 256, feederChunkSparse = 4096;   // slots per work-head atomic: full pool / mostly dead pool   // the pool is split into this many independent groups, one HIP stream each
     std::vector<hipStream_t> groupStreams;   // streams of groups 1.. (group 0 runs on the caller's stream)
     std::vector<hipEvent_t> groupEvents;
     int refillBelow = 40;
@@ -495,7 +495,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
         hipStream_t stream;
         uint32_t* scalars;
         bool done;
-        bool sparse;   // few live slots left (end of the frame)
+        uint32_t feederChunk;   // slots per work-head atomic; grows as the group drains at the end of the frame
     };
     uint32_t groupCount = std::min<uint32_t>(soloGroup ? 1u : ds.poolGroups, std::max<uint32_t>(1u, slots >> 20));   // >= 1 Mi slots per group
     const uint32_t groupSlots = ((slots + groupCount - 1u) / groupCount + 255u) & ~255u;
@@ -535,7 +535,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
         gr.cfg = LaunchConfig{ds.traceGrid, ds.spill.ptr + g * spillWords, gr.scalars + 1, ds.refillBelow};
         gr.stream = g == 0 ? stream : ds.groupStreams[g - 1];
         gr.done = false;
-        gr.sparse = false;
+        gr.feederChunk = ds.feederChunk;
     }
 
     const bool timed = stats != nullptr;
@@ -543,6 +543,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     struct Span {
         hipEvent_t a, b;
         int kind;
+        const void* stream;
     };
     std::vector<Span> spans;
     auto timedLaunch = [&](int kind, hipStream_t st, auto&& fn) {
@@ -551,7 +552,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
             HIP_CHECK(hipEventRecord(a, st));
             fn();
             HIP_CHECK(hipEventRecord(b, st));
-            spans.push_back({a, b, kind});
+            spans.push_back({a, b, kind, st});
         } else {
             fn();
         }
@@ -594,7 +595,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
         for (Group& gr : groups) {
             if (gr.done) continue;
             uint32_t* aliveSlot = gr.scalars + kAliveBase + ring;
-            gr.cfg.feederChunk = gr.sparse ? ds.feederChunkSparse : ds.feederChunk;
+            gr.cfg.feederChunk = gr.feederChunk;
             // work heads and the next live-slot counter are cleared by k_shade (all zero at the start of the frame)
             const ShadeResets resets{gr.scalars + 1, gr.scalars + 2, gr.scalars + kAliveBase + (ring + 1u) % kAliveRing};
             timedLaunch(0, gr.stream, [&] { launchExtend(ds.view, gr.pool, gr.cfg, queueDry ? aliveSlot : nullptr, count, gr.stream); });
@@ -622,8 +623,10 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
                 HIP_CHECK(hipStreamSynchronize(gr.stream));
                 if (queueDry) {
                     if (ds.pinnedAlive[g] == 0u) gr.done = true;
-                    // fewer than 1 live slot in 8: claim the work list in bigger chunks (see WaveFeeder)
-                    gr.sparse = ds.pinnedAlive[g] < gr.pool.slots / 8u;
+                    // the fewer live slots, the bigger the chunks the work list is claimed in (see WaveFeeder): a chunk
+                    // should still hold about as many live slots as a full one does when the pool is full
+                    const uint32_t thin = gr.pool.slots / std::max(ds.pinnedAlive[g], 1u);
+                    gr.feederChunk = std::min(ds.feederChunkSparse, ds.feederChunk * std::max(thin, 1u));
                 }
                 allDone = allDone && gr.done;
             }
@@ -669,7 +672,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
                 float t0 = 0.0f, t1 = 0.0f;
                 HIP_CHECK(hipEventElapsedTime(&t0, spans.front().a, s.a));
                 HIP_CHECK(hipEventElapsedTime(&t1, spans.front().a, s.b));
-                std::fprintf(stderr, "[launch] kind %d  start %.3f  end %.3f  (%.3f ms)\n", s.kind, t0, t1, t1 - t0);
+                std::fprintf(stderr, "[launch] kind %d  start %.3f  end %.3f  (%.3f ms)  stream %p\n", s.kind, t0, t1, t1 - t0, s.stream);
             }
         }
         for (const Span& s : spans) {

@@ -54,7 +54,20 @@ def main():
             print("it %3d start %8.2f  extend %.3f  shade %.3f  connect %.3f  iteration %.3f" %
                   (i // 3, float(e[1]), float(e[3]), float(s[3]), float(c[3]), float(c[2]) - float(e[1])))
     else:
-        print("(set PTR_POOL_GROUPS=1 for a per-iteration table; last launch ended at %.2f ms)" % max(float(x[2]) for x in rows))
+        # several groups: how much of the frame had at least one / exactly k kernels running
+        ev = sorted([(float(x[1]), 1) for x in rows] + [(float(x[2]), -1) for x in rows])
+        busy = {}
+        level, last = 0, ev[0][0]
+        for t, d in ev:
+            busy[level] = busy.get(level, 0.0) + (t - last)
+            level, last = level + d, t
+        end = max(float(x[2]) for x in rows)
+        print("last launch ended at %.2f ms; time with k kernels in flight: %s" %
+              (end, ", ".join("%d: %.2f ms" % (k, v) for k, v in sorted(busy.items()))))
+        names = {0: "extend", 1: "shade", 2: "connect"}
+        for kind in (0, 1, 2):
+            d = [float(x[3]) for x in rows if int(x[0]) == kind]
+            print("  %-8s %4d launches, sum %.2f ms, mean %.3f ms" % (names[kind], len(d), sum(d), sum(d) / max(len(d), 1)))
 
 
 if __name__ == "__main__":
