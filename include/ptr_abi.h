@@ -158,11 +158,15 @@ typedef struct PtrSettings {
      * thin-walled dielectrics (typeEta.w > 0.5) keep etaI = 1 on both faces and never enter a medium (:4589-4592,
      * 5649-5659, 5683).  Bit 2 (PTR_METAL_FACE_NORMAL): dielectrics are shaded with the geometric normal turned
      * towards the incoming ray (set_face_normal, :1187-1191); the Embree backend passes the unflipped normal
-     * (EmbreeHeadlessRenderer.mm:2333-2339, 2641-2644), which sends a ray that tries to leave a glass body back inside. */
+     * (EmbreeHeadlessRenderer.mm:2333-2339, 2641-2644), which sends a ray that tries to leave a glass body back inside.
+     * Bit 3 (PTR_METAL_SPECULAR): rough metals (type 1) sample the distribution of visible normals, use the pdf
+     * D*G1*cos(h)/(4 wo.wh) and scale the lobe by the multiple-scattering energy compensation (:3724-3739, 3770-3797,
+     * 4610-4630, 5000-5023, 5228-5283); the Embree backend samples half vectors with pdf D*cos(h)/(4 wo.wh) and has no
+     * compensation.  The PBR model's Metal variant (three lobes, textures) is not covered. */
     uint32_t metalSemantics;
 } PtrSettings;
 
-enum { PTR_METAL_MEDIA = 1u, PTR_METAL_THIN = 2u, PTR_METAL_FACE_NORMAL = 4u };
+enum { PTR_METAL_MEDIA = 1u, PTR_METAL_THIN = 2u, PTR_METAL_FACE_NORMAL = 4u, PTR_METAL_SPECULAR = 8u };
 
 typedef struct PtrRenderStats {
     double totalSeconds;                /* integrate phase only (reference: out.totalSeconds) */

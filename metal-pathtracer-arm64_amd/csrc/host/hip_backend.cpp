@@ -350,7 +350,7 @@ void fillRenderParams(const PtrSettings& s, uint32_t spp, RenderParams& rp) {
     rp.minSpecularPdf = std::max(s.minSpecularPdf, 1.0e-8f);
     rp.clampEnabled = s.fireflyClampEnabled ? 1.0f : 0.0f;
     rp.emissionScale = (s.emissionScale > 0.0f && std::isfinite(s.emissionScale)) ? s.emissionScale : 1.0f;
-    rp.mediaMode = s.metalSemantics & (PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL);
+    rp.mediaMode = s.metalSemantics & (PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL | PTR_METAL_SPECULAR);
 }
 
 // Local pixel order of a partition: its 16-row bands top to bottom, each walked in 8x8 blocks so the

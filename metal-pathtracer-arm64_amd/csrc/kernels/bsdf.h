@@ -15,6 +15,7 @@ struct ClampCfg {
     float factor, floorLum, throughput, tailBase, tailRoughScale, minSpecPdf;
     bool enabled;
     bool thinDielectrics;   // PTR_METAL_THIN: honour the thin-walled flag of dielectrics (Metal semantics)
+    bool metalSpecular;     // PTR_METAL_SPECULAR: VNDF sampling, G1 pdf and energy compensation for rough metals
 };
 
 __device__ __forceinline__ uint32_t rngHash(uint32_t x) {  // lowbias32
@@ -180,6 +181,34 @@ __device__ __forceinline__ float ggxPdf(float alpha, f3 n, f3 wo, f3 wi) {
     const float cosH = dot(n, wh);
     const float denom = 4.0f * smax(dot(wo, wh), 1.0e-6f);
     return ggxD(alpha, smax(cosH, 0.0f)) * smax(cosH, 0.0f) / denom;
+}
+
+// Metal-only (PTR_METAL_SPECULAR): pdf of reflecting a VNDF-sampled half vector, shaders/pathtrace.metal:3724-3739
+__device__ __forceinline__ float ggxPdfVisible(float alpha, f3 n, f3 wo, f3 wi) {
+    const f3 wh = normalize(wo + wi);
+    const float cosH = dot(n, wh), woh = dot(wo, wh), cosO = dot(n, wo);
+    if (cosO <= 0.0f || cosH <= 0.0f || woh <= 0.0f) return 0.0f;
+    return ggxD(alpha, cosH) * ggxG1(alpha, cosO) * cosH / (4.0f * smax(woh, 1.0e-6f));
+}
+
+// Metal-only: multiple-scattering compensation of a specular lobe, shaders/pathtrace.metal:4610-4630
+__device__ __forceinline__ f3 specularEnergyCompensation(f3 f0, float roughness, float nov) {
+    const float n = clampf(nov, 0.0f, 1.0f);
+    const float rx = roughness * -1.0f + 1.0f, ry = roughness * -0.0275f + 0.0425f;
+    const float rz = roughness * -0.572f + 1.04f, rw = roughness * 0.022f + -0.04f;
+    const float a004 = smin(rx * rx, exp2f(-9.28f * n)) * rx + ry;
+    const float dfgX = -1.04f * a004 + rz, dfgY = 1.04f * a004 + rw;
+    float out[3];
+    const float f[3] = {f0.x, f0.y, f0.z};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float fss = clampf(f[c] * dfgX + dfgY, 0.0f, 0.99f);
+        const float favg = f[c] + (1.0f - f[c]) * (1.0f / 21.0f);
+        const float oneMinus = clampf(1.0f - fss, 0.0f, 1.0f);
+        const float fms = (favg * oneMinus) / smax(1.0f - favg * oneMinus, 1.0e-3f);
+        out[c] = clampf((fss + fms) / smax(fss, 1.0e-4f), 1.0f, 2.0f);
+    }
+    return mk3(out[0], out[1], out[2]);
 }
 
 __device__ __forceinline__ f3 sampleGgxHalf(uint32_t& rng, float alpha, f3 n) {
@@ -556,8 +585,9 @@ __device__ BsdfEvalResult evalBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 wi
             if (!halfOk(wh, n, wo, wi)) return r;
             const Conductor c = loadMetal(m);
             f3 spec = microfacet(conductorF(c, dot(wi, wh)), alpha, n, wh, cosO, cosI);
+            if (cc.metalSpecular) spec = spec * specularEnergyCompensation(c.f0, rough, cosO);
             spec = clampSpecTail(spec, rough, c.f0, cc);
-            const float pdf = ggxPdf(alpha, n, wo, wi);
+            const float pdf = cc.metalSpecular ? ggxPdfVisible(alpha, n, wo, wi) : ggxPdf(alpha, n, wo, wi);
             if (pdf > 0.0f) {
                 r.value = vmax0(spec);
                 r.pdf = clampSpecPdf(pdf, cc);
@@ -673,7 +703,7 @@ __device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f
                 return r;
             }
             const float alpha = rough * rough;
-            const f3 wh = sampleGgxHalf(rng, alpha, n);
+            const f3 wh = cc.metalSpecular ? sampleGgxVndf(rng, rough, n, wo) : sampleGgxHalf(rng, alpha, n);
             if (dot(wh, n) <= 0.0f) return r;
             const f3 wi = normalize(reflectDir(-wo, wh));
             const float cosI = dot(n, wi), cosO = dot(n, wo);
@@ -684,8 +714,9 @@ __device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f
             const float D = ggxD(alpha, dot(n, wh));
             const float G = ggxG1(alpha, cosO) * ggxG1(alpha, cosI);
             f3 f = F * (D * G / smax(4.0f * cosO * cosI, 1.0e-6f));
+            if (cc.metalSpecular) f = f * specularEnergyCompensation(c.f0, rough, cosO);
             f = clampSpecTail(f, rough, c.f0, cc);
-            const float pdf = D * smax(dot(n, wh), 0.0f) / smax(4.0f * woh, 1.0e-6f);
+            const float pdf = cc.metalSpecular ? ggxPdfVisible(alpha, n, wo, wi) : D * smax(dot(n, wh), 0.0f) / smax(4.0f * woh, 1.0e-6f);
             if (pdf <= 0.0f) return r;
             const float pdfC = clampSpecPdf(pdf, cc);
             const f3 w = f * cosI / pdfC;

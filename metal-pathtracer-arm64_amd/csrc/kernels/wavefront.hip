@@ -46,6 +46,7 @@ __device__ __forceinline__ ClampCfg clampCfg(const RenderParams& rp) {
     c.minSpecPdf = rp.minSpecularPdf;
     c.enabled = rp.clampEnabled >= 0.5f;
     c.thinDielectrics = (rp.mediaMode & PTR_METAL_THIN) != 0u;
+    c.metalSpecular = (rp.mediaMode & PTR_METAL_SPECULAR) != 0u;
     return c;
 }
 

@@ -220,6 +220,31 @@ float ggxPdf(float alpha, V3 normal, V3 wo, V3 wi) {  // half-vector pdf, no G1 
     return d * std::max(cosThetaH, 0.0f) / denom;
 }
 
+// Metal-only (PTR_METAL_SPECULAR): pdf of reflecting a VNDF-sampled half vector, shaders/pathtrace.metal:3724-3739
+float ggxPdfVisible(float alpha, V3 normal, V3 wo, V3 wi) {
+    const V3 wh = normalize(wo + wi);
+    const float cosThetaH = dot(normal, wh), dotWoWh = dot(wo, wh), cosThetaO = dot(normal, wo);
+    if (cosThetaO <= 0.0f || cosThetaH <= 0.0f || dotWoWh <= 0.0f) return 0.0f;
+    return ggxDistribution(alpha, cosThetaH) * ggxG1(alpha, cosThetaO) * cosThetaH / (4.0f * std::max(dotWoWh, 1.0e-6f));
+}
+
+// Metal-only: multiple-scattering compensation of a specular lobe, shaders/pathtrace.metal:4610-4630
+V3 specularEnergyCompensation(V3 f0, float roughness, float nov) {
+    const float n = clampf(nov, 0.0f, 1.0f);
+    const float rx = roughness * -1.0f + 1.0f, ry = roughness * -0.0275f + 0.0425f;
+    const float rz = roughness * -0.572f + 1.04f, rw = roughness * 0.022f + -0.04f;
+    const float a004 = std::min(rx * rx, std::exp2(-9.28f * n)) * rx + ry;
+    const float dfgX = -1.04f * a004 + rz, dfgY = 1.04f * a004 + rw;
+    auto channel = [&](float f) {
+        const float fss = clampf(f * dfgX + dfgY, 0.0f, 0.99f);
+        const float favg = f + (1.0f - f) * (1.0f / 21.0f);
+        const float oneMinus = clampf(1.0f - fss, 0.0f, 1.0f);
+        const float fms = (favg * oneMinus) / std::max(1.0f - favg * oneMinus, 1.0e-3f);
+        return clampf((fss + fms) / std::max(fss, 1.0e-4f), 1.0f, 2.0f);
+    };
+    return V3(channel(f0.x), channel(f0.y), channel(f0.z));
+}
+
 V3 sampleGgxHalfVector(Rng& rng, float alpha, V3 n) {  // E:579-590
     const float u1 = rng.nextFloat();
     const float u2 = rng.nextFloat();
@@ -697,6 +722,7 @@ ClampParams makeClampParams(const PtrSettings& s) {  // E:381-391
     p.minSpecularPdf = std::max(s.minSpecularPdf, 1.0e-8f);
     p.enabled = s.fireflyClampEnabled ? 1.0f : 0.0f;
     p.thinDielectrics = (s.metalSemantics & PTR_METAL_THIN) != 0u;   // Metal-only semantics, off on the Embree path
+    p.metalSpecular = (s.metalSemantics & PTR_METAL_SPECULAR) != 0u;
     return p;
 }
 
@@ -806,8 +832,9 @@ BsdfEval evaluateBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 wi
         if (!halfVectorUsable(wh, normal, wo, wi)) return r;
         const V3 f0 = conductorF0(m);
         V3 spec = specTerm(metalFresnel(m, f0, dot(wi, wh)), alpha, normal, wh, cosO, cosI);
+        if (cp.metalSpecular) spec = spec * specularEnergyCompensation(f0, roughness, cosO);   // M:5011
         spec = clampSpecularTail(spec, roughness, f0, cp);
-        const float pdf = ggxPdf(alpha, normal, wo, wi);
+        const float pdf = cp.metalSpecular ? ggxPdfVisible(alpha, normal, wo, wi) : ggxPdf(alpha, normal, wo, wi);
         if (pdf > 0.0f) {
             r.value = vmax(spec, V3());
             r.pdf = clampSpecularPdf(pdf, cp);
@@ -944,7 +971,8 @@ BsdfSample sampleBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 in
             return r;
         }
         const float alpha = roughness * roughness;
-        const V3 wh = sampleGgxHalfVector(rng, alpha, normal);
+        // Metal-only: visible-normal sampling (M:5228), otherwise plain half-vector sampling
+        const V3 wh = cp.metalSpecular ? sampleGgxVndf(rng, roughness, normal, wo) : sampleGgxHalfVector(rng, alpha, normal);
         if (dot(wh, normal) <= 0.0f) return r;
         const V3 wi = normalize(reflect(-wo, wh));
         const float cosI = dot(normal, wi);
@@ -957,8 +985,10 @@ BsdfSample sampleBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 in
         const float G = ggxG1(alpha, cosO) * ggxG1(alpha, cosI);
         const float denom = 4.0f * cosO * cosI;
         V3 f = F * (D * G / std::max(denom, 1.0e-6f));
+        if (cp.metalSpecular) f = f * specularEnergyCompensation(f0, roughness, cosO);   // M:5262
         f = clampSpecularTail(f, roughness, f0, cp);
-        const float pdf = D * std::max(dot(normal, wh), 0.0f) / std::max(4.0f * dotWoWh, 1.0e-6f);
+        const float pdf = cp.metalSpecular ? ggxPdfVisible(alpha, normal, wo, wi)
+                                           : D * std::max(dot(normal, wh), 0.0f) / std::max(4.0f * dotWoWh, 1.0e-6f);
         if (pdf <= 0.0f) return r;
         const float clampedPdf = clampSpecularPdf(pdf, cp);
         const V3 weight = f * cosI / clampedPdf;

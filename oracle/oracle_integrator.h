@@ -74,6 +74,7 @@ struct ClampParams {  // FireflyClampParams, :136-144
     float specularTailClampBase = 0.0f, specularTailClampRoughnessScale = 0.0f;
     float minSpecularPdf = 1.0e-8f, enabled = 0.0f;
     bool thinDielectrics = false;   // PTR_METAL_THIN (Metal-only semantics, shaders/pathtrace.metal:4589-4592, 5649-5659)
+    bool metalSpecular = false;     // PTR_METAL_SPECULAR: VNDF sampling, G1 pdf, energy compensation for rough metals
 };
 
 struct BsdfEval {

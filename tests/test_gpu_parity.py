@@ -312,6 +312,34 @@ def test_metal_media_semantics(tmp_path):
     assert np.allclose(centre, (1 - fr) ** 4 * np.exp(-2.0 * np.array([0.30, 0.10, 0.02])) + fr * fr, rtol=0.02), centre
 
 
+def test_metal_specular_semantics(materials_scene):
+    # PTR_METAL_SPECULAR: rough metals with VNDF sampling, the G1 pdf and energy compensation (Metal formulas, restated in
+    # the oracle too): device functions and images agree with the oracle, and differ from the Embree-parity mode
+    host, dev, osc = materials_scene
+    _image_parity(host, dev, osc, 96, 64, 6, 1, 32, 0.88, metalSemantics=8)
+    s0 = host.settings_for(width=96, height=64, max_depth=6, seed=1337)
+    s8 = s0.copy()
+    s8.metalSemantics = 8
+    assert _rmse(dev.render_image(s0, 32)[0], dev.render_image(s8, 32)[0]) > 0.005
+    d = host.desc
+    rough = [i for i in range(d.materialCount) if int(d.materials[i].typeEta[0]) == 1 and d.materials[i].baseColorRoughness[3] > 0.05]
+    assert rough
+    rng = np.random.default_rng(3)
+    n = 3000
+    wo = rng.normal(size=(n, 3))
+    wo[:, 2] = np.abs(wo[:, 2]) + 0.1
+    wo = (wo / np.linalg.norm(wo, axis=1, keepdims=True)).astype(np.float32)
+    inp = np.concatenate([np.zeros((n, 3), np.float32), np.tile(np.array([0, 0, 1], np.float32), (n, 1)), wo], axis=1)
+    states = rng.integers(1, 2**32 - 1, size=n, dtype=np.uint64).astype(np.uint32)
+    front = np.ones(n, dtype=np.uint32)
+    g, gs = pt.debug_sample_bsdf(d.materials[rough[0]], s8, inp, front, states)
+    o, os_ = ol.sample_bsdf(d.materials[rough[0]], s8, inp, front, states)
+    assert np.array_equal(gs, os_)
+    both = (g[:, 6] > 0) & (o[:, 6] > 0)
+    assert both.mean() > 0.75 and np.array_equal(g[:, 6] > 0, o[:, 6] > 0)
+    assert np.allclose(g[both, :3], o[both, :3], atol=2e-4) and np.allclose(g[both, 3:7], o[both, 3:7], rtol=2e-3, atol=1e-4)
+
+
 def test_first_hit_aovs(materials_scene):
     # denoiser inputs: albedo = base colour of the first hit, normal = shading normal * 0.5 + 0.5, distance in normal.w
     host, dev, osc = materials_scene
