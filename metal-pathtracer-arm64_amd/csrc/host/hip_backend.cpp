@@ -700,6 +700,14 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
             stats->shadedHits = c[kCntShadedHits];
             stats->triangleHits = c[kCntTriangleHits];
             stats->shadowEarlyExits = c[kCntShadowEarlyExit];
+            if (std::getenv("PTR_TRACE_STEPS")) {   // lane utilisation of k_extend's step loop (counting build)
+                const double nodeLanes = static_cast<double>(c[kCntExtendNodes] - c[kCntExtendLeaves]), primLanes = static_cast<double>(c[kCntExtendPrims]);
+                const double nodeSlots = static_cast<double>(c[kCntExtendWaveNodeSteps]), primSlots = static_cast<double>(c[kCntExtendWavePrimSteps]);
+                std::fprintf(stderr, "[steps] k_extend: %.3g rays; node steps %.3g lane / %.3g slots = %.3f; prim steps %.3g lane / %.3g slots = %.3f; "
+                                     "refill passes %.3g (x64 lanes)\n",
+                             static_cast<double>(c[kCntExtendRays]), nodeLanes, nodeSlots, nodeLanes / std::max(nodeSlots, 1.0), primLanes, primSlots,
+                             primLanes / std::max(primSlots, 1.0), static_cast<double>(c[kCntExtendRefillPasses]));
+            }
         }
     }
 }

@@ -160,6 +160,10 @@ enum CounterSlot : uint32_t {
     kCntPrimaryRays = 8,
     kCntShadowEarlyExit = 9,
     kCntStackOverflow = 10,
+    kCntExtendLeaves = 11,          // k_extend only, counting build: lane-utilisation bookkeeping (PTR_TRACE_STEPS)
+    kCntExtendWaveNodeSteps = 12,   // 64 x node steps executed by waves
+    kCntExtendWavePrimSteps = 13,   // 64 x primitive steps executed by waves
+    kCntExtendRefillPasses = 14,    // 64 x refill passes
     kCounterSlots = 16,
 };
 

@@ -21,6 +21,9 @@ namespace ptrk {
 struct TraceCounters {
     uint32_t nodes;   // internal nodes fetched + leaves visited (== "nodes popped" of a reference-layout BVH)
     uint32_t prims;   // primitive tests
+    // counting build only, lane-utilisation bookkeeping: steps the WAVE executed (every lane counts them, so the wave sum
+    // is 64 x the number of steps) and leaves this lane entered
+    uint32_t waveNodeSteps = 0, wavePrimSteps = 0, leaves = 0;
 };
 
 // LDS words are addressed through an address-space-3 pointer so the stack always compiles to ds_read/ds_write
@@ -249,7 +252,7 @@ __device__ __forceinline__ bool travPrimStep(const SceneView& sc, const SceneMem
     const uint32_t first = cur & kRefOffsetMask;
     const uint32_t count = ((cur >> kRefCountShift) & 0xFu) + 1u;
     const uint32_t index = first + t.leafPos;
-    if (COUNT) { ++cnt.prims; if (t.leafPos == 0u) ++cnt.nodes; }
+    if (COUNT) { ++cnt.prims; if (t.leafPos == 0u) { ++cnt.nodes; ++cnt.leaves; } }
     if (cur & kRefSphereBit) {
         float tt;
         if (sphereTest(sc.spheres[index], t.org, t.dir, t.tnear, t.hit.t, tt)) {
@@ -293,6 +296,7 @@ __device__ __forceinline__ bool travVote(const SceneView& sc, const SceneMem& me
     const int nNode = __popcll(__ballot(wantsNode));
     bool more = true;
     if (nNode >= nPrim) {
+        if (COUNT) ++cnt.waveNodeSteps;
         if (wantsNode) more = travNodeStep<COUNT>(sc, mem, t, stack, cnt);
         // further node steps without another vote while most of these lanes land on an internal node again (the vote -
         // two ballots, two popcounts, the branch - costs about a fifth of a step)
@@ -300,14 +304,17 @@ __device__ __forceinline__ bool travVote(const SceneView& sc, const SceneMem& me
         for (int extra = 0; extra < PTR_EXTRA_NODE_STEPS; ++extra) {
             const bool again = wantsNode && more && !travAtLeaf(t);
             if (__popcll(__ballot(again)) * 2 < nNode) break;
+            if (COUNT) ++cnt.waveNodeSteps;
             if (again) more = travNodeStep<COUNT>(sc, mem, t, stack, cnt);
         }
     } else {
+        if (COUNT) ++cnt.wavePrimSteps;
         if (wantsPrim) more = travPrimStep<COUNT>(sc, mem, t, stack, cnt);
 #pragma unroll
         for (int extra = 0; extra < PTR_EXTRA_PRIM_STEPS; ++extra) {
             const bool again = wantsPrim && more && travAtLeaf(t);
             if (__popcll(__ballot(again)) * 2 < nPrim) break;
+            if (COUNT) ++cnt.wavePrimSteps;
             if (again) more = travPrimStep<COUNT>(sc, mem, t, stack, cnt);
         }
     }

@@ -410,6 +410,7 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
     TraceCounters cnt{0u, 0u};
     uint32_t rays = 0u;
     uint32_t aliveSeen = 0u;   // live slots this wave picked up (host termination check, end of the frame only)
+    uint32_t refills = 0u;     // counting build: refill passes of this wave
 
     const SceneMem mem = sceneMem(sc);
     WaveFeeder feeder;
@@ -421,6 +422,7 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
     while (true) {
         const int nActive = __popcll(__ballot(active));
         if (nActive < kRefillBelow && !feeder.exhausted) {
+            if (COUNT) ++refills;
             const uint32_t idx = feeder.take(!active);
             const bool live = idx != WaveFeeder::kNone && (pool.state[idx].z & kFlagAlive);
             if (ALIVE) aliveSeen += static_cast<uint32_t>(__popcll(__ballot(live)));   // wave-uniform: stays in an SGPR
@@ -447,6 +449,10 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
         addCounter(pool.counters, kCntExtendRays, rays);
         addCounter(pool.counters, kCntExtendNodes, cnt.nodes);
         addCounter(pool.counters, kCntExtendPrims, cnt.prims);
+        addCounter(pool.counters, kCntExtendLeaves, cnt.leaves);
+        addCounter(pool.counters, kCntExtendWaveNodeSteps, cnt.waveNodeSteps);
+        addCounter(pool.counters, kCntExtendWavePrimSteps, cnt.wavePrimSteps);
+        addCounter(pool.counters, kCntExtendRefillPasses, refills);
     }
 }
 
