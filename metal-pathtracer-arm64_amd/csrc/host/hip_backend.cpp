@@ -214,6 +214,7 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     v.qnodes = ds.qnodes.ptr;
     std::memcpy(v.gridOrigin, bvh.gridOrigin, sizeof(v.gridOrigin));
     std::memcpy(v.gridCell, bvh.gridCell, sizeof(v.gridCell));
+    for (int a = 0; a < 3; ++a) v.gridInvCell[a] = 1.0f / bvh.gridCell[a];
     // 32 B quantised nodes halve the node fetches; use them unless the 16-bit grid is coarse next to the
     // primitives (cell > 1/8 of the mean primitive extent would inflate leaf boxes noticeably)
     const float maxCell = std::max(std::max(bvh.gridCell[0], bvh.gridCell[1]), bvh.gridCell[2]);
@@ -707,6 +708,8 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
                                      "refill passes %.3g (x64 lanes)\n",
                              static_cast<double>(c[kCntExtendRays]), nodeLanes, nodeSlots, nodeLanes / std::max(nodeSlots, 1.0), primLanes, primSlots,
                              primLanes / std::max(primSlots, 1.0), static_cast<double>(c[kCntExtendRefillPasses]));
+                std::fprintf(stderr, "[steps] k_extend: refill passes take %.1f %% of the waves' time in the kernel\n",
+                             100.0 * static_cast<double>(c[kCntExtendRefillTicks]) / std::max(static_cast<double>(c[kCntExtendWaveTicks]), 1.0));
             }
         }
     }

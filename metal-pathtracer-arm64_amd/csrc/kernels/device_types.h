@@ -25,6 +25,7 @@ struct SceneView {
     const uint4* qnodes;
     float gridOrigin[3];
     float gridCell[3];
+    float gridInvCell[3];          // 1 / gridCell
     uint32_t useQuantized;
     const float4* tris;
     const float4* triNormals;
@@ -164,7 +165,9 @@ enum CounterSlot : uint32_t {
     kCntExtendWaveNodeSteps = 12,   // 64 x node steps executed by waves
     kCntExtendWavePrimSteps = 13,   // 64 x primitive steps executed by waves
     kCntExtendRefillPasses = 14,    // 64 x refill passes
-    kCounterSlots = 16,
+    kCntExtendRefillTicks = 15,     // 64 x clock64 ticks / 16 spent in refill passes
+    kCntExtendWaveTicks = 16,       // 64 x clock64 ticks / 16 a wave spent in the kernel
+    kCounterSlots = 24,
 };
 
 }  // namespace ptrk

@@ -168,11 +168,14 @@ __device__ __forceinline__ bool travBegin(const SceneView& sc, Trav& t, f3 org, 
     // persistent wave holds the whole launch (measured: k_extend 10x slower).  A clamped reciprocal treats the
     // component as +-1e-28: still "parallel" for any scene, and all box arithmetic stays finite.
     constexpr float kInvMax = 1.0e28f;
-    t.inv = mk3(fminf(fmaxf(1.0f / dir.x, -kInvMax), kInvMax), fminf(fmaxf(1.0f / dir.y, -kInvMax), kInvMax),
-                fminf(fmaxf(1.0f / dir.z, -kInvMax), kInvMax));
+    // v_rcp_f32 (1 ulp) instead of IEEE divisions: these values only feed the box tests, which carry 4 ulp of slack
+    // and padded boxes; the reported hit comes from the exact primitive tests on t.org / t.dir
+    t.inv = mk3(fminf(fmaxf(__builtin_amdgcn_rcpf(dir.x), -kInvMax), kInvMax), fminf(fmaxf(__builtin_amdgcn_rcpf(dir.y), -kInvMax), kInvMax),
+                fminf(fmaxf(__builtin_amdgcn_rcpf(dir.z), -kInvMax), kInvMax));
     if (sc.useQuantized) {
         const f3 cell = mk3(sc.gridCell[0], sc.gridCell[1], sc.gridCell[2]);
-        const f3 orgQ = (org - mk3(sc.gridOrigin[0], sc.gridOrigin[1], sc.gridOrigin[2])) / cell;
+        const f3 invCell = mk3(sc.gridInvCell[0], sc.gridInvCell[1], sc.gridInvCell[2]);
+        const f3 orgQ = (org - mk3(sc.gridOrigin[0], sc.gridOrigin[1], sc.gridOrigin[2])) * invCell;
         t.inv = t.inv * cell;
         t.oi = orgQ * t.inv;
     } else {
@@ -284,6 +287,10 @@ __device__ __forceinline__ bool travPrimStep(const SceneView& sc, const SceneMem
 #ifndef PTR_EXTRA_PRIM_STEPS
 #define PTR_EXTRA_PRIM_STEPS 1
 #endif
+#ifndef PTR_REPEAT_NUM   // a step is repeated while at least NUM/DEN of the lanes that voted for it want it again
+#define PTR_REPEAT_NUM 1
+#define PTR_REPEAT_DEN 2
+#endif
 
 // One wave iteration for all traversing lanes: majority vote between node steps and primitive steps.
 // Returns (per lane) false when that lane's ray has just finished.  Lanes not voted for return true unchanged.
@@ -303,7 +310,7 @@ __device__ __forceinline__ bool travVote(const SceneView& sc, const SceneMem& me
 #pragma unroll
         for (int extra = 0; extra < PTR_EXTRA_NODE_STEPS; ++extra) {
             const bool again = wantsNode && more && !travAtLeaf(t);
-            if (__popcll(__ballot(again)) * 2 < nNode) break;
+            if (__popcll(__ballot(again)) * PTR_REPEAT_DEN < nNode * PTR_REPEAT_NUM) break;
             if (COUNT) ++cnt.waveNodeSteps;
             if (again) more = travNodeStep<COUNT>(sc, mem, t, stack, cnt);
         }
@@ -313,7 +320,7 @@ __device__ __forceinline__ bool travVote(const SceneView& sc, const SceneMem& me
 #pragma unroll
         for (int extra = 0; extra < PTR_EXTRA_PRIM_STEPS; ++extra) {
             const bool again = wantsPrim && more && travAtLeaf(t);
-            if (__popcll(__ballot(again)) * 2 < nPrim) break;
+            if (__popcll(__ballot(again)) * PTR_REPEAT_DEN < nPrim * PTR_REPEAT_NUM) break;
             if (COUNT) ++cnt.wavePrimSteps;
             if (again) more = travPrimStep<COUNT>(sc, mem, t, stack, cnt);
         }

@@ -411,6 +411,8 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
     uint32_t rays = 0u;
     uint32_t aliveSeen = 0u;   // live slots this wave picked up (host termination check, end of the frame only)
     uint32_t refills = 0u;     // counting build: refill passes of this wave
+    uint32_t refillCycles = 0u;   // counting build: clock64 ticks spent in them
+    const long long kernelStart = COUNT ? clock64() : 0ll;
 
     const SceneMem mem = sceneMem(sc);
     WaveFeeder feeder;
@@ -423,6 +425,7 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
         const int nActive = __popcll(__ballot(active));
         if (nActive < kRefillBelow && !feeder.exhausted) {
             if (COUNT) ++refills;
+            const long long refillStart = COUNT ? clock64() : 0ll;
             const uint32_t idx = feeder.take(!active);
             const bool live = idx != WaveFeeder::kNone && (pool.state[idx].z & kFlagAlive);
             if (ALIVE) aliveSeen += static_cast<uint32_t>(__popcll(__ballot(live)));   // wave-uniform: stays in an SGPR
@@ -431,6 +434,11 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
                 if (COUNT) ++rays;
                 active = travBegin(sc, t, mk3(pool.rayOrg[idx]), mk3(pool.rayDir[idx]), kEps, INFINITY, false, stack);
                 if (!active) pool.hit[idx] = make_float4(INFINITY, 0.0f, 0.0f, __uint_as_float(kHitMiss));
+            }
+            if (COUNT) {
+                // make the loaded values "used" here so the pass is timed with its memory waits, as it runs
+                asm volatile("" ::"v"(t.inv.x), "v"(t.oi.x));
+                refillCycles += static_cast<uint32_t>(clock64() - refillStart);
             }
             continue;
         }
@@ -453,6 +461,8 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
         addCounter(pool.counters, kCntExtendWaveNodeSteps, cnt.waveNodeSteps);
         addCounter(pool.counters, kCntExtendWavePrimSteps, cnt.wavePrimSteps);
         addCounter(pool.counters, kCntExtendRefillPasses, refills);
+        addCounter(pool.counters, kCntExtendRefillTicks, refillCycles >> 4);
+        addCounter(pool.counters, kCntExtendWaveTicks, static_cast<uint32_t>((clock64() - kernelStart) >> 4));
     }
 }
 
