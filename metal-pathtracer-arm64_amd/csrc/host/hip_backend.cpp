@@ -708,6 +708,10 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
                                      "refill passes %.3g (x64 lanes)\n",
                              static_cast<double>(c[kCntExtendRays]), nodeLanes, nodeSlots, nodeLanes / std::max(nodeSlots, 1.0), primLanes, primSlots,
                              primLanes / std::max(primSlots, 1.0), static_cast<double>(c[kCntExtendRefillPasses]));
+                const double votes = static_cast<double>(c[kCntExtendVoteIterations]) / 64.0;
+                std::fprintf(stderr, "[steps] k_extend: %.3g vote iterations; lanes holding a ray %.1f / 64 on average, of which at a leaf %.1f\n", votes,
+                             static_cast<double>(c[kCntExtendActiveLanes]) / std::max(votes, 1.0),
+                             static_cast<double>(c[kCntExtendLeafLanes]) / std::max(votes, 1.0));
                 std::fprintf(stderr, "[steps] k_extend: refill passes take %.1f %% of the waves' time in the kernel\n",
                              100.0 * static_cast<double>(c[kCntExtendRefillTicks]) / std::max(static_cast<double>(c[kCntExtendWaveTicks]), 1.0));
             }

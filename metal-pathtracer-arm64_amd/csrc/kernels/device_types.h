@@ -167,6 +167,9 @@ enum CounterSlot : uint32_t {
     kCntExtendRefillPasses = 14,    // 64 x refill passes
     kCntExtendRefillTicks = 15,     // 64 x clock64 ticks / 16 spent in refill passes
     kCntExtendWaveTicks = 16,       // 64 x clock64 ticks / 16 a wave spent in the kernel
+    kCntExtendActiveLanes = 17,     // sum over vote iterations of the lanes holding a ray
+    kCntExtendLeafLanes = 18,       // ... of which at a leaf
+    kCntExtendVoteIterations = 19,  // 64 x vote iterations
     kCounterSlots = 24,
 };
 

@@ -287,6 +287,9 @@ __device__ __forceinline__ bool travPrimStep(const SceneView& sc, const SceneMem
 #ifndef PTR_EXTRA_PRIM_STEPS
 #define PTR_EXTRA_PRIM_STEPS 1
 #endif
+#ifndef PTR_PRIM_BIAS     // a primitive step is taken once the lanes at a leaf exceed 1/PTR_PRIM_BIAS of the lanes at a node
+#define PTR_PRIM_BIAS 2
+#endif
 #ifndef PTR_REPEAT_NUM   // a step is repeated while at least NUM/DEN of the lanes that voted for it want it again
 #define PTR_REPEAT_NUM 1
 #define PTR_REPEAT_DEN 2
@@ -302,7 +305,7 @@ __device__ __forceinline__ bool travVote(const SceneView& sc, const SceneMem& me
     const int nPrim = __popcll(__ballot(wantsPrim));
     const int nNode = __popcll(__ballot(wantsNode));
     bool more = true;
-    if (nNode >= nPrim) {
+    if (nNode >= nPrim * PTR_PRIM_BIAS) {
         if (COUNT) ++cnt.waveNodeSteps;
         if (wantsNode) more = travNodeStep<COUNT>(sc, mem, t, stack, cnt);
         // further node steps without another vote while most of these lanes land on an internal node again (the vote -

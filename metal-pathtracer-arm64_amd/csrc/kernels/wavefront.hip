@@ -96,25 +96,31 @@ struct WaveFeeder {
         end = 0u;
         exhausted = (n == 0u);
     }
-    // must be called by all 64 lanes (converged)
+    // must be called by all 64 lanes (converged).  Every idle lane gets an index while any are left: a chunk that
+    // runs out in the middle of a pass is followed by the next one in the same pass.
     __device__ __forceinline__ uint32_t take(bool idle) {
         const unsigned long long mask = __ballot(idle);
         if (mask == 0ull || exhausted) return kNone;
-        if (next >= end) {
-            uint32_t base = 0u;
-            if (laneId() == 0u) base = atomicAdd(counter, chunk);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= total) {
-                exhausted = true;
-                return kNone;
-            }
-            next = base;
-            end = min(base + chunk, total);
-        }
-        const uint32_t avail = end - next;
+        const uint32_t need = static_cast<uint32_t>(__popcll(mask));
         const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << laneId()) - 1ull)));
-        const uint32_t idx = (idle && rank < avail) ? (next + rank) : kNone;
-        next += min(static_cast<uint32_t>(__popcll(mask)), avail);
+        uint32_t idx = kNone, served = 0u;
+        while (served < need) {
+            if (next >= end) {
+                uint32_t base = 0u;
+                if (laneId() == 0u) base = atomicAdd(counter, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= total) {
+                    exhausted = true;
+                    break;
+                }
+                next = base;
+                end = min(base + chunk, total);
+            }
+            const uint32_t n = min(end - next, need - served);
+            if (idle && rank >= served && rank < served + n) idx = next + (rank - served);
+            next += n;
+            served += n;
+        }
         return idx;
     }
 };
@@ -412,6 +418,7 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
     uint32_t aliveSeen = 0u;   // live slots this wave picked up (host termination check, end of the frame only)
     uint32_t refills = 0u;     // counting build: refill passes of this wave
     uint32_t refillCycles = 0u;   // counting build: clock64 ticks spent in them
+    uint32_t activeLanes = 0u, leafLanes = 0u, voteIterations = 0u;   // counting build: occupancy of the vote iterations
     const long long kernelStart = COUNT ? clock64() : 0ll;
 
     const SceneMem mem = sceneMem(sc);
@@ -443,6 +450,11 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
             continue;
         }
         if (nActive == 0) break;
+        if (COUNT) {
+            activeLanes += static_cast<uint32_t>(nActive);   // wave-uniform: per-lane copies, the wave sum is 64 x
+            leafLanes += static_cast<uint32_t>(__popcll(__ballot(active && travAtLeaf(t))));
+            ++voteIterations;
+        }
         if (!travVote<COUNT>(sc, mem, t, active, stack, cnt)) {
             active = false;
             pool.hit[mySlot] = make_float4(t.hit.t, t.hit.u, t.hit.v, __uint_as_float(t.hit.prim));
@@ -461,6 +473,9 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
         addCounter(pool.counters, kCntExtendWaveNodeSteps, cnt.waveNodeSteps);
         addCounter(pool.counters, kCntExtendWavePrimSteps, cnt.wavePrimSteps);
         addCounter(pool.counters, kCntExtendRefillPasses, refills);
+        addCounter(pool.counters, kCntExtendActiveLanes, activeLanes >> 6);
+        addCounter(pool.counters, kCntExtendLeafLanes, leafLanes >> 6);
+        addCounter(pool.counters, kCntExtendVoteIterations, voteIterations);
         addCounter(pool.counters, kCntExtendRefillTicks, refillCycles >> 4);
         addCounter(pool.counters, kCntExtendWaveTicks, static_cast<uint32_t>((clock64() - kernelStart) >> 4));
     }
