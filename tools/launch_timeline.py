@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--parts", type=int, default=8)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "cornell_mesh.scene"))
+    ap.add_argument("--dump", default=None, help="write the raw [launch] lines to this file")
     ap.add_argument("--child", action="store_true")
     args = ap.parse_args()
     if args.child:
@@ -46,6 +47,9 @@ def main():
         return
     r = subprocess.run([sys.executable, __file__, "--child", "--parts", str(args.parts), "--spp", str(args.spp), "--scene", args.scene],
                        capture_output=True, text=True)
+    if args.dump:
+        with open(args.dump, "w") as f:
+            f.write("".join(l + "\n" for l in r.stderr.splitlines() if l.startswith("[launch]")))
     rows = [re.findall(r"[-\d.]+", l) for l in r.stderr.splitlines() if l.startswith("[launch]")]
     print(r.stdout.strip(), "| %d launches" % len(rows))
     if os.environ.get("PTR_POOL_GROUPS") == "1":
