@@ -5,7 +5,7 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step = one full render of the configuration: every rank renders its interleaved 16-row bands of the image
+A step = one full render of the configuration: every rank renders its interleaved 8-row bands of the image
 from a scene already resident in its HBM, then the HDR band buffers are gathered on rank 0 (RCCL).  Total work
 per step is fixed, so scaling is "strong".  Rank 0 prints one JSON line.
 """
@@ -209,7 +209,7 @@ def main():
             "config": {
                 "workload": "BASELINE configs[1]: Cornell box + one 70,688-triangle OBJ mesh, %dx%d, depth %d, %d spp, seed 1337"
                             % (args.width, args.height, args.depth, args.spp),
-                "partition": "16-row bands round-robin over %d rank(s), RCCL gather of the HDR buffer" % world,
+                "partition": "8-row bands round-robin over %d rank(s), RCCL gather of the HDR buffer" % world,
                 "bvh_upload_s": round(upload_s, 3),
             },
             "roofline": {

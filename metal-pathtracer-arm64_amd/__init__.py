@@ -264,6 +264,9 @@ def device_count() -> int:
     return int(load_library().ptr_device_count())
 
 
+BAND_ROWS = 8   # PTR_BAND_ROWS of include/ptr_abi.h
+
+
 def band_count(height: int, part: int = 0, parts: int = 1) -> int:
     return int(load_library().ptr_part_band_count(height, part, parts))
 
@@ -345,10 +348,10 @@ class DeviceScene:
 
     def render(self, settings: PtrSettings, spp: int, part: int = 0, parts: int = 1, count: bool = False
                ) -> Tuple[np.ndarray, PtrRenderStats]:
-        """Render one partition to host memory.  Returns ([bands*16, W, 3] float32, stats)."""
+        """Render one partition to host memory.  Returns ([bands*BAND_ROWS, W, 3] float32, stats)."""
         lib = load_library()
         bands = band_count(settings.height, part, parts)
-        out = np.zeros((bands * 16, settings.width, 3), dtype=np.float32)
+        out = np.zeros((bands * BAND_ROWS, settings.width, 3), dtype=np.float32)
         stats = PtrRenderStats()
         err = _err_buf()
         _check(lib.ptr_render_bands(self._h, C.byref(settings), spp, part, parts, _fptr(out), int(count),
@@ -404,14 +407,15 @@ class DeviceScene:
 
 
 def assemble_bands(parts_out, width: int, height: int) -> np.ndarray:
-    """Interleave per-partition band buffers ([bands*16, W, 3] each, band b of part p = image band p + b*P)."""
+    """Interleave per-partition band buffers ([bands*BAND_ROWS, W, 3] each, band b of part p = image band p + b*P)."""
     parts = len(parts_out)
-    img = np.zeros((((height + 15) // 16) * 16, width, 3), dtype=np.float32)
+    R = BAND_ROWS
+    img = np.zeros((((height + R - 1) // R) * R, width, 3), dtype=np.float32)
     for p, buf in enumerate(parts_out):
-        nb = buf.shape[0] // 16
+        nb = buf.shape[0] // R
         for b in range(nb):
             g = p + b * parts
-            img[g * 16:(g + 1) * 16] = buf[b * 16:(b + 1) * 16]
+            img[g * R:(g + 1) * R] = buf[b * R:(b + 1) * R]
     return img[:height]
 
 

@@ -1,6 +1,6 @@
 """Image partition across ranks and the final gather (torch.distributed plumbing only).
 
-The path shards by pixels: rank r of P renders the 16-row bands b with b % P == r (scene replicated, RNG a pure
+The path shards by pixels: rank r of P renders the 8-row bands b with b % P == r (scene replicated, RNG a pure
 function of (seed, pixel, sample) so any partition reproduces the single-GPU image bit for bit).  The only
 exchange is one gather of the HDR band buffers to rank 0 per render — RCCL over xGMI on GPUs (backend "nccl"),
 gloo in the CPU tests.  The reference has no multi-device code; its closest relative is the Embree backend's
@@ -10,11 +10,11 @@ from __future__ import annotations
 
 from typing import List, Optional
 
-BAND_ROWS = 16
+BAND_ROWS = 8   # PTR_BAND_ROWS of include/ptr_abi.h
 
 
 def band_count(height: int, part: int, parts: int) -> int:
-    """Number of 16-row bands owned by `part` (same rule as ptr_part_band_count in the C-ABI)."""
+    """Number of BAND_ROWS-row bands owned by `part` (same rule as ptr_part_band_count in the C-ABI)."""
     bands = (height + BAND_ROWS - 1) // BAND_ROWS
     if parts <= 0 or part >= parts or bands <= part:
         return 0
@@ -26,9 +26,9 @@ def max_band_count(height: int, parts: int) -> int:
 
 
 def gather_bands(local, height: int, rank: int, world: int, group=None):
-    """Gather every rank's [bands*16, W, 3] buffer on rank 0 and interleave the bands into the image.
+    """Gather every rank's [bands*BAND_ROWS, W, 3] buffer on rank 0 and interleave the bands into the image.
 
-    `local` must be padded to max_band_count(height, world)*16 rows so all ranks send equal blocks.
+    `local` must be padded to max_band_count(height, world)*BAND_ROWS rows so all ranks send equal blocks.
     Returns the [height, W, 3] image on rank 0, None elsewhere.
     """
     import torch
@@ -57,6 +57,6 @@ def assemble(parts_out, height: int):
     world = len(parts_out)
     width = parts_out[0].shape[1]
     total_bands = (height + BAND_ROWS - 1) // BAND_ROWS
-    stacked = torch.stack([p.reshape(-1, BAND_ROWS, width, 3) for p in parts_out], dim=1)  # [b, P, 16, W, 3]
+    stacked = torch.stack([p.reshape(-1, BAND_ROWS, width, 3) for p in parts_out], dim=1)  # [b, P, BAND_ROWS, W, 3]
     img = stacked.reshape(-1, BAND_ROWS, width, 3)[:total_bands]                            # band index = b*P + p
     return img.reshape(-1, width, 3)[:height]

@@ -104,8 +104,8 @@ struct PtrDeviceScene {
     // render-time resources, grown on demand and kept across calls
     DeviceBuffer<float4> rayOrg, rayDir, hit, throughput, accum, recBuf, itemAccum;
     uint64_t poolSlots = 16ull << 20;
-    uint32_t poolGroups = 4;
-    uint32_t feederChunk = 256, feederChunkSparse = 4096;   // slots per work-head atomic: full pool / mostly dead pool   // the pool is split into this many independent groups, one HIP stream each
+    uint32_t poolGroups = 4;   // the pool is split into this many independent groups, one HIP stream each
+    uint32_t feederChunk = 256, feederChunkSparse = 0;   // slots per work-head claim: full pool / mostly dead pool (0: slots per resident wave)
     std::vector<hipStream_t> groupStreams;   // streams of groups 1.. (group 0 runs on the caller's stream)
     std::vector<hipEvent_t> groupEvents;
     int refillBelow = 40;
@@ -354,13 +354,13 @@ void fillRenderParams(const PtrSettings& s, uint32_t spp, RenderParams& rp) {
     rp.mediaMode = s.metalSemantics & (PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL | PTR_METAL_SPECULAR);
 }
 
-// Local pixel order of a partition: its 16-row bands top to bottom, each walked in 8x8 blocks so the
+// Local pixel order of a partition: its PTR_BAND_ROWS-row bands top to bottom, each walked in 8x8 blocks so the
 // 64 lanes of a wave start with a compact, coherent bundle of primary rays.
 void partitionPixels(uint32_t width, uint32_t height, uint32_t part, uint32_t parts, std::vector<uint32_t>& out) {
     out.clear();
-    const uint32_t bands = (height + 15u) / 16u;
+    const uint32_t bands = (height + PTR_BAND_ROWS - 1u) / PTR_BAND_ROWS;
     for (uint32_t b = part; b < bands; b += parts) {
-        const uint32_t y0 = b * 16u, y1 = std::min(y0 + 16u, height);
+        const uint32_t y0 = b * PTR_BAND_ROWS, y1 = std::min(y0 + PTR_BAND_ROWS, height);
         for (uint32_t ty = y0; ty < y1; ty += 8u) {
             for (uint32_t tx = 0; tx < width; tx += 8u) {
                 for (uint32_t y = ty; y < std::min(ty + 8u, y1); ++y) {
@@ -410,7 +410,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     }
     const uint32_t localPixels = ds.cachedLocalPixels;
     const uint32_t bandCount = ptr_part_band_count(settings.height, part, parts);
-    const size_t outFloats = static_cast<size_t>(bandCount) * 16u * settings.width * 3u;
+    const size_t outFloats = static_cast<size_t>(bandCount) * PTR_BAND_ROWS * settings.width * 3u;
     HIP_CHECK(hipMemsetAsync(dOut, 0, outFloats * sizeof(float), stream));
     if (localPixels == 0) {
         HIP_CHECK(hipStreamSynchronize(stream));
@@ -626,8 +626,13 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
                     if (ds.pinnedAlive[g] == 0u) gr.done = true;
                     // the fewer live slots, the bigger the chunks the work list is claimed in (see WaveFeeder): a chunk
                     // should still hold about as many live slots as a full one does when the pool is full
+                    // up to the point where the static first chunks of the resident waves cover the whole list and
+                    // the head is not touched at all
                     const uint32_t thin = gr.pool.slots / std::max(ds.pinnedAlive[g], 1u);
-                    gr.feederChunk = std::min(ds.feederChunkSparse, ds.feederChunk * std::max(thin, 1u));
+                    const uint32_t waves = std::max(gr.cfg.traceGrid * (kTraceBlock / 64u), 1u);
+                    const uint32_t perWave = ((gr.pool.slots + waves - 1u) / waves + 63u) / 64u * 64u;
+                    const uint32_t cap = ds.feederChunkSparse ? ds.feederChunkSparse : std::max(perWave, ds.feederChunk);
+                    gr.feederChunk = std::min(cap, ds.feederChunk * std::max(thin, 1u));
                 }
                 allDone = allDone && gr.done;
             }
@@ -731,7 +736,7 @@ int ptr_device_count(void) {
 
 uint32_t ptr_part_band_count(uint32_t height, uint32_t part_index, uint32_t part_count) {
     if (part_count == 0 || part_index >= part_count) return 0;
-    const uint32_t bands = (height + 15u) / 16u;
+    const uint32_t bands = (height + PTR_BAND_ROWS - 1u) / PTR_BAND_ROWS;
     return bands > part_index ? (bands - part_index + part_count - 1u) / part_count : 0u;
 }
 
@@ -793,7 +798,7 @@ int ptr_render_bands(PtrDeviceScene* scene, const PtrSettings* settings, uint32_
         return 1;
     }
     try {
-        const size_t floats = static_cast<size_t>(ptr_part_band_count(settings->height, part_index, part_count)) * 16u * settings->width * 3u;
+        const size_t floats = static_cast<size_t>(ptr_part_band_count(settings->height, part_index, part_count)) * PTR_BAND_ROWS * settings->width * 3u;
         HIP_CHECK(hipSetDevice(scene->device));
         scene->outBands.ensure(floats);
         renderBands(*scene, *settings, spp, part_index, part_count, scene->outBands.ptr, nullptr, count_traversal, stats);
@@ -814,8 +819,8 @@ int ptr_render(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t 
     PtrDeviceScene* ds = nullptr;
     int rc = ptr_scene_upload(scene, 0, &ds, err, err_cap);
     if (rc != 0) return rc;
-    const uint32_t bands = (settings->height + 15u) / 16u;
-    std::vector<float> banded(static_cast<size_t>(bands) * 16u * settings->width * 3u);
+    const uint32_t bands = (settings->height + PTR_BAND_ROWS - 1u) / PTR_BAND_ROWS;
+    std::vector<float> banded(static_cast<size_t>(bands) * PTR_BAND_ROWS * settings->width * 3u);
     PtrRenderStats local{};
     rc = ptr_render_bands(ds, settings, spp, 0, 1, banded.data(), 0, &local, err, err_cap);
     if (rc == 0) {

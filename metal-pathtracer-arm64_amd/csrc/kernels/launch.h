@@ -30,7 +30,7 @@ void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& po
 void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count,
                    hipStream_t stream);
 // Adds outstanding light connections, reduces the slots of each pixel in fixed order and writes
-// out[((localBand*16 + row) * width + x) * 3 + c] = sum / spp.
+// out[((localBand*PTR_BAND_ROWS + row) * width + x) * 3 + c] = sum / spp.
 void launchResolve(const RenderParams& rp, const PathPool& pool, uint32_t partCount, float* dOut, hipStream_t stream);
 
 void launchTraceRays(const SceneView& sc, const float4* dRays, uint64_t n, bool anyHit, PtrHit* dOut, const LaunchConfig& cfg,

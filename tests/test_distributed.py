@@ -33,8 +33,9 @@ def _local_buffer(height, width, rank, world):
     buf = np.zeros((rows, width, 3), dtype=np.float32)
     for b in range(bands.band_count(height, rank, world)):
         g = rank + b * world
-        y0, y1 = g * 16, min(g * 16 + 16, height)
-        buf[b * 16:b * 16 + (y1 - y0)] = full[y0:y1]
+        R = bands.BAND_ROWS
+        y0, y1 = g * R, min(g * R + R, height)
+        buf[b * R:b * R + (y1 - y0)] = full[y0:y1]
     return torch.from_numpy(buf)
 
 
@@ -73,6 +74,6 @@ def test_assemble_matches_numpy_reference_for_many_partitions():
             parts = [_local_buffer(height, 8, r, world) for r in range(world)]
             img = bands.assemble(parts, height).numpy()
             assert np.array_equal(img, _pattern(height, 8))
-            trimmed = [p.numpy()[: bands.band_count(height, r, world) * 16] for r, p in enumerate(parts)]
+            trimmed = [p.numpy()[: bands.band_count(height, r, world) * bands.BAND_ROWS] for r, p in enumerate(parts)]
             assert np.array_equal(pt.assemble_bands(trimmed, 8, height), img)
             assert [bands.band_count(height, r, world) for r in range(world)] == [pt.band_count(height, r, world) for r in range(world)]

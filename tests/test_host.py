@@ -54,8 +54,11 @@ def test_device_path_fails_loudly_without_gpu():
 
 
 def test_band_partition_counts():
+    src = open(os.path.join(ROOT, "include", "ptr_abi.h")).read()
+    assert "#define PTR_BAND_ROWS %du" % pt.BAND_ROWS in src
+    assert importlib.import_module("metal-pathtracer-arm64_amd.bands").BAND_ROWS == pt.BAND_ROWS
     for height in (8, 16, 17, 64, 1080, 2160):
-        bands = (height + 15) // 16
+        bands = (height + pt.BAND_ROWS - 1) // pt.BAND_ROWS
         for parts in (1, 2, 3, 8):
             counts = [pt.band_count(height, p, parts) for p in range(parts)]
             assert sum(counts) == bands and max(counts) - min(counts) <= 1

@@ -26,7 +26,7 @@ def child(args):
     host = pt.HostScene.load(args.scene, os.path.join(ROOT, "scenes"))
     s = host.settings_for(seed=1337)
     scene = pt.DeviceScene(host.desc, 0, keepalive=host)
-    rows = bands.max_band_count(s.height, args.parts) * 16
+    rows = bands.max_band_count(s.height, args.parts) * bands.BAND_ROWS
     out = torch.zeros((rows, s.width, 3), dtype=torch.float32, device="cuda")
     scene.render_device(s, args.spp, out.data_ptr(), 0, 0, args.parts, want_stats=False)   # warm-up
     os.environ["PTR_TRACE_ITERATIONS"] = "1"

@@ -22,7 +22,7 @@ for pool in [int(x) for x in os.environ.get("POOLS", "0").split(",")]:
     scene = pt.DeviceScene(host.desc, 0, keepalive=host)
     base = None
     for parts in (1, 2, 4, 8):
-        rows = bands.max_band_count(1080, parts) * 16
+        rows = bands.max_band_count(1080, parts) * bands.BAND_ROWS
         out = torch.zeros((rows, 1920, 3), dtype=torch.float32, device=dev)
         scene.render_device(s, spp, out.data_ptr(), 0, 0, parts, want_stats=False)
         torch.cuda.synchronize()
