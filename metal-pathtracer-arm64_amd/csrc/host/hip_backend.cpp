@@ -598,7 +598,8 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
             uint32_t* aliveSlot = gr.scalars + kAliveBase + ring;
             gr.cfg.feederChunk = gr.feederChunk;
             // work heads and the next live-slot counter are cleared by k_shade (all zero at the start of the frame)
-            const ShadeResets resets{gr.scalars + 1, gr.scalars + 2, gr.scalars + kAliveBase + (ring + 1u) % kAliveRing};
+            const ShadeResets resets{gr.scalars + 1, gr.scalars + 2, gr.scalars + kAliveBase + (ring + 1u) % kAliveRing,
+                                     (queueDry && gr.feederChunk > ds.feederChunk) ? 1u : 0u};
             timedLaunch(0, gr.stream, [&] { launchExtend(ds.view, gr.pool, gr.cfg, queueDry ? aliveSlot : nullptr, count, gr.stream); });
             timedLaunch(1, gr.stream, [&] { launchShade(rp, ds.view, gr.pool, resets, count, gr.stream); });
             timedLaunch(2, gr.stream, [&] { launchConnect(rp, ds.view, gr.pool, gr.cfg, count, gr.stream); });

@@ -24,6 +24,7 @@ struct ShadeResets {
     uint32_t* extendHead;    // work head of the next k_extend
     uint32_t* connectHead;   // work head of this iteration's k_connect
     uint32_t* nextAlive;     // live-slot counter of the next k_extend
+    uint32_t drained;        // nonzero once most slots are dead: waves look at the state word alone before loading the rest
 };
 void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, bool count,
                  hipStream_t stream);

@@ -538,6 +538,12 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
     // zero word when the record is not pending, so the kernel has ~11 loads in flight per lane after ONE dependent
     // step (the state word) instead of walking a chain of ten load-wait pairs at 5 waves per SIMD.
     const uint32_t at = inRange ? slot : 0u;
+    if (resets.drained) {
+        // end of the frame: most waves cover 64 dead slots, and the loads below would still stream 96 B per slot
+        const uint4 peek = pool.state[at];
+        const bool busy = inRange && ((peek.z & (kFlagAlive | kFlagFlush)) != 0u || (peek.w & 0xFFu) != 0u);
+        if (__ballot(busy) == 0ull) return;
+    }
     uint4 st = pool.state[at];
     const float4 acc4 = pool.accum[at];
     const float4 rayO4 = pool.rayOrg[at], rayD4 = pool.rayDir[at];
