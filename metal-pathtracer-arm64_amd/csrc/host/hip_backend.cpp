@@ -588,7 +588,9 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     // slots it traced: one atomic per persistent wave).  A poll joins all streams, which
     // costs the overlap between groups once; polling every 4 iterations throughout was 5 % slower.  (Polling through
     // events without joining was tried: the host then runs up to a dozen empty iterations past the end - no gain.)
-    constexpr uint64_t kPollEvery = 4;
+    uint64_t kPollEvery = 4;
+    if (const char* e = std::getenv("PTR_POLL_EVERY")) kPollEvery = static_cast<uint64_t>(std::min(std::max(std::atoi(e), 1), 64));   // tuning knob
+    const bool tracePolls = std::getenv("PTR_TRACE_ITERATIONS") != nullptr;   // debugging aid: live slots per poll
     uint64_t nextCheck = kPollEvery;
     bool queueDry = false;
     while (rp.maxDepth > 0) {
@@ -625,6 +627,10 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
                 HIP_CHECK(hipStreamSynchronize(gr.stream));
                 if (queueDry) {
                     if (ds.pinnedAlive[g] == 0u) gr.done = true;
+                    if (tracePolls) {
+                        std::fprintf(stderr, "[poll] iteration %llu group %u live %u of %u chunk %u\n", static_cast<unsigned long long>(iterations), g,
+                                     ds.pinnedAlive[g], gr.pool.slots, gr.feederChunk);
+                    }
                     // the fewer live slots, the bigger the chunks the work list is claimed in (see WaveFeeder): a chunk
                     // should still hold about as many live slots as a full one does when the pool is full
                     // up to the point where the static first chunks of the resident waves cover the whole list and

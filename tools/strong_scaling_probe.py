@@ -21,7 +21,7 @@ for pool in [int(x) for x in os.environ.get("POOLS", "0").split(",")]:
         os.environ["PTR_POOL_SLOTS"] = str(pool)
     scene = pt.DeviceScene(host.desc, 0, keepalive=host)
     base = None
-    for parts in (1, 2, 4, 8):
+    for parts in [int(x) for x in os.environ.get("PARTS", "1,2,4,8").split(",")]:
         rows = bands.max_band_count(1080, parts) * bands.BAND_ROWS
         out = torch.zeros((rows, 1920, 3), dtype=torch.float32, device=dev)
         scene.render_device(s, spp, out.data_ptr(), 0, 0, parts, want_stats=False)
@@ -32,8 +32,8 @@ for pool in [int(x) for x in os.environ.get("POOLS", "0").split(",")]:
             scene.render_device(s, spp, out.data_ptr(), 0, 0, parts, want_stats=False)
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) / reps
-        if parts == 1:
-            base = t
+        if base is None:
+            base = t * parts
         print("pool %9d  parts %d  part-0 render %.2f ms  efficiency %.3f  (%.0f Msamples/s projected)" %
               (pool, parts, t * 1e3, base / (parts * t), 1920 * 1080 * spp / t / 1e6 * 1.0), flush=True)
     scene.close()
