@@ -162,11 +162,19 @@ typedef struct PtrSettings {
      * Bit 3 (PTR_METAL_SPECULAR): rough metals (type 1) sample the distribution of visible normals, use the pdf
      * D*G1*cos(h)/(4 wo.wh) and scale the lobe by the multiple-scattering energy compensation (:3724-3739, 3770-3797,
      * 4610-4630, 5000-5023, 5228-5283); the Embree backend samples half vectors with pdf D*cos(h)/(4 wo.wh) and has no
-     * compensation.  The PBR model's Metal variant (three lobes, textures) is not covered. */
+     * compensation.  Bit 4 (PTR_METAL_SSS): subsurface materials (type 5) follow the Metal integrator: their BSDF
+     * evaluates to zero (is_bssrdf: no next-event estimation, :5078-5084), and with sssMode = 1 they are sampled with
+     * the separable diffusion profile - an exit point on the tangent plane at a radius drawn from exp(-sigma_tr r),
+     * a cosine-distributed direction from it, weight = profile * cos / (area pdf * directional pdf), and the next
+     * ray starts at the biased exit point (:3916-3994, 5398-5507, 6740-6766); otherwise the Lambert fallback.  The
+     * Embree backend treats type 5 as Lambertian with NEE.  The random-walk mode (sssMode = 2 on materials that ask
+     * for it) traces inside the sampling step and is not implemented: such a render is refused with an error.
+     * The PBR model's Metal variant (three lobes, textures) is not covered. */
     uint32_t metalSemantics;
+    uint32_t sssMode;   /* RenderSettings::SssMode: 0 off, 1 separable, 2 random walk; read only with PTR_METAL_SSS */
 } PtrSettings;
 
-enum { PTR_METAL_MEDIA = 1u, PTR_METAL_THIN = 2u, PTR_METAL_FACE_NORMAL = 4u, PTR_METAL_SPECULAR = 8u };
+enum { PTR_METAL_MEDIA = 1u, PTR_METAL_THIN = 2u, PTR_METAL_FACE_NORMAL = 4u, PTR_METAL_SPECULAR = 8u, PTR_METAL_SSS = 16u };
 
 typedef struct PtrRenderStats {
     double totalSeconds;                /* integrate phase only (reference: out.totalSeconds) */

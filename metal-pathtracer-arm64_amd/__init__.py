@@ -130,6 +130,7 @@ class PtrSettings(C.Structure):
         ("fireflyClampMaxContribution", C.c_float),
         ("emissionScale", C.c_float),
         ("metalSemantics", C.c_uint32),
+        ("sssMode", C.c_uint32),
     ]
 
     def copy(self) -> "PtrSettings":

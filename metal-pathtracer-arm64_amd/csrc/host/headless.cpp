@@ -39,6 +39,7 @@ void FillPtrSettings(const RenderSettings& s, PtrSettings& o) {
     o.fireflyClampMaxContribution = s.fireflyClampMaxContribution;
     o.emissionScale = 1.0f;
     o.metalSemantics = s.metalSemantics;
+    o.sssMode = static_cast<uint32_t>(s.sssMode);
 }
 
 bool HipHeadlessRenderer::render(const HeadlessScene& scene, const HeadlessCamera&, const RenderSettings& settings,

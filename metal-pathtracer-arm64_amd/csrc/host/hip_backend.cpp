@@ -100,6 +100,7 @@ struct PtrDeviceScene {
     SceneView view{};
     uint64_t info[8] = {0};
     double uploadSeconds = 0.0;
+    bool hasRandomWalkMaterial = false;   // a type-5 material with sssParams.y >= 0.5 (Metal random-walk subsurface)
 
     // render-time resources, grown on demand and kept across calls
     DeviceBuffer<float4> rayOrg, rayDir, hit, throughput, accum, recBuf, itemAccum;
@@ -144,7 +145,7 @@ void compactMaterial(const PtrMaterial& m, std::vector<float>& out) {
     const float* rows[kMaterialVec4] = {m.baseColorRoughness, m.typeEta,        m.emission,           m.conductorEta,
                                         m.conductorK,         m.coatParams,     m.coatTint,           m.coatAbsorption,
                                         m.carpaintBaseParams, m.carpaintFlakeParams, m.carpaintBaseEta, m.carpaintBaseK,
-                                        m.dielectricSigmaA};
+                                        m.dielectricSigmaA,   m.sssSigmaA,      m.sssSigmaS,          m.sssParams};
     for (uint32_t r = 0; r < kMaterialVec4; ++r) {
         float v[4] = {rows[r][0], rows[r][1], rows[r][2], rows[r][3]};
         if (r == kMatCoatTint) v[3] = m.pbrParams[0];   // PBR metallic rides in the free w lane
@@ -164,6 +165,11 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     std::vector<float> mats;
     mats.reserve(static_cast<size_t>(desc.materialCount) * kMaterialVec4 * 4);
     for (uint32_t i = 0; i < desc.materialCount; ++i) compactMaterial(desc.materials[i], mats);
+    ds.hasRandomWalkMaterial = false;
+    for (uint32_t i = 0; i < desc.materialCount; ++i) {
+        const PtrMaterial& m = desc.materials[i];
+        if (static_cast<uint32_t>(m.typeEta[0]) == PTR_MAT_SUBSURFACE && m.sssParams[1] >= 0.5f) ds.hasRandomWalkMaterial = true;
+    }
 
     // rectangle lights: DiffuseLight rectangles with non-zero emission (:2484-2522)
     std::vector<float> lights;
@@ -351,7 +357,8 @@ void fillRenderParams(const PtrSettings& s, uint32_t spp, RenderParams& rp) {
     rp.minSpecularPdf = std::max(s.minSpecularPdf, 1.0e-8f);
     rp.clampEnabled = s.fireflyClampEnabled ? 1.0f : 0.0f;
     rp.emissionScale = (s.emissionScale > 0.0f && std::isfinite(s.emissionScale)) ? s.emissionScale : 1.0f;
-    rp.mediaMode = s.metalSemantics & (PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL | PTR_METAL_SPECULAR);
+    rp.mediaMode = s.metalSemantics & (PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL | PTR_METAL_SPECULAR | PTR_METAL_SSS);
+    rp.sssMode = s.sssMode;
 }
 
 // Local pixel order of a partition: its PTR_BAND_ROWS-row bands top to bottom, each walked in 8x8 blocks so the
@@ -393,6 +400,9 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     const bool soloGroup = (mode & 2) != 0;     // one pool group: kernels run alone, for clean per-kernel timings
     if (settings.width == 0 || settings.height == 0) throw HipError{"render size must be non-zero"};
     if (parts == 0 || part >= parts) throw HipError{"bad partition"};
+    if ((settings.metalSemantics & PTR_METAL_SSS) && settings.sssMode == 2u && ds.hasRandomWalkMaterial) {
+        throw HipError{"random-walk subsurface scattering (sssMode 2 on a material that asks for it) is not implemented"};
+    }
     HIP_CHECK(hipSetDevice(ds.device));
 
     RenderParams rp;

@@ -16,6 +16,8 @@ struct ClampCfg {
     bool enabled;
     bool thinDielectrics;   // PTR_METAL_THIN: honour the thin-walled flag of dielectrics (Metal semantics)
     bool metalSpecular;     // PTR_METAL_SPECULAR: VNDF sampling, G1 pdf and energy compensation for rough metals
+    bool metalSss;          // PTR_METAL_SSS: type 5 evaluates to zero (no NEE); separable diffusion sampling when sssMode == 1
+    uint32_t sssMode;
 };
 
 __device__ __forceinline__ uint32_t rngHash(uint32_t x) {  // lowbias32
@@ -34,7 +36,7 @@ __device__ __forceinline__ float rngNext(uint32_t& state) {
 
 __device__ __forceinline__ float luminance(f3 c) { return (0.2126f * c.x + 0.7152f * c.y) + 0.0722f * c.z; }
 
-// Material record view: 13 float4, fetched on demand (most branches need 2-4 of them).
+// Material record view: 16 float4, fetched on demand (most branches need 2-4 of them).
 struct Mat {
     const float4* p;
     __device__ __forceinline__ float4 v(uint32_t slot) const { return p[slot]; }
@@ -539,11 +541,15 @@ struct BsdfEvalResult {
     bool isDelta;
 };
 
+// SSS: compiled with the Metal subsurface semantics (PTR_METAL_SSS).  A template parameter, not a run-time flag: the extra
+// branch and the exit point it carries cost the default k_shade 3 % when they were merely predicated off.
+template <bool SSS = false>
 __device__ BsdfEvalResult evalBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 wi, const ClampCfg& cc) {
     BsdfEvalResult r{mk3(0.0f), 0.0f, false};
     const float cosO = smax(dot(n, wo), 0.0f), cosI = smax(dot(n, wi), 0.0f);
     if (cosI <= 0.0f || cosO <= 0.0f) return r;
     const uint32_t type = m.type();
+    if (SSS && type == 5u && cc.metalSss) return r;   // is_bssrdf: value 0, pdf 0 -> no next-event estimation (pathtrace.metal:5078-5084)
     switch (type) {
         case 7u: {  // PBR metallic-roughness
             const Pbr p = loadPbr(m);
@@ -618,12 +624,116 @@ struct BsdfSampleResult {
     float pdf;
     bool isDelta;
     int mediumEvent;   // +1: refracted into a dielectric through its front face, -1: out through a back face, else 0
+    bool hasExit;      // separable subsurface sample: the path leaves the surface at exitPoint (normal = the shading normal)
+    f3 exitPoint;
 };
 
+// ---- separable subsurface scattering of the Metal integrator (shaders/pathtrace.metal:3916-3994) ----
+struct SssCoefficients {
+    f3 sigmaA, sigmaSPrime;
+};
+
+// sss_sigma_a / sss_sigma_s_prime (:3916-3950): the material's override pair, or derived from base colour and mean free path
+__device__ __forceinline__ SssCoefficients sssCoefficients(const Mat& m, float meanFreePath, float anisotropy) {
+    SssCoefficients c;
+    const float4 a = m.v(kMatSssSigmaA);
+    const float reduce = smax(1.0f - anisotropy, 0.01f);
+    if (a.w > 0.5f) {
+        c.sigmaA = vmaxs(mk3(a), 1.0e-6f);
+        c.sigmaSPrime = vmax0(mk3(m.v(kMatSssSigmaS))) * reduce;
+        return c;
+    }
+    const float sigmaT = 1.0f / smax(meanFreePath, 1.0e-4f);
+    f3 sigmaS = vmax0(vclamp(m.baseColor(), 0.0f, 0.999f) * sigmaT) * reduce;
+    c.sigmaA = vmaxs(mk3(sigmaT) - sigmaS, 1.0e-6f);
+    c.sigmaSPrime = sigmaS;
+    return c;
+}
+
+// normalized_diffusion_profile (:3952-3971): dipole reflectance at `radius`, per colour channel
+__device__ __forceinline__ f3 diffusionProfile(float radius, f3 sigmaA, f3 sigmaSPrime) {
+    const f3 sigmaTPrime = vmaxs(sigmaA + sigmaSPrime, 1.0e-6f);
+    const f3 alphaPrime = vclamp(sigmaSPrime / sigmaTPrime, 0.0f, 1.0f);
+    const f3 D = mk3(1.0f) / vmaxs(3.0f * sigmaTPrime, 1.0e-6f);
+    const f3 sigmaTr = vsqrt(vmaxs(sigmaA / D, 1.0e-6f));
+    const float r = smax(radius, 1.0e-4f);
+    const f3 zr = mk3(1.0f) / sigmaTPrime;
+    const f3 dr = vsqrt(mk3(r * r) + zr * zr);
+    const f3 vr = zr + 4.0f * D;
+    const f3 dv = vsqrt(mk3(r * r) + vr * vr);
+    const f3 expDr = vexp(-(sigmaTr * dr));
+    const f3 expDv = vexp(-(sigmaTr * dv));
+    const f3 termDr = (zr * (mk3(1.0f) + sigmaTr * dr)) / vmaxs(dr * dr * dr, 1.0e-6f);
+    const f3 termDv = (vr * (mk3(1.0f) + sigmaTr * dv)) / vmaxs(dv * dv * dv, 1.0e-6f);
+    return vmax0((alphaPrime / (4.0f * kPi)) * (termDr * expDr + termDv * expDv));
+}
+
+// sss_sigma_tr_scalar (:3973-3980)
+__device__ __forceinline__ float sssSigmaTrScalar(f3 sigmaA, f3 sigmaSPrime) {
+    const f3 sigmaTPrime = vmaxs(sigmaA + sigmaSPrime, 1.0e-6f);
+    const f3 D = mk3(1.0f) / vmaxs(3.0f * sigmaTPrime, 1.0e-6f);
+    return smax(luminance(vsqrt(vmaxs(sigmaA / D, 1.0e-6f))), 1.0e-4f);
+}
+
+// The separable branch of sample_bsdf case 5 (:5398-5481).  Returns false when it does not apply or gives up on the
+// way (the caller then takes the Lambert fallback with the generator wherever this left it, like the reference).
+__device__ bool sampleSeparableSss(const Mat& m, f3 position, f3 n, f3 wo, uint32_t& rng, const ClampCfg& cc, BsdfSampleResult& r) {
+    const float4 params = m.v(kMatSssParams);
+    const float meanFreePath = smax(params.x, 1.0e-4f);
+    if (!(cc.sssMode == 1u && params.y < 0.5f && meanFreePath > 1.0e-4f)) return false;
+    const float anisotropy = clampf(m.v(kMatSssSigmaS).w, -0.99f, 0.99f);
+    const SssCoefficients c = sssCoefficients(m, meanFreePath, anisotropy);
+    const float sigmaTr = sssSigmaTrScalar(c.sigmaA, c.sigmaSPrime);
+    if (sigmaTr <= 0.0f) return false;
+    const float u = clampf(rngNext(rng), 1.0e-6f, 1.0f - 1.0e-6f);
+    float radius = -logf(1.0f - u) / smax(sigmaTr, 1.0e-4f);
+    radius = smin(radius, meanFreePath * 10.0f);
+    const float sigma = smax(sigmaTr, 1.0e-4f);
+    const float pdfRadius = radius <= 0.0f ? 0.0f : sigma * expf(-sigma * radius);
+    if (pdfRadius <= 0.0f || !isfinite(pdfRadius)) return false;
+    const float phi = 2.0f * kPi * rngNext(rng);
+    const Frame fr = makeFrame(n);
+    const f3 exitPoint = position + fr.t * (radius * cosf(phi)) + fr.b * (radius * sinf(phi));
+    float pdfDir = 0.0f;
+    const f3 wi = cosineHemisphere(rng, n, pdfDir);
+    const float cosExit = dot(n, wi);
+    pdfDir = cosExit > 0.0f ? cosExit / kPi : 0.0f;   // lambert_pdf of the normalised direction
+    const float pdfArea = pdfRadius / (2.0f * kPi * smax(radius, 1.0e-4f));
+    if (cosExit <= 0.0f || pdfDir <= 0.0f || pdfArea <= 0.0f) return false;
+    f3 profile = diffusionProfile(radius, c.sigmaA, c.sigmaSPrime);
+    const float4 coat = m.v(kMatCoatParams);
+    const float coatAverage = 1.0f - clampf(coat.w, 0.0f, 1.0f);
+    float coatTransmission = 1.0f;
+    if (params.z > 0.5f) {
+        const float coatIor = smax(m.v(kMatTypeEta).z, 1.0f);
+        float f0 = (coatIor - 1.0f) / (coatIor + 1.0f);
+        f0 *= f0;
+        const float transIn = 1.0f - (f0 + (1.0f - f0) * schlickW(smax(dot(n, wo), 0.0f)));
+        const float transOut = 1.0f - (f0 + (1.0f - f0) * schlickW(cosExit));
+        coatTransmission = clampf(transIn * transOut, 0.0f, 1.0f);
+        profile = profile * vclamp(mk3(m.v(kMatCoatTint)), 0.0f, 1.0f);
+    }
+    const float denom = smax(pdfArea * pdfDir, 1.0e-6f);
+    const f3 weight = vmax0((profile * (cosExit * coatAverage * coatTransmission)) / denom);
+    if (!finite3(weight)) return false;
+    r.dir = wi;
+    r.weight = weight;
+    // The reference reports pdf = area pdf x directional pdf and keeps the directional pdf for the MIS weight of the next
+    // emitter hit (lastBsdfPdf = directionalPdf, :7269); both are positive here, so the one pdf this struct carries is
+    // the directional one.
+    r.pdf = pdfDir;
+    r.isDelta = false;
+    r.hasExit = true;
+    r.exitPoint = exitPoint;
+    return true;
+}
+
+template <bool SSS = false>
 __device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 incident, bool frontFace,
                                        uint32_t& rng, const ClampCfg& cc) {
-    BsdfSampleResult r{mk3(0.0f), mk3(0.0f), 0.0f, false, 0};
+    BsdfSampleResult r{mk3(0.0f), mk3(0.0f), 0.0f, false, 0, false, mk3(0.0f)};
     const uint32_t type = m.type();
+    if (SSS && type == 5u && cc.metalSss && sampleSeparableSss(m, position, n, wo, rng, cc, r)) return r;
     switch (type) {
         case 7u: {
             const Pbr p = loadPbr(m);

@@ -52,7 +52,7 @@ struct SceneView {
 };
 
 // Compact material record: the MaterialData fields the Embree-semantics integrator reads.
-constexpr uint32_t kMaterialVec4 = 13u;
+constexpr uint32_t kMaterialVec4 = 16u;
 enum MaterialSlot : uint32_t {
     kMatBaseColorRoughness = 0,
     kMatTypeEta = 1,
@@ -67,6 +67,9 @@ enum MaterialSlot : uint32_t {
     kMatCarpaintBaseEta = 10,
     kMatCarpaintBaseK = 11,
     kMatDielectricSigmaA = 12,   // xyz absorption coefficient of a dielectric's interior (Metal media semantics)
+    kMatSssSigmaA = 13,          // xyz sigma_a override, w > 0.5: the override is in force (Metal subsurface semantics)
+    kMatSssSigmaS = 14,          // xyz sigma_s override, w anisotropy g
+    kMatSssParams = 15,          // x mean free path, y method (>= 0.5: random walk), z coat enabled
 };
 
 struct CameraParams {
@@ -84,7 +87,8 @@ struct RenderParams {
     uint32_t chunkCount;           // ceil(spp / C)
     uint32_t itemCount;            // localPixels * chunkCount; item w = chunk * localPixels + localPixel
     uint32_t localPixels;          // pixels owned by this partition
-    uint32_t mediaMode;            // PTR_METAL_MEDIA | PTR_METAL_THIN (0 = Embree-parity integrator)
+    uint32_t mediaMode;            // PTR_METAL_* bits (0 = Embree-parity integrator)
+    uint32_t sssMode;              // RenderSettings::SssMode, read only with PTR_METAL_SSS
     uint32_t itemHeadFirst;        // items below this are pre-assigned to the slots by k_generate
     uint32_t itemsPerHead;         // the remaining items are split into kItemHeads ranges of this size (multiple of 64)
     uint32_t enableRussianRoulette, enableSpecularNee, enableMnee, enableMneeSecondary;

@@ -40,6 +40,8 @@ __device__ __forceinline__ float smin(float a, float b) { return (b < a) ? b : a
 __device__ __forceinline__ f3 vmax(f3 a, f3 b) { return f3{smax(a.x, b.x), smax(a.y, b.y), smax(a.z, b.z)}; }
 __device__ __forceinline__ f3 vmax0(f3 a) { return f3{smax(a.x, 0.0f), smax(a.y, 0.0f), smax(a.z, 0.0f)}; }
 __device__ __forceinline__ f3 vsqrt(f3 a) { return f3{sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)}; }
+__device__ __forceinline__ f3 vmaxs(f3 a, float s) { return f3{smax(a.x, s), smax(a.y, s), smax(a.z, s)}; }
+__device__ __forceinline__ f3 vexp(f3 a) { return f3{expf(a.x), expf(a.y), expf(a.z)}; }
 // std::clamp semantics for lo <= hi (NaN passes through)
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return (v < lo) ? lo : ((hi < v) ? hi : v); }
 __device__ __forceinline__ f3 vclamp(f3 a, float lo, float hi) {

@@ -47,6 +47,8 @@ __device__ __forceinline__ ClampCfg clampCfg(const RenderParams& rp) {
     c.enabled = rp.clampEnabled >= 0.5f;
     c.thinDielectrics = (rp.mediaMode & PTR_METAL_THIN) != 0u;
     c.metalSpecular = (rp.mediaMode & PTR_METAL_SPECULAR) != 0u;
+    c.metalSss = (rp.mediaMode & PTR_METAL_SSS) != 0u;
+    c.sssMode = rp.sssMode;
     return c;
 }
 
@@ -334,6 +336,20 @@ __device__ __forceinline__ f3 offsetOrigin(const Surface& s, f3 direction) {
     return o;
 }
 
+// Origin of the ray that leaves a separable-subsurface exit point (shaders/pathtrace.metal:6740-6766): offset_surface_point
+// (:1210-1220), then 0.02 along the exit normal and 0.04 along the direction - the biases the reference uses to get clear
+// of the mesh, since the exit point lies on the tangent plane, not on the surface.
+__device__ __forceinline__ f3 sssExitOrigin(f3 exitPoint, f3 exitNormal, f3 direction) {
+    const f3 n = (finite3(exitNormal) && dot(exitNormal, exitNormal) > 0.0f) ? normalize(exitNormal) : mk3(0.0f, 1.0f, 0.0f);
+    const float sign = dot(direction, n) >= 0.0f ? 1.0f : -1.0f;
+    f3 o = exitPoint + n * (sign * kEps * 4.0f);
+    o += (direction * kEps) * 0.5f;
+    o += n * smax(5.0e-3f * 4.0f, kEps * 32.0f);
+    const f3 d = (finite3(direction) && dot(direction, direction) > 0.0f) ? normalize(direction) : n;
+    o += d * smax(5.0e-3f * 8.0f, kEps * 32.0f);
+    return o;
+}
+
 // pdf (solid angle, incl. 1/N light pick) of hitting rectangle `rectIndex` at `position` from `origin`
 __device__ __forceinline__ float rectLightPdfForHit(const SceneView& sc, uint32_t primType, uint32_t rectIndex, f3 position, f3 origin) {
     if (sc.rectLightCount == 0u || sc.rectCount == 0u) return 0.0f;
@@ -523,7 +539,8 @@ __device__ __forceinline__ uint4 mediumWithEntry(uint4 ms, uint32_t i, uint32_t 
 #define PTR_SHADE_WAVES 5
 #endif
 #define PTR_SHADE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PTR_SHADE_WAVES, PTR_SHADE_WAVES)))
-template <bool COUNT>
+// SSS: the instantiation with the Metal subsurface semantics (launched when PTR_METAL_SSS is set)
+template <bool COUNT, bool SSS>
 __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(RenderParams rp, SceneView sc, PathPool pool, ShadeResets resets) {
     const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x;
     if (slot == 0u) {
@@ -697,7 +714,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
                                 const f3 emission = mk3(L[4]) * rp.emissionScale;
                                 const float nDotL = smax(dot(n, ldir), 0.0f);
                                 if (pdf > 0.0f && isfinite(pdf) && (dot(emission, emission) > 0.0f) && nDotL > 0.0f) {
-                                    const BsdfEvalResult be = evalBsdf(mat, sf.position, n, wo, ldir, cc);
+                                    const BsdfEvalResult be = evalBsdf<SSS>(mat, sf.position, n, wo, ldir, cc);
                                     if (!be.isDelta && be.pdf > 0.0f) {
                                         const float w = pdf / (pdf + be.pdf);   // balance heuristic, unclamped
                                         f3 contrib = (emission * be.value) * nDotL;
@@ -728,7 +745,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
                         const float nDotL = smax(dot(n, edir), 0.0f);
                         if (epdf > 0.0f && nDotL > 0.0f) {
                             const f3 envRadiance = envLookup(sc, edir, rp.envRotation, rp.envIntensity);
-                            const BsdfEvalResult be = evalBsdf(mat, sf.position, n, wo, edir, cc);
+                            const BsdfEvalResult be = evalBsdf<SSS>(mat, sf.position, n, wo, edir, cc);
                             if (!be.isDelta && be.pdf > 0.0f) {
                                 const float w = epdf / (epdf + be.pdf);
                                 f3 contrib = (envRadiance * be.value) * nDotL;
@@ -745,7 +762,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
                     }
 
                     // ---- continue the path ----
-                    const BsdfSampleResult bs = sampleBsdf(mat, sf.position, n, wo, incident, sf.frontFace, rng, cc);
+                    const BsdfSampleResult bs = sampleBsdf<SSS>(mat, sf.position, n, wo, incident, sf.frontFace, rng, cc);
                     if (bs.pdf <= 0.0f || dot(bs.dir, bs.dir) <= 0.0f || !finite3(bs.weight)) {
                         endPath = true;
                     } else {
@@ -805,7 +822,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
                         } else {
                             lastPdf = bs.pdf > 0.0f ? bs.pdf : lastPdf;
                             lastDelta = bs.isDelta;
-                            nextO = offsetOrigin(sf, bs.dir);
+                            nextO = (SSS && bs.hasExit) ? sssExitOrigin(bs.exitPoint, n, bs.dir) : offsetOrigin(sf, bs.dir);
                             nextD = bs.dir;
                             if (rp.enableRussianRoulette && depth >= 5u) {
                                 const float p = clampf(maxComp, 0.05f, 0.95f);
@@ -1299,7 +1316,7 @@ __global__ void k_debug_eval(const float4* material, RenderParams rp, const floa
     if (i >= n) return;
     const float* p = in + i * 12u;
     const Mat m{material};
-    const BsdfEvalResult e = evalBsdf(m, ld3(p), ld3(p + 3), ld3(p + 6), ld3(p + 9), clampCfg(rp));
+    const BsdfEvalResult e = evalBsdf<true>(m, ld3(p), ld3(p + 3), ld3(p + 6), ld3(p + 9), clampCfg(rp));   // (the run-time flag still decides)
     float* o = out + i * 5u;
     o[0] = e.value.x; o[1] = e.value.y; o[2] = e.value.z; o[3] = e.pdf; o[4] = e.isDelta ? 1.0f : 0.0f;
 }
@@ -1312,7 +1329,7 @@ __global__ void k_debug_sample(const float4* material, RenderParams rp, const fl
     const Mat m{material};
     uint32_t rng = rngIn[i];
     const f3 wo = ld3(p + 6);
-    const BsdfSampleResult s = sampleBsdf(m, ld3(p), ld3(p + 3), wo, -wo, front[i] != 0u, rng, clampCfg(rp));
+    const BsdfSampleResult s = sampleBsdf<true>(m, ld3(p), ld3(p + 3), wo, -wo, front[i] != 0u, rng, clampCfg(rp));
     float* o = out + i * 8u;
     o[0] = s.dir.x; o[1] = s.dir.y; o[2] = s.dir.z;
     o[3] = s.weight.x; o[4] = s.weight.y; o[5] = s.weight.z;
@@ -1359,10 +1376,12 @@ void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig&
 void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, bool count,
                  hipStream_t stream) {
     const uint32_t grid = ceilDiv(pool.slots, kShadeBlock);
+    const bool sss = (rp.mediaMode & PTR_METAL_SSS) != 0u;
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, resets); };
     if (count) {
-        hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, resets);
+        if (sss) launch(k_shade<true, true>); else launch(k_shade<true, false>);
     } else {
-        hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, resets);
+        if (sss) launch(k_shade<false, true>); else launch(k_shade<false, false>);
     }
 }
 

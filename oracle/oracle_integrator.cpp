@@ -723,6 +723,8 @@ ClampParams makeClampParams(const PtrSettings& s) {  // E:381-391
     p.enabled = s.fireflyClampEnabled ? 1.0f : 0.0f;
     p.thinDielectrics = (s.metalSemantics & PTR_METAL_THIN) != 0u;   // Metal-only semantics, off on the Embree path
     p.metalSpecular = (s.metalSemantics & PTR_METAL_SPECULAR) != 0u;
+    p.metalSss = (s.metalSemantics & PTR_METAL_SSS) != 0u;
+    p.sssMode = s.sssMode;
     return p;
 }
 
@@ -777,6 +779,7 @@ BsdfEval evaluateBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 wi
     const float cosI = std::max(dot(normal, wi), 0.0f);
     if (cosI <= 0.0f || cosO <= 0.0f) return r;
     const uint32_t type = matType(m);
+    if (type == PTR_MAT_SUBSURFACE && cp.metalSss) return r;   // M:5078-5084: isBssrdf, value 0, pdf 0 -> no NEE
 
     if (type == PTR_MAT_LAMBERTIAN || type == PTR_MAT_SUBSURFACE) {
         r.value = baseColor(m) / kPi;
@@ -860,10 +863,125 @@ BsdfEval evaluateBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 wi
     return r;
 }
 
+// ---- separable subsurface scattering of the Metal integrator (Metal-only semantics, PTR_METAL_SSS) ----
+namespace {
+
+V3 vmaxs(V3 a, float s) { return {std::max(a.x, s), std::max(a.y, s), std::max(a.z, s)}; }
+V3 vsqrt3(V3 a) { return {std::sqrt(a.x), std::sqrt(a.y), std::sqrt(a.z)}; }
+V3 vexp3(V3 a) { return {std::exp(a.x), std::exp(a.y), std::exp(a.z)}; }
+V3 vclamp01(V3 a) { return {clampf(a.x, 0.0f, 1.0f), clampf(a.y, 0.0f, 1.0f), clampf(a.z, 0.0f, 1.0f)}; }
+
+// sss_sigma_a / sss_sigma_s_prime, M:3916-3950
+void sssCoefficients(const PtrMaterial& m, float meanFreePath, float anisotropy, V3& sigmaA, V3& sigmaSPrime) {
+    const float reduce = std::max(1.0f - anisotropy, 0.01f);
+    if (m.sssSigmaA[3] > 0.5f) {
+        sigmaA = vmaxs(V3(m.sssSigmaA[0], m.sssSigmaA[1], m.sssSigmaA[2]), 1.0e-6f);
+        sigmaSPrime = vmax(V3(m.sssSigmaS[0], m.sssSigmaS[1], m.sssSigmaS[2]), V3()) * reduce;
+        return;
+    }
+    const float sigmaT = 1.0f / std::max(meanFreePath, 1.0e-4f);
+    const V3 bc = baseColor(m);
+    V3 sigmaS = V3(clampf(bc.x, 0.0f, 0.999f), clampf(bc.y, 0.0f, 0.999f), clampf(bc.z, 0.0f, 0.999f)) * sigmaT;
+    sigmaS = vmax(sigmaS, V3()) * reduce;
+    sigmaA = vmaxs(V3(sigmaT, sigmaT, sigmaT) - sigmaS, 1.0e-6f);
+    sigmaSPrime = sigmaS;
+}
+
+// normalized_diffusion_profile, M:3952-3971
+V3 diffusionProfile(float radius, V3 sigmaA, V3 sigmaSPrime) {
+    const V3 one(1.0f, 1.0f, 1.0f);
+    const V3 sigmaTPrime = vmaxs(sigmaA + sigmaSPrime, 1.0e-6f);
+    const V3 alphaPrime = vclamp01(sigmaSPrime / sigmaTPrime);
+    const V3 D = one / vmaxs(3.0f * sigmaTPrime, 1.0e-6f);
+    const V3 sigmaTr = vsqrt3(vmaxs(sigmaA / D, 1.0e-6f));
+    const float r = std::max(radius, 1.0e-4f);
+    const V3 rr(r * r, r * r, r * r);
+    const V3 zr = one / sigmaTPrime;
+    const V3 dr = vsqrt3(rr + zr * zr);
+    const V3 vr = zr + 4.0f * D;
+    const V3 dv = vsqrt3(rr + vr * vr);
+    const V3 expDr = vexp3(-(sigmaTr * dr));
+    const V3 expDv = vexp3(-(sigmaTr * dv));
+    const V3 termDr = (zr * (one + sigmaTr * dr)) / vmaxs(dr * dr * dr, 1.0e-6f);
+    const V3 termDv = (vr * (one + sigmaTr * dv)) / vmaxs(dv * dv * dv, 1.0e-6f);
+    return vmax((alphaPrime / (4.0f * kPi)) * (termDr * expDr + termDv * expDv), V3());
+}
+
+// sss_sigma_tr_scalar, M:3973-3980
+float sssSigmaTrScalar(V3 sigmaA, V3 sigmaSPrime) {
+    const V3 sigmaTPrime = vmaxs(sigmaA + sigmaSPrime, 1.0e-6f);
+    const V3 D = V3(1.0f, 1.0f, 1.0f) / vmaxs(3.0f * sigmaTPrime, 1.0e-6f);
+    return std::max(luminance(vsqrt3(vmaxs(sigmaA / D, 1.0e-6f))), 1.0e-4f);
+}
+
+// The separable branch of sample_bsdf case 5, M:5398-5481.  false: not applicable / gave up (Lambert fallback follows,
+// with the generator wherever this left it).
+bool sampleSeparableSss(const PtrMaterial& m, V3 position, V3 normal, V3 wo, Rng& rng, const ClampParams& cp, BsdfSample& r) {
+    const float meanFreePath = std::max(m.sssParams[0], 1.0e-4f);
+    if (!(cp.sssMode == 1u && m.sssParams[1] < 0.5f && meanFreePath > 1.0e-4f)) return false;
+    const float anisotropy = clampf(m.sssSigmaS[3], -0.99f, 0.99f);
+    V3 sigmaA, sigmaSPrime;
+    sssCoefficients(m, meanFreePath, anisotropy, sigmaA, sigmaSPrime);
+    const float sigmaTr = sssSigmaTrScalar(sigmaA, sigmaSPrime);
+    if (sigmaTr <= 0.0f) return false;
+    const float u = clampf(rng.nextFloat(), 1.0e-6f, 1.0f - 1.0e-6f);   // sample_sss_radius, M:3982-3986
+    float radius = -std::log(1.0f - u) / std::max(sigmaTr, 1.0e-4f);
+    radius = std::min(radius, meanFreePath * 10.0f);
+    const float sigma = std::max(sigmaTr, 1.0e-4f);                      // pdf_sss_radius, M:3988-3994
+    const float pdfRadius = radius <= 0.0f ? 0.0f : sigma * std::exp(-sigma * radius);
+    if (pdfRadius <= 0.0f || !std::isfinite(pdfRadius)) return false;
+    const float phi = 2.0f * kPi * rng.nextFloat();
+    const Onb onb = buildOnb(normal);
+    const V3 exitPoint = position + onb.tangent * (radius * std::cos(phi)) + onb.bitangent * (radius * std::sin(phi));
+    float pdfDir = 0.0f;
+    const V3 wi = sampleCosineHemisphere(rng, normal, pdfDir);
+    const float cosExit = dot(normal, wi);
+    pdfDir = cosExit > 0.0f ? cosExit / kPi : 0.0f;   // lambert_pdf, M:967-971
+    const float pdfArea = pdfRadius / (2.0f * kPi * std::max(radius, 1.0e-4f));
+    if (cosExit <= 0.0f || pdfDir <= 0.0f || pdfArea <= 0.0f) return false;
+    V3 profile = diffusionProfile(radius, sigmaA, sigmaSPrime);
+    const float coatAverage = 1.0f - clampf(m.coatParams[3], 0.0f, 1.0f);
+    float coatTransmission = 1.0f;
+    if (m.sssParams[2] > 0.5f) {
+        const float coatIor = std::max(m.typeEta[2], 1.0f);
+        float f0 = (coatIor - 1.0f) / (coatIor + 1.0f);
+        f0 *= f0;
+        const float transIn = 1.0f - (f0 + (1.0f - f0) * schlickWeight(std::max(dot(normal, wo), 0.0f)));
+        const float transOut = 1.0f - (f0 + (1.0f - f0) * schlickWeight(cosExit));
+        coatTransmission = clampf(transIn * transOut, 0.0f, 1.0f);
+        profile = profile * vclamp01(V3(m.coatTint[0], m.coatTint[1], m.coatTint[2]));
+    }
+    const float denom = std::max(pdfArea * pdfDir, 1.0e-6f);
+    const V3 weight = vmax((profile * (cosExit * coatAverage * coatTransmission)) / denom, V3());
+    if (!finite3(weight)) return false;
+    r.direction = wi;
+    r.weight = weight;
+    r.pdf = pdfDir;   // the reference's pdf is area x directional; the directional one is what the next emitter hit's MIS uses (M:7269)
+    r.isDelta = false;
+    r.hasExitPoint = true;
+    r.exitPoint = exitPoint;
+    return true;
+}
+
+// Origin of the ray leaving a subsurface exit point, M:6740-6766 (offset_surface_point M:1210-1220 + the two biases)
+V3 sssExitOrigin(V3 exitPoint, V3 exitNormal, V3 direction) {
+    const V3 n = (finite3(exitNormal) && dot(exitNormal, exitNormal) > 0.0f) ? normalize(exitNormal) : V3(0.0f, 1.0f, 0.0f);
+    const float sign = dot(direction, n) >= 0.0f ? 1.0f : -1.0f;
+    V3 o = exitPoint + n * (sign * kEpsilon * 4.0f);
+    o += (direction * kEpsilon) * 0.5f;
+    o += n * std::max(5.0e-3f * 4.0f, kEpsilon * 32.0f);
+    const V3 d = (finite3(direction) && dot(direction, direction) > 0.0f) ? normalize(direction) : n;
+    o += d * std::max(5.0e-3f * 8.0f, kEpsilon * 32.0f);
+    return o;
+}
+
+}  // namespace
+
 BsdfSample sampleBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 incidentDir, bool frontFace, Rng& rng,
                       const ClampParams& cp) {  // E:1493-1918
     BsdfSample r;
     const uint32_t type = matType(m);
+    if (type == PTR_MAT_SUBSURFACE && cp.metalSss && sampleSeparableSss(m, position, normal, wo, rng, cp, r)) return r;
 
     if (type == PTR_MAT_LAMBERTIAN || type == PTR_MAT_SUBSURFACE) {
         float pdf = 0.0f;
@@ -1586,7 +1704,7 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
 
                 lastBsdfPdf = bs.pdf > 0.0f ? bs.pdf : lastBsdfPdf;
                 lastScatterWasDelta = bs.isDelta;
-                ray.origin = offsetRayOrigin(hit, bs.direction);
+                ray.origin = bs.hasExitPoint ? sssExitOrigin(bs.exitPoint, shadingNormal, bs.direction) : offsetRayOrigin(hit, bs.direction);
                 ray.direction = bs.direction;
 
                 if (settings.enableRussianRoulette && depth >= 5) {

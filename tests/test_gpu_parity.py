@@ -340,6 +340,63 @@ def test_metal_specular_semantics(materials_scene):
     assert np.allclose(g[both, :3], o[both, :3], atol=2e-4) and np.allclose(g[both, 3:7], o[both, 3:7], rtol=2e-3, atol=1e-4)
 
 
+def test_metal_subsurface_semantics(tmp_path):
+    # PTR_METAL_SSS: type 5 evaluates to zero (no NEE) and, with `renderer sss=separable`, is sampled with the separable
+    # diffusion profile - exit point on the tangent plane, biased next-ray origin (shaders/pathtrace.metal:3916-3994,
+    # 5398-5507, 6740-6766; restated in the oracle too).  Device functions and images agree with the oracle and differ
+    # from the Embree-parity mode; the random-walk mode is refused.
+    scene = ("camera target=0,0.2,0 distance=7 yaw=0.8 pitch=0.35 vfov=30\n"
+             "renderer width=96 height=64 maxDepth=6 seed=1337 sss=%s\n"
+             "background solid=0.5,0.6,0.8\n"
+             "material type=lambert albedo=0.7,0.7,0.7 name=floor\n"
+             "material type=sss albedo=0.8,0.5,0.3 mfp=0.3%s name=skin\n"
+             "material type=sss albedo=0.3,0.6,0.8 mfp=0.15 g=0.3 sigma_a=0.4,0.2,0.1 sigma_s=3.0,4.0,5.0 coat=on name=jade\n"
+             "material type=diffuse_light emit=12,11,10 name=lamp\n"
+             "rectangle x=-6,6 y=-1 z=-6,6 normal=1 material=0\n"
+             "rectangle x=-1,1 y=4 z=-1,1 normal=-1 material=3\n"
+             "sphere center=-1.1,0,0 radius=1 material=1\n"
+             "sphere center=1.1,0,0 radius=1 material=2\n")
+    p = tmp_path / "sss.scene"
+    p.write_text(scene % ("separable", ""))
+    host = pt.HostScene.load(str(p))
+    assert host.desc.materials[2].sssParams[2] == 1.0 and host.desc.materials[2].sssSigmaA[3] == 1.0     # coat on, sigma override
+    dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
+    s0 = host.settings_for(seed=1337)
+    assert s0.sssMode == 1
+    _image_parity(host, dev, osc, 96, 64, 6, 1, 32, 0.88, metalSemantics=16)
+    s16 = s0.copy()
+    s16.metalSemantics = 16
+    assert _rmse(dev.render_image(s0, 32)[0], dev.render_image(s16, 32)[0]) > 0.005
+    d = host.desc
+    rng = np.random.default_rng(9)
+    n = 4000
+    wo = rng.normal(size=(n, 3))
+    wo[:, 2] = np.abs(wo[:, 2]) + 0.1
+    wo = (wo / np.linalg.norm(wo, axis=1, keepdims=True)).astype(np.float32)
+    inp = np.concatenate([rng.normal(size=(n, 3)).astype(np.float32), np.tile(np.array([0, 0, 1], np.float32), (n, 1)), wo], axis=1)
+    states = rng.integers(1, 2**32 - 1, size=n, dtype=np.uint64).astype(np.uint32)
+    front = np.ones(n, dtype=np.uint32)
+    for mi in (1, 2):
+        g, gs = pt.debug_sample_bsdf(d.materials[mi], s16, inp, front, states)
+        o, os_ = ol.sample_bsdf(d.materials[mi], s16, inp, front, states)
+        assert np.array_equal(gs, os_)                              # four draws on both sides
+        assert np.array_equal(g[:, 6] > 0, o[:, 6] > 0) and (o[:, 6] > 0).mean() > 0.99
+        assert np.allclose(g[:, :3], o[:, :3], atol=2e-4) and np.allclose(g[:, 3:7], o[:, 3:7], rtol=3e-3, atol=1e-5)
+        wi = g[:, :3]
+        ev = pt.debug_eval_bsdf(d.materials[mi], s16, np.concatenate([inp, wi], axis=1))
+        assert np.all(ev[:, :4] == 0.0)
+    # random walk: refused, loudly
+    p.write_text(scene % ("randomwalk", " method=randomwalk"))
+    wh = pt.HostScene.load(str(p))
+    wdev = pt.DeviceScene(wh.desc, 0, keepalive=wh)
+    sw = wh.settings_for(seed=1, metalSemantics=16)
+    assert sw.sssMode == 2
+    with pytest.raises(pt.PtrError, match="random-walk"):
+        wdev.render_image(sw, 1)
+    sw.metalSemantics = 0                                            # Embree-parity mode ignores the setting
+    assert np.isfinite(wdev.render_image(sw, 1)[0]).all()
+
+
 def test_first_hit_aovs(materials_scene):
     # denoiser inputs: albedo = base colour of the first hit, normal = shading normal * 0.5 + 0.5, distance in normal.w
     host, dev, osc = materials_scene

@@ -345,3 +345,83 @@ def test_metal_specular_semantics_consistency_and_furnace(tmp_path):
     img8, _, _ = osc.render(s8, 256, threads=0)
     c0, c8 = float(img0[8:16, 8:16].mean()), float(img8[8:16, 8:16].mean())
     assert c0 < 0.93 and c8 > c0 + 0.03, (c0, c8)
+
+
+SSS_SCENE = ("camera target=0,0,0 distance=6 yaw=1.0 pitch=0.3 vfov=25\n"
+             "renderer width=24 height=24 maxDepth=6 seed=3 russianRoulette=0 sss=%s\n"
+             "background solid=1,1,1\n"
+             "material type=sss albedo=0.8,0.5,0.3 mfp=0.25 name=skin\n"
+             "material type=sss albedo=0.8,0.5,0.3 mfp=0.25 method=randomwalk name=walker\n"
+             "sphere center=0,0,0 radius=1 material=0\n")
+
+
+def _dipole_reflectance(albedo, mfp):
+    """pi * integral of the reference's normalized_diffusion_profile over the tangent plane, truncated at 10 mfp like the
+    sampler's radius (numerical; shaders/pathtrace.metal:3916-3971)."""
+    sigma_t = 1.0 / mfp
+    sigma_s = np.clip(albedo, 0.0, 0.999) * sigma_t            # g = 0
+    sigma_a = np.maximum(sigma_t - sigma_s, 1e-6)
+    stp = sigma_a + sigma_s
+    alpha = sigma_s / stp
+    D = 1.0 / (3.0 * stp)
+    str_ = np.sqrt(sigma_a / D)
+    r = np.linspace(1e-4, 10.0 * mfp, 400001)[:, None]
+    zr = 1.0 / stp
+    vr = zr + 4.0 * D
+    dr = np.sqrt(r * r + zr * zr)
+    dv = np.sqrt(r * r + vr * vr)
+    prof = alpha / (4 * np.pi) * (zr * (1 + str_ * dr) * np.exp(-str_ * dr) / dr ** 3 + vr * (1 + str_ * dv) * np.exp(-str_ * dv) / dv ** 3)
+    return np.pi * np.trapezoid(prof * 2 * np.pi * r, r[:, 0], axis=0)
+
+
+def test_metal_separable_subsurface_sampler(tmp_path):
+    """PTR_METAL_SSS with sssMode = 1 (shaders/pathtrace.metal:5398-5481): exit point on the tangent plane at a radius
+    drawn from exp(-sigma_tr r), cosine direction, weight = profile * cos / (pdfArea * pdfDir).  The expected weight is
+    pi x the integral of the profile (the reference's weight has no 1/pi), which pins the restated profile and pdfs;
+    evaluation returns zero (no NEE); without the bit, or with sssMode 0 / a random-walk material, type 5 stays Lambert."""
+    p = tmp_path / "sss.scene"
+    p.write_text(SSS_SCENE % "separable")
+    host = pt.HostScene.load(str(p))
+    mat = host.desc.materials[0]
+    n = 200000
+    rng = np.random.default_rng(5)
+    normal = np.tile(np.array([0, 0, 1], np.float32), (n, 1))
+    wo = np.tile(np.array([0.3, 0.1, 0.9], np.float32) / np.linalg.norm([0.3, 0.1, 0.9]).astype(np.float32), (n, 1))
+    pos = np.zeros((n, 3), np.float32)
+    inp = np.concatenate([pos, normal, wo], axis=1).astype(np.float32)
+    states = rng.integers(1, 2**32 - 1, size=n, dtype=np.uint64).astype(np.uint32)
+    front = np.ones(n, dtype=np.uint32)
+    s = host.settings_for(metalSemantics=16, fireflyClampEnabled=0)
+    assert s.sssMode == 1                                   # `renderer sss=separable` reaches the settings
+    out, st = ol.sample_bsdf(mat, s, inp, front, states)
+    ok = out[:, 6] > 0
+    assert ok.mean() > 0.999
+    assert np.allclose(out[ok, 6], out[ok, 2] / np.pi, rtol=1e-4)        # the pdf carried on is the cosine pdf of the direction
+    mean_w = out[:, 3:6].astype(np.float64).mean(axis=0)
+    # coatParams.w = the coat's average Fresnel reflectance; the weight carries (1 - that) even without a coat (:5437)
+    expect = _dipole_reflectance(np.array([0.8, 0.5, 0.3]), 0.25) * (1.0 - mat.coatParams[3])
+    assert np.allclose(mean_w, expect, rtol=0.03), (mean_w, expect)
+    # four numbers per sample: radius, angle, two for the direction (Lambert draws two)
+    s0 = host.settings_for(metalSemantics=0, fireflyClampEnabled=0)
+    out0, st0 = ol.sample_bsdf(mat, s0, inp, front, states)
+    assert not np.array_equal(st, st0)
+    assert np.allclose(out0[:, 3:6], np.array([0.8, 0.5, 0.3]), atol=1e-5)          # Lambert weight = albedo
+    # evaluation: zero with the bit, Lambert without
+    wi = np.tile(np.array([0.0, 0.0, 1.0], np.float32), (8, 1))
+    ein = np.concatenate([pos[:8], normal[:8], wo[:8], wi], axis=1)
+    assert np.all(ol.eval_bsdf(mat, s, ein) == 0.0)
+    assert np.allclose(ol.eval_bsdf(mat, s0, ein)[:, :3], np.array([0.8, 0.5, 0.3]) / np.pi, rtol=1e-5)
+    # a material that asks for the random walk, or sssMode off, falls back to Lambert (two draws) even with the bit
+    walker = host.desc.materials[1]
+    outw, stw = ol.sample_bsdf(walker, s, inp, front, states)
+    assert np.array_equal(stw, st0) and np.allclose(outw[:, 3:6], out0[:, 3:6])
+    s_off = s.copy()
+    s_off.sssMode = 0
+    outo, sto = ol.sample_bsdf(mat, s_off, inp, front, states)
+    assert np.array_equal(sto, st0)
+    # image level: the separable sphere differs from the Lambert one and stays finite
+    osc = ol.OracleScene(host)
+    img_l, _, _ = osc.render(s0, 32, threads=0)
+    img_s, _, _ = osc.render(s, 32, threads=0)
+    assert np.isfinite(img_s).all() and img_s.min() >= 0
+    assert np.sqrt(np.mean((img_l - img_s) ** 2)) > 0.01
