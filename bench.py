@@ -43,6 +43,17 @@ def measured_stream_gbs(torch, device):
     return 2.0 * 4.0 * n * reps / dt / 1e9
 
 
+def recorded_parity():
+    """Full-frame parity of BASELINE configs[1] from the last tools/full_configs.py pass (RMSE against the oracle, the oracle's
+    seed-to-seed noise floor N, mean-luminance ratio), or None."""
+    try:
+        row = json.load(open(os.path.join(ROOT, "profiles", "r1_full_configs.json")))["2"]
+        return {"rmse": row["rmse_vs_oracle"], "noise_floor_N": row["noise_floor_N"], "mean_luminance_ratio": row["mean_luminance_ratio"],
+                "spp": row["parity_spp"], "pass": row["pass"]}
+    except Exception:
+        return None
+
+
 def recorded_traffic(spp):
     """HBM bytes per k_extend launch from the committed PMC passes (same command line, see profiles/README.md).
     Returned only when the passes were taken at this spp; otherwise None (bench.py cannot run rocprofv3 on itself)."""
@@ -256,8 +267,21 @@ def main():
             osc.render(settings, 1, threads=threads, rows=(y0, y1))                      # warm the thread pool / caches
             _, secs4, _ = osc.render(settings, 4, threads=threads, rows=(y0, y1))       # calibration pass
             cpu_spp = int(min(args.spp, max(1, round(4.0 * 15.0 / max(secs4, 1e-3)))))
-            _, secs, _ = osc.render(settings, cpu_spp, threads=threads, rows=(y0, y1))
+            ref, secs, _ = osc.render(settings, cpu_spp, threads=threads, rows=(y0, y1))
             cpu_samples = args.width * (y1 - y0) * cpu_spp
+            # the second half of BASELINE's metric ("PFM RMSE vs Embree ref"): the same strip at the same spp through the HIP
+            # path (untimed), compared with the oracle image that was just timed; the full-frame protocol with its noise
+            # floor is tools/full_configs.py (profiles/r1_full_configs.json)
+            scene.render_device(settings, cpu_spp, local.data_ptr(), stream.cuda_stream, 0, 1, want_stats=True)
+            gpu = local[:args.height].cpu().numpy()[y0:y1].astype(np.float64)
+            cpu = ref[y0:y1].astype(np.float64)
+            lum = np.array([0.2126, 0.7152, 0.0722])
+            out["parity"] = {
+                "rmse_vs_oracle": float(np.sqrt(np.mean((gpu - cpu) ** 2))),
+                "mean_luminance_ratio": round(float((gpu @ lum).mean() / max((cpu @ lum).mean(), 1e-30)), 5),
+                "rows": [y0, y1], "spp": cpu_spp,
+                "recorded_full_frame": recorded_parity(),
+            }
             out["cpu_baseline"] = {
                 "value": round(cpu_samples / secs / 1e6, 4),
                 "unit": "Msamples/s",
