@@ -313,7 +313,7 @@ __device__ __forceinline__ bool travVote(const SceneView& sc, const SceneMem& me
 #pragma unroll
         for (int extra = 0; extra < PTR_EXTRA_NODE_STEPS; ++extra) {
             const bool again = wantsNode && more && !travAtLeaf(t);
-            if (__popcll(__ballot(again)) * PTR_REPEAT_DEN < nNode * PTR_REPEAT_NUM) break;
+            if (static_cast<int>(__popcll(__ballot(again))) * PTR_REPEAT_DEN < nNode * PTR_REPEAT_NUM) break;
             if (COUNT) ++cnt.waveNodeSteps;
             if (again) more = travNodeStep<COUNT>(sc, mem, t, stack, cnt);
         }
@@ -323,7 +323,7 @@ __device__ __forceinline__ bool travVote(const SceneView& sc, const SceneMem& me
 #pragma unroll
         for (int extra = 0; extra < PTR_EXTRA_PRIM_STEPS; ++extra) {
             const bool again = wantsPrim && more && travAtLeaf(t);
-            if (__popcll(__ballot(again)) * PTR_REPEAT_DEN < nPrim * PTR_REPEAT_NUM) break;
+            if (static_cast<int>(__popcll(__ballot(again))) * PTR_REPEAT_DEN < nPrim * PTR_REPEAT_NUM) break;
             if (COUNT) ++cnt.wavePrimSteps;
             if (again) more = travPrimStep<COUNT>(sc, mem, t, stack, cnt);
         }

@@ -61,19 +61,6 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
     return v;
 }
 
-// One atomic per wave; returns this lane's slot in the queue (valid where `want`).
-__device__ __forceinline__ uint32_t waveAppend(uint32_t* counter, bool want) {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return 0u;
-    const uint32_t total = static_cast<uint32_t>(__popcll(mask));
-    const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(mask))) - 1u;
-    uint32_t base = 0u;
-    if (laneId() == leader) base = atomicAdd(counter, total);
-    base = __shfl(base, static_cast<int>(leader), 64);
-    const unsigned long long below = mask & ((1ull << laneId()) - 1ull);
-    return base + static_cast<uint32_t>(__popcll(below));
-}
-
 __device__ __forceinline__ void addCounter(uint64_t* counters, uint32_t slot, uint32_t value) {
     const uint32_t total = waveSum(value);
     if (laneId() == 0 && total != 0u) atomicAdd(reinterpret_cast<unsigned long long*>(counters + slot), static_cast<unsigned long long>(total));
@@ -440,7 +427,6 @@ template <bool COUNT, bool ALIVE>
 __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride, uint32_t* workCounter,
                                                          int kRefillBelow, uint32_t feederChunk, uint32_t* aliveOut) {
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
-    const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
     stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
     stack.spill = spill;
@@ -1059,7 +1045,6 @@ template <bool COUNT>
 __global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) k_connect(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride,
                                                           uint32_t* workCounter, int kRefillBelow, uint32_t feederChunk) {
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
-    const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
     LaneStack stack;
     stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
     stack.spill = spill;
