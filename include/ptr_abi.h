@@ -167,11 +167,14 @@ typedef struct PtrSettings {
      * the separable diffusion profile - an exit point on the tangent plane at a radius drawn from exp(-sigma_tr r),
      * a cosine-distributed direction from it, weight = profile * cos / (area pdf * directional pdf), and the next
      * ray starts at the biased exit point (:3916-3994, 5398-5507, 6740-6766); otherwise the Lambert fallback.  The
-     * Embree backend treats type 5 as Lambertian with NEE.  The random-walk mode (sssMode = 2 on materials that ask
-     * for it) traces inside the sampling step and is not implemented: such a render is refused with an error.
+     * Embree backend treats type 5 as Lambertian with NEE.  With sssMode = 2, front-face hits of materials that ask for
+     * it (sssParams.y >= 0.5) run the random walk of sample_sss_random_walk_software (:4060-4311): coat lobe or refraction
+     * into the medium, free flights against the closest boundary with Henyey-Greenstein scattering, up to sssMaxSteps
+     * queries, Lambert fallback when the walk is abandoned - each query one extend/shade iteration of the wavefront.
      * The PBR model's Metal variant (three lobes, textures) is not covered. */
     uint32_t metalSemantics;
     uint32_t sssMode;   /* RenderSettings::SssMode: 0 off, 1 separable, 2 random walk; read only with PTR_METAL_SSS */
+    uint32_t sssMaxSteps;   /* RenderSettings::sssMaxSteps (32): closest-hit queries per random walk, at least 1 */
 } PtrSettings;
 
 enum { PTR_METAL_MEDIA = 1u, PTR_METAL_THIN = 2u, PTR_METAL_FACE_NORMAL = 4u, PTR_METAL_SPECULAR = 8u, PTR_METAL_SSS = 16u };

@@ -131,6 +131,7 @@ class PtrSettings(C.Structure):
         ("emissionScale", C.c_float),
         ("metalSemantics", C.c_uint32),
         ("sssMode", C.c_uint32),
+        ("sssMaxSteps", C.c_uint32),
     ]
 
     def copy(self) -> "PtrSettings":

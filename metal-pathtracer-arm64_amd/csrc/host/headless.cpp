@@ -40,6 +40,7 @@ void FillPtrSettings(const RenderSettings& s, PtrSettings& o) {
     o.emissionScale = 1.0f;
     o.metalSemantics = s.metalSemantics;
     o.sssMode = static_cast<uint32_t>(s.sssMode);
+    o.sssMaxSteps = s.sssMaxSteps;
 }
 
 bool HipHeadlessRenderer::render(const HeadlessScene& scene, const HeadlessCamera&, const RenderSettings& settings,

@@ -359,6 +359,7 @@ void fillRenderParams(const PtrSettings& s, uint32_t spp, RenderParams& rp) {
     rp.emissionScale = (s.emissionScale > 0.0f && std::isfinite(s.emissionScale)) ? s.emissionScale : 1.0f;
     rp.mediaMode = s.metalSemantics & (PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL | PTR_METAL_SPECULAR | PTR_METAL_SSS);
     rp.sssMode = s.sssMode;
+    rp.sssMaxSteps = std::max(s.sssMaxSteps, 1u);
 }
 
 // Local pixel order of a partition: its PTR_BAND_ROWS-row bands top to bottom, each walked in 8x8 blocks so the
@@ -400,9 +401,6 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     const bool soloGroup = (mode & 2) != 0;     // one pool group: kernels run alone, for clean per-kernel timings
     if (settings.width == 0 || settings.height == 0) throw HipError{"render size must be non-zero"};
     if (parts == 0 || part >= parts) throw HipError{"bad partition"};
-    if ((settings.metalSemantics & PTR_METAL_SSS) && settings.sssMode == 2u && ds.hasRandomWalkMaterial) {
-        throw HipError{"random-walk subsurface scattering (sssMode 2 on a material that asks for it) is not implemented"};
-    }
     HIP_CHECK(hipSetDevice(ds.device));
 
     RenderParams rp;
@@ -590,7 +588,9 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     for (uint32_t g = 1; g < groupCount; ++g) HIP_CHECK(hipStreamWaitEvent(groups[g].stream, ds.groupEvents[0], 0));
     uint64_t iterations = 0;
     // Worst case: every sample runs maxDepth bounces in sequence on its slot.
-    const uint64_t maxIterations = static_cast<uint64_t>(rp.maxDepth) * ((itemCount64 + slots - 1) / slots + 1) * chunkSize + 8;
+    // (a subsurface random walk adds up to sssMaxSteps iterations to a bounce)
+    const uint64_t perBounce = ((rp.mediaMode & PTR_METAL_SSS) && rp.sssMode == 2u && ds.hasRandomWalkMaterial) ? 1ull + rp.sssMaxSteps : 1ull;
+    const uint64_t maxIterations = static_cast<uint64_t>(rp.maxDepth) * perBounce * ((itemCount64 + slots - 1) / slots + 1) * chunkSize + 8;
     // Phase 1: while unclaimed work items remain nobody needs to count survivors; the host looks at the item head
     // only when it expects it to be nearly exhausted (items are claimed at a steady rate, so after the first look the
     // next one is scheduled at 3/4 of the predicted remaining iterations).  Phase 2 (queue dry): k_shade counts live

@@ -728,6 +728,171 @@ __device__ bool sampleSeparableSss(const Mat& m, f3 position, f3 n, f3 wo, uint3
     return true;
 }
 
+// ---- random-walk subsurface scattering of the Metal integrator (sample_sss_random_walk_software,
+// shaders/pathtrace.metal:4060-4311), cut into "begin" and "step": the reference runs the walk as a loop of closest-hit
+// queries inside the sampling step; in the wavefront every query is one extend/shade iteration, and the slot carries
+// the walk state in between (k_shade).  oracle/oracle_integrator.cpp holds the same two functions.
+struct SssWalk {
+    f3 position, direction, throughput;
+    uint32_t step;
+};
+constexpr int kWalkFallback = 0, kWalkSample = 1, kWalkWalking = 2;
+
+__device__ __forceinline__ f3 refractMetal(f3 i, f3 n, float eta) {   // MSL refract(): zero vector on total internal reflection
+    const float ndi = dot(n, i);
+    const float k = 1.0f - eta * eta * (1.0f - ndi * ndi);
+    if (k < 0.0f) return mk3(0.0f);
+    return eta * i - (eta * ndi + sqrtf(k)) * n;
+}
+
+__device__ __forceinline__ f3 offsetSurfacePoint(f3 point, f3 normal, f3 direction) {   // :1210-1220
+    const f3 n = (finite3(normal) && dot(normal, normal) > 0.0f) ? normalize(normal) : mk3(0.0f, 1.0f, 0.0f);
+    const float sign = dot(direction, n) >= 0.0f ? 1.0f : -1.0f;
+    f3 origin = point + n * (sign * 1.0e-4f * 4.0f);
+    origin += (direction * 1.0e-4f) * 0.5f;
+    return origin;
+}
+
+// lobe pick, then the coat reflection (a finished sample) or the refraction into the medium (walk state)
+__device__ int sssWalkBegin(const Mat& m, f3 point, f3 entryNormal, f3 wo, f3 incident, uint32_t& rng, const ClampCfg& cc,
+                            BsdfSampleResult& sample, SssWalk& walk) {
+    const Coat c = loadCoat(m);
+    const float pCoat = clampf(c.sampleWeight, 0.0f, 1.0f);
+    const float randLobe = rngNext(rng);
+    const float alpha = c.roughness * c.roughness;
+    const float ratio = (c.ior - 1.0f) / smax(c.ior + 1.0f, 1.0e-6f);
+    const f3 f0 = mk3(clampf(ratio * ratio, 0.0f, 0.999f));   // plastic_coat_f0, :3861-3866
+    const f3 specTint = coatSpecTint(c);
+    if (pCoat > 0.0f && randLobe < pCoat) {   // :4104-4155
+        const f3 wh = sampleGgxVndf(rng, c.roughness, entryNormal, wo);
+        if (dot(wh, entryNormal) <= 0.0f) return kWalkFallback;
+        f3 wi = reflectDir(-wo, wh);
+        if (!(dot(wi, wi) > 0.0f)) return kWalkFallback;
+        wi = normalize(wi);
+        if (!finite3(wi)) return kWalkFallback;
+        const float cosI = dot(entryNormal, wi), cosO = dot(entryNormal, wo);
+        if (cosI <= 0.0f || cosO <= 0.0f) return kWalkFallback;
+        const float dotWiWh = dot(wi, wh);
+        if (dotWiWh <= 0.0f) return kWalkFallback;
+        const float D = ggxD(alpha, dot(entryNormal, wh));
+        const float G = ggxG1(alpha, cosO) * ggxG1(alpha, cosI);
+        const f3 F = schlick(f0, dotWiWh);
+        f3 spec = F * (D * G / smax(4.0f * cosO * cosI, 1.0e-6f));
+        spec = clampSpecTail(spec * specTint, c.roughness, f0, cc);
+        const float specPdfRaw = ggxPdfVisible(alpha, entryNormal, wo, wi);
+        if (specPdfRaw <= 0.0f) return kWalkFallback;
+        const float specPdf = clampSpecPdf(specPdfRaw, cc);
+        const float combinedPdf = smax(pCoat * specPdf, 1.0e-6f);
+        const f3 weight = vmax0(spec * cosI / combinedPdf);
+        if (!finite3(weight)) return kWalkFallback;
+        sample.dir = wi;
+        sample.weight = weight;
+        sample.pdf = specPdf;   // the directional pdf (see sampleSeparableSss)
+        sample.isDelta = false;
+        sample.mediumEvent = 0;
+        sample.hasExit = false;
+        return kWalkSample;
+    }
+    const float pDiffuse = smax(1.0f - pCoat, 1.0e-3f);
+    f3 throughput = mk3(1.0f / pDiffuse);
+    const float etaInside = smax(m.ior(), 1.0f);
+    const float cosThetaI = dot(-incident, entryNormal);
+    if (cosThetaI <= 0.0f) return kWalkFallback;
+    float cosThetaT = 0.0f;
+    const float frEntry = fresnelDielectric(cosThetaI, 1.0f, etaInside, cosThetaT);
+    f3 enterDir = refractMetal(incident, entryNormal, 1.0f / etaInside);
+    if (!finite3(enterDir) || dot(enterDir, enterDir) <= 0.0f) return kWalkFallback;
+    enterDir = normalize(enterDir);
+    const float scaleEntry = (etaInside * etaInside) * (cosThetaT / smax(cosThetaI, 1.0e-6f));
+    throughput *= smax(1.0f - frEntry, 0.0f) * scaleEntry;
+    if (m.v(kMatSssParams).z > 0.5f) throughput = throughput * specTint;
+    walk.position = offsetSurfacePoint(point, -entryNormal, enterDir);
+    walk.direction = enterDir;
+    walk.throughput = throughput;
+    walk.step = 0u;
+    return kWalkWalking;
+}
+
+__device__ __forceinline__ f3 sampleHenyeyGreenstein(f3 reference, float g, uint32_t& rng) {   // :4011-4036
+    const float u1 = rngNext(rng);
+    const float u2 = rngNext(rng);
+    float cosTheta;
+    if (fabsf(g) < 1.0e-3f) {
+        cosTheta = 1.0f - 2.0f * u1;
+    } else {
+        const float s = (1.0f - g * g) / (1.0f - g + 2.0f * g * u1);
+        cosTheta = clampf((1.0f + g * g - s * s) / (2.0f * g), -1.0f, 1.0f);
+    }
+    const float sinTheta = sqrtf(smax(0.0f, 1.0f - cosTheta * cosTheta));
+    const float phi = 2.0f * kPi * u2;
+    const f3 local = mk3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+    if (!(dot(reference, reference) > 0.0f)) return mk3(0.0f);
+    const Frame fr = makeFrame(reference);
+    const f3 world = (local.x * fr.t + local.y * fr.b) + local.z * fr.n;
+    return dot(world, world) > 0.0f ? normalize(world) : mk3(0.0f);
+}
+
+// one pass of the reference's loop body, given the closest hit of the ray (walk.position, walk.direction)
+__device__ int sssWalkStep(const Mat& m, uint32_t maxSteps, SssWalk& walk, bool hitBoundary, float hitT, f3 hitPoint, f3 outwardNormal,
+                           uint32_t& rng, BsdfSampleResult& sample) {
+    const float anisotropy = clampf(m.v(kMatSssSigmaS).w, -0.99f, 0.99f);
+    const SssCoefficients c = sssCoefficients(m, smax(m.v(kMatSssParams).x, 1.0e-4f), anisotropy);
+    const f3 sigmaT = vmaxs(c.sigmaA + c.sigmaSPrime, 1.0e-6f);
+    const float sigmaTScalar = smax(smax(sigmaT.x, smax(sigmaT.y, sigmaT.z)), 1.0e-4f);
+    const float xi = clampf(rngNext(rng), 1.0e-6f, 1.0f - 1.0e-6f);
+    const float distance = -logf(1.0f - xi) / sigmaTScalar;
+    if (!hitBoundary) return kWalkFallback;
+    const float boundaryDistance = smax(hitT, 1.0e-4f);
+    const uint32_t limit = max(maxSteps, 1u);
+    if (distance < boundaryDistance) {   // scattering event inside, :4227-4245
+        walk.throughput = walk.throughput * vexp(-(sigmaT * distance));
+        walk.throughput = walk.throughput * vclamp(c.sigmaSPrime / vmaxs(sigmaT, 1.0e-6f), 0.0f, 1.0f);
+        if (smax(walk.throughput.x, smax(walk.throughput.y, walk.throughput.z)) < 1.0e-3f) return kWalkFallback;
+        walk.position += walk.direction * distance;
+        const f3 scattered = sampleHenyeyGreenstein(-walk.direction, anisotropy, rng);
+        if (!finite3(scattered) || dot(scattered, scattered) <= 0.0f) return kWalkFallback;
+        walk.direction = normalize(scattered);
+        ++walk.step;
+        return walk.step < limit ? kWalkWalking : kWalkFallback;
+    }
+    walk.throughput = walk.throughput * vexp(-(sigmaT * boundaryDistance));
+    if (smax(walk.throughput.x, smax(walk.throughput.y, walk.throughput.z)) < 1.0e-3f) return kWalkFallback;
+    if (!finite3(outwardNormal) || dot(outwardNormal, outwardNormal) <= 0.0f) return kWalkFallback;
+    outwardNormal = normalize(outwardNormal);
+    const float etaI = smax(m.ior(), 1.0f);
+    // :4262-4268 as written: the exit is taken only where the geometric normal faces the ray; a ray that reaches the
+    // boundary of a closed mesh from inside is reflected back in
+    const float cosExitI = dot(-walk.direction, outwardNormal);
+    f3 refracted = mk3(0.0f);
+    float cosExitT = 0.0f, frExit = 1.0f;
+    bool leaves = cosExitI > 0.0f;
+    if (leaves) {
+        frExit = fresnelDielectric(cosExitI, etaI, 1.0f, cosExitT);
+        refracted = refractMetal(walk.direction, outwardNormal, etaI);
+        leaves = finite3(refracted) && dot(refracted, refracted) > 0.0f;
+    }
+    if (!leaves) {
+        walk.position = hitPoint;
+        walk.direction = normalize(reflectDir(walk.direction, outwardNormal));
+        ++walk.step;
+        return walk.step < limit ? kWalkWalking : kWalkFallback;
+    }
+    refracted = normalize(refracted);
+    const float scaleExit = (1.0f / (etaI * etaI)) * (cosExitT / smax(cosExitI, 1.0e-6f));
+    f3 throughput = walk.throughput * (smax(1.0f - frExit, 0.0f) * scaleExit);
+    if (m.v(kMatSssParams).z > 0.5f) throughput = throughput * coatSpecTint(loadCoat(m));
+    throughput = vmax0(throughput);
+    if (!finite3(throughput)) return kWalkFallback;
+    sample.dir = refracted;
+    sample.weight = throughput;
+    sample.pdf = 1.0f;   // directionalPdf (:4297)
+    sample.isDelta = false;
+    sample.mediumEvent = 0;
+    sample.hasExit = true;
+    sample.exitPoint = hitPoint;
+    return kWalkSample;
+}
+
 template <bool SSS = false>
 __device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 incident, bool frontFace,
                                        uint32_t& rng, const ClampCfg& cc) {

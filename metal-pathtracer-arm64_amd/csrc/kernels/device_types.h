@@ -89,6 +89,7 @@ struct RenderParams {
     uint32_t localPixels;          // pixels owned by this partition
     uint32_t mediaMode;            // PTR_METAL_* bits (0 = Embree-parity integrator)
     uint32_t sssMode;              // RenderSettings::SssMode, read only with PTR_METAL_SSS
+    uint32_t sssMaxSteps;          // closest-hit queries per random walk (>= 1)
     uint32_t itemHeadFirst;        // items below this are pre-assigned to the slots by k_generate
     uint32_t itemsPerHead;         // the remaining items are split into kItemHeads ranges of this size (multiple of 64)
     uint32_t enableRussianRoulette, enableSpecularNee, enableMnee, enableMneeSecondary;
@@ -148,6 +149,7 @@ constexpr uint32_t kFlagAlive = 1u << 0;
 constexpr uint32_t kFlagLastDelta = 1u << 1;
 constexpr uint32_t kFlagFlush = 1u << 2;        // accumulator belongs to a finished item: store it, then zero
 constexpr uint32_t kFlagMediumShift = 3u;       // 4 bits: depth of the medium stack (0..8)
+constexpr uint32_t kFlagWalk = 1u << 7;         // the slot's ray is a step of a subsurface random walk (state in record slot 4)
 constexpr uint32_t kMaxMediumStack = 8u;
 constexpr uint32_t kFlagDepthShift = 8u;        // 12 bits
 constexpr uint32_t kFlagSpecDepthShift = 20u;   // 12 bits

@@ -565,7 +565,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
     const bool touched = inRange && (active || (st.w & 0xFFu) != 0u || (st.z & kFlagFlush));   // state/accum rewritten
 
     bool want[kRecSlots] = {false, false, false, false, false};
-    bool stillAlive = false, needItem = false;
+    bool stillAlive = false, needItem = false, walkFlag = false;
     uint32_t shadedHit = 0u, triHit = 0u, primary = 0u;
     uint32_t sampleInChunk = (st.w >> 8) & 0xFFu;
     uint32_t rng = st.x;
@@ -604,8 +604,66 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
             bool endPath = false;
             nextO = rayO;
             nextD = rayD;
+            bool walking = false;   // SSS: the slot stays in (or enters) a subsurface random walk: no bounce bookkeeping this visit
 
-            if (prim == kHitMiss) {
+            if (SSS && (st.z & kFlagWalk)) {
+                // ---- one step of a subsurface random walk: this ray was the walk's boundary query (bsdf.h: sssWalkStep) ----
+                const ShadowRecordView& wr = pool.rec[4];
+                const float4 w0 = wr.org[slot], w1 = wr.dir[slot], w2 = wr.a[slot], w3 = wr.b[slot];
+                const uint32_t entryMaterial = __float_as_uint(w1.w);
+                const Mat mat{sc.materials + static_cast<size_t>(min(entryMaterial, sc.materialCount - 1u)) * kMaterialVec4};
+                SssWalk walk{rayO, rayD, mk3(w2), __float_as_uint(w2.w)};
+                f3 hitPoint = rayO, outward = mk3(0.0f);
+                if (prim != kHitMiss) {
+                    const Surface bsf = reconstruct(sc, rayO, rayD, hitv.x, hitv.y, hitv.z, prim);
+                    hitPoint = bsf.position;
+                    outward = bsf.normal;   // the geometric normal as stored = the reference's face-forwarded normal turned back
+                }
+                BsdfSampleResult bs{mk3(0.0f), mk3(0.0f), 0.0f, false, 0, false, mk3(0.0f)};
+                int outcome = sssWalkStep(mat, rp.sssMaxSteps, walk, prim != kHitMiss, hitv.x, hitPoint, outward, rng, bs);
+                if (outcome == kWalkWalking) {
+                    walking = true;
+                    nextO = walk.position;
+                    nextD = walk.direction;
+                    wr.a[slot] = mk4(walk.throughput, __uint_as_float(walk.step));
+                } else {
+                    // the walk is over: its exit sample, or (abandoned) the ordinary sample at the entry point
+                    const f3 entryN = mk3(w3);
+                    if (outcome == kWalkFallback) bs = sampleBsdf<true>(mat, mk3(w0), entryN, entryN, -entryN, true, rng, cc);
+                    if (bs.pdf <= 0.0f || dot(bs.dir, bs.dir) <= 0.0f || !finite3(bs.weight)) {
+                        endPath = true;
+                    } else {
+                        specDepth = 0u;
+                        thr *= bs.weight;
+                        thr = clampThroughput(thr, cc);
+                        const float maxComp = smax(smax(thr.x, thr.y), thr.z);
+                        if (!finite3(thr) || maxComp <= 0.0f) {
+                            endPath = true;
+                        } else {
+                            lastPdf = bs.pdf > 0.0f ? bs.pdf : lastPdf;
+                            lastDelta = false;
+                            if (outcome == kWalkSample) {
+                                nextO = sssExitOrigin(bs.exitPoint, outward, bs.dir);
+                            } else {
+                                // offsetOrigin at the entry hit (its offset normal and distance were parked with the walk)
+                                const f3 on = mk3(w1);
+                                const float sign = dot(bs.dir, on) >= 0.0f ? 1.0f : -1.0f;
+                                nextO = mk3(w0) + on * (sign * smax(fabsf(w0.w) * 1.0e-4f, kEps));
+                                nextO += (bs.dir * kEps) * 0.5f;
+                            }
+                            nextD = bs.dir;
+                            if (rp.enableRussianRoulette && depth >= 5u) {
+                                const float p = clampf(maxComp, 0.05f, 0.95f);
+                                if (rngNext(rng) > p) {
+                                    endPath = true;
+                                } else {
+                                    thr /= p;
+                                }
+                            }
+                        }
+                    }
+                }
+            } else if (prim == kHitMiss) {
                 // ---- escaped: background, MIS-weighted against environment sampling ----
                 f3 bg;
                 if (rp.backgroundMode == PTR_BG_SOLID) {
@@ -748,8 +806,33 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
                     }
 
                     // ---- continue the path ----
-                    const BsdfSampleResult bs = sampleBsdf<SSS>(mat, sf.position, n, wo, incident, sf.frontFace, rng, cc);
-                    if (bs.pdf <= 0.0f || dot(bs.dir, bs.dir) <= 0.0f || !finite3(bs.weight)) {
+                    BsdfSampleResult bs{mk3(0.0f), mk3(0.0f), 0.0f, false, 0, false, mk3(0.0f)};
+                    bool haveSample = false;
+                    if (SSS && type == 5u && cc.metalSss && rp.sssMode == 2u && mat.v(kMatSssParams).y >= 0.5f && sf.frontFace) {
+                        // random-walk subsurface scattering (pathtrace.metal:6650-6676): coat lobe, or into the medium
+                        SssWalk walk;
+                        const int outcome = sssWalkBegin(mat, sf.position, sf.normal, wo, incident, rng, cc, bs, walk);
+                        haveSample = outcome == kWalkSample;
+                        if (outcome == kWalkWalking) {
+                            walking = true;
+                            nextO = walk.position;
+                            nextD = walk.direction;
+                            // what the ordinary sample needs should the walk be abandoned: entry point and hit distance, the
+                            // normal offsetOrigin pushes along, the material, the shading normal
+                            f3 on = sf.hitShadingNormal;
+                            if (dot(on, on) <= 0.0f) on = sf.normal;
+                            if (dot(on, on) <= 0.0f) on = mk3(0.0f, 1.0f, 0.0f);
+                            const ShadowRecordView& wr = pool.rec[4];
+                            wr.org[slot] = mk4(sf.position, sf.t);
+                            wr.dir[slot] = mk4(normalize(on), __uint_as_float(min(sf.material, sc.materialCount - 1u)));
+                            wr.a[slot] = mk4(walk.throughput, __uint_as_float(0u));
+                            wr.b[slot] = mk4(n, 0.0f);
+                        }
+                    }
+                    if (!SSS || (!haveSample && !walking)) bs = sampleBsdf<SSS>(mat, sf.position, n, wo, incident, sf.frontFace, rng, cc);
+                    if (SSS && walking) {
+                        // nothing else this visit: the walk's first boundary query is the slot's next ray
+                    } else if (bs.pdf <= 0.0f || dot(bs.dir, bs.dir) <= 0.0f || !finite3(bs.weight)) {
                         endPath = true;
                     } else {
                         if ((rp.mediaMode & PTR_METAL_MEDIA) && bs.mediumEvent != 0) {
@@ -823,8 +906,10 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
                 }
             }
 
-            ++depth;
-            if (depth >= rp.maxDepth) endPath = true;
+            if (!(SSS && walking)) {
+                ++depth;
+                if (depth >= rp.maxDepth) endPath = true;
+            }
 
             if (endPath) {
                 // next sample of the same work item, or (below, wave-wide) a new work item
@@ -847,6 +932,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
                 }
             } else {
                 stillAlive = true;
+                walkFlag = SSS && walking;
             }
         }
     }
@@ -923,7 +1009,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
     }
     if (touched) {
         st.x = rng;
-        st.z = (stillAlive ? kFlagAlive : 0u) | (lastDelta ? kFlagLastDelta : 0u) | (flushNext ? kFlagFlush : 0u) |
+        st.z = (stillAlive ? kFlagAlive : 0u) | (lastDelta ? kFlagLastDelta : 0u) | (flushNext ? kFlagFlush : 0u) | (walkFlag ? kFlagWalk : 0u) |
                (depth << kFlagDepthShift) | (specDepth << kFlagSpecDepthShift) | (mediumDepth << kFlagMediumShift);
         st.w = pendingMask | (sampleInChunk << 8);
         pool.state[slot] = st;

@@ -725,6 +725,7 @@ ClampParams makeClampParams(const PtrSettings& s) {  // E:381-391
     p.metalSpecular = (s.metalSemantics & PTR_METAL_SPECULAR) != 0u;
     p.metalSss = (s.metalSemantics & PTR_METAL_SSS) != 0u;
     p.sssMode = s.sssMode;
+    p.sssMaxSteps = std::max(s.sssMaxSteps, 1u);
     return p;
 }
 
@@ -973,6 +974,182 @@ V3 sssExitOrigin(V3 exitPoint, V3 exitNormal, V3 direction) {
     const V3 d = (finite3(direction) && dot(direction, direction) > 0.0f) ? normalize(direction) : n;
     o += d * std::max(5.0e-3f * 8.0f, kEpsilon * 32.0f);
     return o;
+}
+
+
+// ---- random-walk subsurface scattering of the Metal integrator, sample_sss_random_walk_software M:4060-4311 ----
+// (Metal-only semantics, PTR_METAL_SSS with sssMode == 2 on front-face hits of materials whose sssParams.y >= 0.5.)
+// The reference runs the walk as a loop of closest-hit queries inside the sampling step; here it is cut into "begin" and
+// "step" so the HIP wavefront, where every query is one extend/shade iteration, runs the very same two functions' twins.
+struct SssWalk {
+    V3 position, direction, throughput;
+    uint32_t step = 0;
+};
+enum class WalkOutcome { Fallback, Sample, Walking };
+
+V3 refractMetal(V3 i, V3 n, float eta) {   // MSL refract(): zero vector on total internal reflection
+    const float ndi = dot(n, i);
+    const float k = 1.0f - eta * eta * (1.0f - ndi * ndi);
+    if (k < 0.0f) return V3();
+    return eta * i - (eta * ndi + std::sqrt(k)) * n;
+}
+
+V3 offsetSurfacePoint(V3 point, V3 normal, V3 direction) {  // M:1210-1220
+    const V3 n = (finite3(normal) && dot(normal, normal) > 0.0f) ? normalize(normal) : V3(0.0f, 1.0f, 0.0f);
+    const float sign = dot(direction, n) >= 0.0f ? 1.0f : -1.0f;
+    V3 origin = point + n * (sign * kEpsilon * 4.0f);
+    origin += (direction * kEpsilon) * 0.5f;
+    return origin;
+}
+
+void sssWalkMedium(const PtrMaterial& m, V3& sigmaT, V3& sigmaSPrime, float& sigmaTScalar, float& anisotropy) {  // M:4158-4166
+    anisotropy = clampf(m.sssSigmaS[3], -0.99f, 0.99f);
+    const float meanFreePath = std::max(m.sssParams[0], 1.0e-4f);
+    V3 sigmaA;
+    sssCoefficients(m, meanFreePath, anisotropy, sigmaA, sigmaSPrime);
+    sigmaT = vmaxs(sigmaA + sigmaSPrime, 1.0e-6f);
+    sigmaTScalar = std::max(std::max(sigmaT.x, std::max(sigmaT.y, sigmaT.z)), 1.0e-4f);
+}
+
+// Lobe pick, then either the coat reflection (a finished sample) or the refraction into the medium (walk state).
+WalkOutcome sssWalkBegin(const PtrMaterial& m, V3 point, V3 entryNormal, V3 wo, V3 incidentDir, Rng& rng, const ClampParams& cp,
+                         BsdfSample& sample, SssWalk& walk) {
+    const float pCoat = clampf(m.coatParams[2], 0.0f, 1.0f);
+    const float randLobe = rng.nextFloat();
+    const float roughness = coatRoughness(m);
+    const float alpha = roughness * roughness;
+    const float eta = coatIor(m);
+    const float ratio = (eta - 1.0f) / std::max(eta + 1.0f, 1.0e-6f);
+    const V3 f0 = splat(clampf(ratio * ratio, 0.0f, 0.999f));   // plastic_coat_f0, M:3861-3866
+    const V3 specTint = plasticSpecularTint(m);
+    if (pCoat > 0.0f && randLobe < pCoat) {   // M:4104-4155
+        const V3 wh = sampleGgxVndf(rng, roughness, entryNormal, wo);
+        if (dot(wh, entryNormal) <= 0.0f) return WalkOutcome::Fallback;
+        V3 wi = reflect(-wo, wh);
+        if (!(dot(wi, wi) > 0.0f)) return WalkOutcome::Fallback;
+        wi = normalize(wi);
+        if (!finite3(wi)) return WalkOutcome::Fallback;
+        const float cosI = dot(entryNormal, wi), cosO = dot(entryNormal, wo);
+        if (cosI <= 0.0f || cosO <= 0.0f) return WalkOutcome::Fallback;
+        const float dotWiWh = dot(wi, wh);
+        if (dotWiWh <= 0.0f) return WalkOutcome::Fallback;
+        const float D = ggxDistribution(alpha, dot(entryNormal, wh));
+        const float G = ggxG1(alpha, cosO) * ggxG1(alpha, cosI);
+        const V3 F = schlickFresnel(f0, dotWiWh);
+        V3 spec = F * (D * G / std::max(4.0f * cosO * cosI, 1.0e-6f));
+        spec = clampSpecularTail(spec * specTint, roughness, f0, cp);
+        const float specPdfRaw = ggxPdfVisible(alpha, entryNormal, wo, wi);
+        if (specPdfRaw <= 0.0f) return WalkOutcome::Fallback;
+        const float specPdf = clampSpecularPdf(specPdfRaw, cp);
+        const float combinedPdf = std::max(pCoat * specPdf, 1.0e-6f);
+        const V3 weight = vmax(spec * cosI / combinedPdf, V3());
+        if (!finite3(weight)) return WalkOutcome::Fallback;
+        sample = BsdfSample();
+        sample.direction = wi;
+        sample.weight = weight;
+        sample.pdf = specPdf;   // directionalPdf: what the next emitter hit's MIS uses (M:7269); pdf = pCoat x this is > 0 with it
+        return WalkOutcome::Sample;
+    }
+    const float pDiffuse = std::max(1.0f - pCoat, 1.0e-3f);
+    V3 throughput = splat(1.0f / pDiffuse);
+    const float etaInside = std::max(m.typeEta[1], 1.0f);
+    const float cosThetaI = dot(-incidentDir, entryNormal);
+    if (cosThetaI <= 0.0f) return WalkOutcome::Fallback;
+    float cosThetaT = 0.0f;
+    const float frEntry = fresnelDielectricExact(cosThetaI, 1.0f, etaInside, cosThetaT);
+    V3 enterDir = refractMetal(incidentDir, entryNormal, 1.0f / etaInside);
+    if (!finite3(enterDir) || dot(enterDir, enterDir) <= 0.0f) return WalkOutcome::Fallback;
+    enterDir = normalize(enterDir);
+    const float scaleEntry = (etaInside * etaInside) * (cosThetaT / std::max(cosThetaI, 1.0e-6f));
+    throughput *= std::max(1.0f - frEntry, 0.0f) * scaleEntry;
+    if (m.sssParams[2] > 0.5f) throughput = throughput * specTint;
+    walk.position = offsetSurfacePoint(point, -entryNormal, enterDir);
+    walk.direction = enterDir;
+    walk.throughput = throughput;
+    walk.step = 0;
+    return WalkOutcome::Walking;
+}
+
+V3 sampleHenyeyGreenstein(V3 reference, float g, Rng& rng) {  // M:4011-4036
+    const float u1 = rng.nextFloat();
+    const float u2 = rng.nextFloat();
+    float cosTheta;
+    if (std::fabs(g) < 1.0e-3f) {
+        cosTheta = 1.0f - 2.0f * u1;
+    } else {
+        const float s = (1.0f - g * g) / (1.0f - g + 2.0f * g * u1);
+        cosTheta = clampf((1.0f + g * g - s * s) / (2.0f * g), -1.0f, 1.0f);
+    }
+    const float sinTheta = std::sqrt(std::max(0.0f, 1.0f - cosTheta * cosTheta));
+    const float phi = 2.0f * kPi * u2;
+    const V3 local(sinTheta * std::cos(phi), sinTheta * std::sin(phi), cosTheta);
+    if (!(dot(reference, reference) > 0.0f)) return V3();
+    const Onb onb = buildOnb(reference);
+    const V3 world = (local.x * onb.tangent + local.y * onb.bitangent) + local.z * onb.normal;
+    return dot(world, world) > 0.0f ? normalize(world) : V3();
+}
+
+// One pass of the reference's loop body, given the closest hit of the ray (walk.position, walk.direction): Walking = go on
+// with the updated ray, Sample = the path leaves the medium, Fallback = the walk is abandoned (pdf 0 in the reference).
+WalkOutcome sssWalkStep(const PtrMaterial& m, uint32_t maxSteps, SssWalk& walk, bool hitBoundary, float hitT, V3 hitPoint, V3 outwardNormal,
+                        Rng& rng, BsdfSample& sample) {
+    V3 sigmaT, sigmaSPrime;
+    float sigmaTScalar, anisotropy;
+    sssWalkMedium(m, sigmaT, sigmaSPrime, sigmaTScalar, anisotropy);
+    const float xi = clampf(rng.nextFloat(), 1.0e-6f, 1.0f - 1.0e-6f);
+    const float distance = -std::log(1.0f - xi) / sigmaTScalar;
+    if (!hitBoundary) return WalkOutcome::Fallback;
+    const float boundaryDistance = std::max(hitT, 1.0e-4f);
+    const uint32_t limit = std::max(maxSteps, 1u);
+    auto goOn = [&]() {
+        ++walk.step;
+        return walk.step < limit ? WalkOutcome::Walking : WalkOutcome::Fallback;
+    };
+    if (distance < boundaryDistance) {   // scattering event inside, M:4227-4245
+        walk.throughput = walk.throughput * vexp3(-(sigmaT * distance));
+        walk.throughput = walk.throughput * vclamp01(sigmaSPrime / vmaxs(sigmaT, 1.0e-6f));
+        if (std::max(walk.throughput.x, std::max(walk.throughput.y, walk.throughput.z)) < 1.0e-3f) return WalkOutcome::Fallback;
+        walk.position += walk.direction * distance;
+        const V3 scattered = sampleHenyeyGreenstein(-walk.direction, anisotropy, rng);
+        if (!finite3(scattered) || dot(scattered, scattered) <= 0.0f) return WalkOutcome::Fallback;
+        walk.direction = normalize(scattered);
+        return goOn();
+    }
+    walk.throughput = walk.throughput * vexp3(-(sigmaT * boundaryDistance));
+    if (std::max(walk.throughput.x, std::max(walk.throughput.y, walk.throughput.z)) < 1.0e-3f) return WalkOutcome::Fallback;
+    if (!finite3(outwardNormal) || dot(outwardNormal, outwardNormal) <= 0.0f) return WalkOutcome::Fallback;
+    outwardNormal = normalize(outwardNormal);
+    const float etaI = std::max(m.typeEta[1], 1.0f);
+    // M:4262-4268 as written: the exit is taken only where the geometric normal faces the ray; a ray that reaches the
+    // boundary of a closed mesh from inside is reflected back in
+    const float cosExitI = dot(-walk.direction, outwardNormal);
+    if (cosExitI <= 0.0f) {
+        walk.position = hitPoint;
+        walk.direction = normalize(reflect(walk.direction, outwardNormal));
+        return goOn();
+    }
+    float cosExitT = 0.0f;
+    const float frExit = fresnelDielectricExact(cosExitI, etaI, 1.0f, cosExitT);
+    V3 refracted = refractMetal(walk.direction, outwardNormal, etaI);
+    if (!finite3(refracted) || dot(refracted, refracted) <= 0.0f) {
+        walk.position = hitPoint;
+        walk.direction = normalize(reflect(walk.direction, outwardNormal));
+        return goOn();
+    }
+    refracted = normalize(refracted);
+    const float scaleExit = (1.0f / (etaI * etaI)) * (cosExitT / std::max(cosExitI, 1.0e-6f));
+    V3 throughput = walk.throughput * (std::max(1.0f - frExit, 0.0f) * scaleExit);
+    if (m.sssParams[2] > 0.5f) throughput = throughput * plasticSpecularTint(m);
+    throughput = vmax(throughput, V3());
+    if (!finite3(throughput)) return WalkOutcome::Fallback;
+    sample = BsdfSample();
+    sample.direction = refracted;
+    sample.weight = throughput;
+    sample.pdf = 1.0f;   // directionalPdf (M:4297); the reference's pdf = max(pDiffuse, 1e-4) is positive with it
+    sample.hasExitPoint = true;
+    sample.exitPoint = hitPoint;
+    sample.exitNormal = outwardNormal;
+    return WalkOutcome::Sample;
 }
 
 }  // namespace
@@ -1602,7 +1779,19 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
                     }
                 }
 
-                const BsdfSample bs = sampleBsdf(material, hit.position, shadingNormal, wo, incidentDir, hit.frontFace, rng, cp);
+                BsdfSample bs;
+                bool usedRandomWalk = false;   // M:6650-6676
+                if (cp.metalSss && cp.sssMode == 2u && matType(material) == PTR_MAT_SUBSURFACE && material.sssParams[1] >= 0.5f && hit.frontFace) {
+                    SssWalk walk;
+                    WalkOutcome outcome = sssWalkBegin(material, hit.position, hit.normal, wo, incidentDir, rng, cp, bs, walk);
+                    while (outcome == WalkOutcome::Walking) {
+                        HitInfo boundary;
+                        const bool hitBoundary = trace(Ray{walk.position, walk.direction}, boundary);
+                        outcome = sssWalkStep(material, cp.sssMaxSteps, walk, hitBoundary, boundary.t, boundary.position, boundary.normal, rng, bs);
+                    }
+                    usedRandomWalk = outcome == WalkOutcome::Sample;
+                }
+                if (!usedRandomWalk) bs = sampleBsdf(material, hit.position, shadingNormal, wo, incidentDir, hit.frontFace, rng, cp);
                 if (bs.pdf <= 0.0f || dot(bs.direction, bs.direction) <= 0.0f || !finite3(bs.weight)) break;
 
                 if (media && bs.mediumEvent != 0) {  // M:6694-6709
@@ -1704,7 +1893,8 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
 
                 lastBsdfPdf = bs.pdf > 0.0f ? bs.pdf : lastBsdfPdf;
                 lastScatterWasDelta = bs.isDelta;
-                ray.origin = bs.hasExitPoint ? sssExitOrigin(bs.exitPoint, shadingNormal, bs.direction) : offsetRayOrigin(hit, bs.direction);
+                ray.origin = bs.hasExitPoint ? sssExitOrigin(bs.exitPoint, dot(bs.exitNormal, bs.exitNormal) > 0.0f ? bs.exitNormal : shadingNormal, bs.direction)
+                                            : offsetRayOrigin(hit, bs.direction);
                 ray.direction = bs.direction;
 
                 if (settings.enableRussianRoulette && depth >= 5) {

@@ -75,8 +75,9 @@ struct ClampParams {  // FireflyClampParams, :136-144
     float minSpecularPdf = 1.0e-8f, enabled = 0.0f;
     bool thinDielectrics = false;   // PTR_METAL_THIN (Metal-only semantics, shaders/pathtrace.metal:4589-4592, 5649-5659)
     bool metalSpecular = false;     // PTR_METAL_SPECULAR: VNDF sampling, G1 pdf, energy compensation for rough metals
-    bool metalSss = false;          // PTR_METAL_SSS: type 5 evaluates to zero; separable diffusion sampling when sssMode == 1
-    uint32_t sssMode = 0;
+    bool metalSss = false;          // PTR_METAL_SSS: type 5 evaluates to zero; separable diffusion sampling when sssMode == 1,
+    uint32_t sssMode = 0;           // random walk when sssMode == 2 on materials that ask for it
+    uint32_t sssMaxSteps = 32;
 };
 
 struct BsdfEval {
@@ -90,8 +91,9 @@ struct BsdfSample {
     float pdf = 0.0f;
     bool isDelta = false;
     int mediumEvent = 0;   // Metal-only: +1 refracted in through a front face, -1 out through a back face (pathtrace.metal:5683)
-    bool hasExitPoint = false;   // Metal-only separable subsurface sample: the path leaves at exitPoint (normal = shading normal)
+    bool hasExitPoint = false;   // Metal-only subsurface samples: the path leaves at exitPoint
     V3 exitPoint;
+    V3 exitNormal;               // random walk: outward normal at the exit (zero: use the shading normal of the entry)
 };
 
 struct HitInfo {  // :97-107

@@ -344,7 +344,7 @@ def test_metal_subsurface_semantics(tmp_path):
     # PTR_METAL_SSS: type 5 evaluates to zero (no NEE) and, with `renderer sss=separable`, is sampled with the separable
     # diffusion profile - exit point on the tangent plane, biased next-ray origin (shaders/pathtrace.metal:3916-3994,
     # 5398-5507, 6740-6766; restated in the oracle too).  Device functions and images agree with the oracle and differ
-    # from the Embree-parity mode; the random-walk mode is refused.
+    # from the Embree-parity mode; so does the random-walk mode (shaders/pathtrace.metal:4060-4311, 6650-6676).
     scene = ("camera target=0,0.2,0 distance=7 yaw=0.8 pitch=0.35 vfov=30\n"
              "renderer width=96 height=64 maxDepth=6 seed=1337 sss=%s\n"
              "background solid=0.5,0.6,0.8\n"
@@ -385,16 +385,25 @@ def test_metal_subsurface_semantics(tmp_path):
         wi = g[:, :3]
         ev = pt.debug_eval_bsdf(d.materials[mi], s16, np.concatenate([inp, wi], axis=1))
         assert np.all(ev[:, :4] == 0.0)
-    # random walk: refused, loudly
-    p.write_text(scene % ("randomwalk", " method=randomwalk"))
+    # random walk (sssMode 2 on a material that asks for it): every boundary query of the walk is one extend/shade iteration of
+    # the wavefront, the walk state rides in the slot.  The small sphere inside the walker is what lets a walk leave its
+    # medium at all: the reference takes the exit only where the geometric normal faces the ray (see bsdf.h: sssWalkStep).
+    p.write_text((scene % ("randomwalk", " method=randomwalk")) + "sphere center=-1.1,0,0 radius=0.35 material=0\n")
     wh = pt.HostScene.load(str(p))
-    wdev = pt.DeviceScene(wh.desc, 0, keepalive=wh)
-    sw = wh.settings_for(seed=1, metalSemantics=16)
-    assert sw.sssMode == 2
-    with pytest.raises(pt.PtrError, match="random-walk"):
-        wdev.render_image(sw, 1)
-    sw.metalSemantics = 0                                            # Embree-parity mode ignores the setting
-    assert np.isfinite(wdev.render_image(sw, 1)[0]).all()
+    wdev, wosc = pt.DeviceScene(wh.desc, 0, keepalive=wh), ol.OracleScene(wh)
+    sw = wh.settings_for(seed=1337, metalSemantics=16)
+    assert sw.sssMode == 2 and sw.sssMaxSteps == 32
+    _image_parity(wh, wdev, wosc, 96, 64, 6, 1, 32, 0.85, metalSemantics=16)
+    _image_parity(wh, wdev, wosc, 64, 48, 6, 1, 16, 0.85, metalSemantics=16, sssMaxSteps=3, enableRussianRoulette=0)
+    # the walk costs closest-hit queries: more rays than the same frame without it, and the image differs from separable mode
+    _, st_walk = wdev.render_image(sw, 4, count=True)
+    s_sep = sw.copy()
+    s_sep.sssMode = 1
+    img_sep, st_sep = wdev.render_image(s_sep, 4, count=True)
+    assert st_walk.extendRays > 1.2 * st_sep.extendRays
+    sw0 = sw.copy()
+    sw0.metalSemantics = 0                                           # Embree-parity mode ignores the setting
+    assert np.isfinite(wdev.render_image(sw0, 1)[0]).all()
 
 
 def test_first_hit_aovs(materials_scene):

@@ -425,3 +425,31 @@ def test_metal_separable_subsurface_sampler(tmp_path):
     img_s, _, _ = osc.render(s, 32, threads=0)
     assert np.isfinite(img_s).all() and img_s.min() >= 0
     assert np.sqrt(np.mean((img_l - img_s) ** 2)) > 0.01
+
+
+def test_metal_random_walk_subsurface(tmp_path):
+    """PTR_METAL_SSS with sssMode = 2 (shaders/pathtrace.metal:4060-4311, 6650-6676): coat lobe or a walk of closest-hit
+    queries.  As written, a walk leaves its medium only where the geometric normal faces the ray, so inside a closed sphere
+    it is reflected back until the throughput cutoff or the step limit and the bounce falls back to the Lambert sample."""
+    p = tmp_path / "walk.scene"
+    p.write_text(SSS_SCENE % "randomwalk" + "sphere center=3,0,0 radius=1 material=1\n")
+    host = pt.HostScene.load(str(p))
+    osc = ol.OracleScene(host)
+    s = host.settings_for(metalSemantics=16, fireflyClampEnabled=0)
+    assert s.sssMode == 2 and s.sssMaxSteps == 32
+    img, _, c32 = osc.render(s, 16, threads=0, count=True)
+    assert np.isfinite(img).all() and img.min() >= 0
+    # render is a pure function of (seed, pixel, sample) with the walk in it, too
+    img_b, _, _ = osc.render(s, 16, threads=3, count=True)
+    assert np.array_equal(img, img_b)
+    # the step limit bounds the queries of a walk: fewer closest-hit rays with sssMaxSteps = 2 than with 32
+    s2 = s.copy()
+    s2.sssMaxSteps = 2
+    _, _, c2 = osc.render(s2, 16, threads=0, count=True)
+    assert c32["extendRays"] > c2["extendRays"]
+    # only materials that ask for the walk take it: with the walker material off screen the frame matches separable-off Lambert
+    s_off = s.copy()
+    s_off.metalSemantics = 0
+    base, _, c0 = osc.render(s_off, 16, threads=0, count=True)
+    assert c32["extendRays"] > c0["extendRays"]
+    assert np.sqrt(np.mean((img - base) ** 2)) > 0.005

@@ -34,6 +34,7 @@ for pool in [int(x) for x in os.environ.get("POOLS", "0").split(",")]:
         t = (time.perf_counter() - t0) / reps
         if base is None:
             base = t * parts
-        print("pool %9d  parts %d  part-0 render %.2f ms  efficiency %.3f  (%.0f Msamples/s projected)" %
-              (pool, parts, t * 1e3, base / (parts * t), 1920 * 1080 * spp / t / 1e6 * 1.0), flush=True)
+        st = scene.render_device(s, spp, out.data_ptr(), 0, 0, parts, want_stats=True)   # the library's own clock (first launch .. resolve)
+        print("pool %9d  parts %d  part-0 render %.2f ms  efficiency %.3f  (%.0f Msamples/s projected)  inside the library %.2f ms" %
+              (pool, parts, t * 1e3, base / (parts * t), 1920 * 1080 * spp / t / 1e6 * 1.0, st.totalSeconds * 1e3), flush=True)
     scene.close()
