@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "cornell_mesh.scene"))
+    ap.add_argument("--semantics", type=int, default=0,
+                    help="PtrSettings.metalSemantics bit mask (31 = every Metal-only behaviour; 0 = the Embree-parity integrator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save", default="", help="write the last image as PFM (rank 0)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
@@ -124,7 +126,7 @@ def main():
 
     # ---- setup (untimed): parse, build BVH, upload; output buffers in HBM ----
     host = pt.HostScene.load(args.scene, os.path.join(ROOT, "scenes"))
-    settings = host.settings_for(width=args.width, height=args.height, max_depth=args.depth, seed=1337)
+    settings = host.settings_for(width=args.width, height=args.height, max_depth=args.depth, seed=1337, metalSemantics=args.semantics)
     t0 = time.time()
     scene = pt.DeviceScene(host.desc, local_rank, keepalive=host)
     upload_s = time.time() - t0
@@ -218,8 +220,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: Cornell box + one 70,688-triangle OBJ mesh, %dx%d, depth %d, %d spp, seed 1337"
-                            % (args.width, args.height, args.depth, args.spp),
+                "workload": ("BASELINE configs[1]: Cornell box + one 70,688-triangle OBJ mesh" if os.path.basename(args.scene) == "cornell_mesh.scene"
+                             else "scene " + os.path.basename(args.scene))
+                            + ", %dx%d, depth %d, %d spp, seed 1337" % (args.width, args.height, args.depth, args.spp)
+                            + (", metalSemantics %d" % args.semantics if args.semantics else ""),
                 "partition": "8-row bands round-robin over %d rank(s), RCCL gather of the HDR buffer" % world,
                 "bvh_upload_s": round(upload_s, 3),
             },
