@@ -171,13 +171,17 @@ typedef struct PtrSettings {
      * it (sssParams.y >= 0.5) run the random walk of sample_sss_random_walk_software (:4060-4311): coat lobe or refraction
      * into the medium, free flights against the closest boundary with Henyey-Greenstein scattering, up to sssMaxSteps
      * queries, Lambert fallback when the walk is abandoned - each query one extend/shade iteration of the wavefront.
-     * The PBR model's Metal variant (three lobes, textures) is not covered. */
+     * Bit 5 (PTR_METAL_PBR): the metallic-roughness model (type 7) follows evaluate_ / sample_pbr_metallic_roughness
+     * (:4598-4948): specular, diffuse and transmission lobes picked by weight (KHR_materials_transmission factor in
+     * pbrExtras.z, thickness tint :3295-3306), visible-normal sampling with the G1 pdf, energy compensation on the
+     * specular lobe, rough refraction with the Walter et al. Jacobian, delta mirror / delta refraction at roughness
+     * <= 1e-3 (which then also counts as a delta surface, :4570-4586); factors only - textures are not covered. */
     uint32_t metalSemantics;
     uint32_t sssMode;   /* RenderSettings::SssMode: 0 off, 1 separable, 2 random walk; read only with PTR_METAL_SSS */
     uint32_t sssMaxSteps;   /* RenderSettings::sssMaxSteps (32): closest-hit queries per random walk, at least 1 */
 } PtrSettings;
 
-enum { PTR_METAL_MEDIA = 1u, PTR_METAL_THIN = 2u, PTR_METAL_FACE_NORMAL = 4u, PTR_METAL_SPECULAR = 8u, PTR_METAL_SSS = 16u };
+enum { PTR_METAL_MEDIA = 1u, PTR_METAL_THIN = 2u, PTR_METAL_FACE_NORMAL = 4u, PTR_METAL_SPECULAR = 8u, PTR_METAL_SSS = 16u, PTR_METAL_PBR = 32u };
 
 typedef struct PtrRenderStats {
     double totalSeconds;                /* integrate phase only (reference: out.totalSeconds) */

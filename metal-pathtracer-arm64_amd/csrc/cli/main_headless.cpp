@@ -217,7 +217,7 @@ bool parseOptions(int argc, const char** argv, CliOptions& o, std::string& error
         } else if (arg == "--semantics") {
             if (!need("--semantics")) return false;
             if (value == "metal") {
-                o.metalSemantics = 31u;   // PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL | PTR_METAL_SPECULAR | PTR_METAL_SSS
+                o.metalSemantics = 63u;   // PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL | PTR_METAL_SPECULAR | PTR_METAL_SSS | PTR_METAL_PBR
             } else if (value == "embree") {
                 o.metalSemantics = 0u;
             } else {

@@ -149,6 +149,7 @@ void compactMaterial(const PtrMaterial& m, std::vector<float>& out) {
     for (uint32_t r = 0; r < kMaterialVec4; ++r) {
         float v[4] = {rows[r][0], rows[r][1], rows[r][2], rows[r][3]};
         if (r == kMatCoatTint) v[3] = m.pbrParams[0];   // PBR metallic rides in the free w lane
+        if (r == kMatDielectricSigmaA) v[3] = m.pbrExtras[2];   // PBR transmission factor (KHR_materials_transmission), Metal PBR model only
         out.insert(out.end(), v, v + 4);
     }
 }
@@ -357,7 +358,7 @@ void fillRenderParams(const PtrSettings& s, uint32_t spp, RenderParams& rp) {
     rp.minSpecularPdf = std::max(s.minSpecularPdf, 1.0e-8f);
     rp.clampEnabled = s.fireflyClampEnabled ? 1.0f : 0.0f;
     rp.emissionScale = (s.emissionScale > 0.0f && std::isfinite(s.emissionScale)) ? s.emissionScale : 1.0f;
-    rp.mediaMode = s.metalSemantics & (PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL | PTR_METAL_SPECULAR | PTR_METAL_SSS);
+    rp.mediaMode = s.metalSemantics & (PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL | PTR_METAL_SPECULAR | PTR_METAL_SSS | PTR_METAL_PBR);
     rp.sssMode = s.sssMode;
     rp.sssMaxSteps = std::max(s.sssMaxSteps, 1u);
 }

@@ -18,6 +18,7 @@ struct ClampCfg {
     bool metalSpecular;     // PTR_METAL_SPECULAR: VNDF sampling, G1 pdf and energy compensation for rough metals
     bool metalSss;          // PTR_METAL_SSS: type 5 evaluates to zero (no NEE); separable diffusion sampling when sssMode == 1
     uint32_t sssMode;
+    bool metalPbr;          // PTR_METAL_PBR: three-lobe metallic-roughness model of the Metal integrator (compiled with SSS = true)
 };
 
 __device__ __forceinline__ uint32_t rngHash(uint32_t x) {  // lowbias32
@@ -541,10 +542,128 @@ struct BsdfEvalResult {
     bool isDelta;
 };
 
+// ---- metallic-roughness model of the Metal integrator (PTR_METAL_PBR): evaluate_ / sample_pbr_metallic_roughness,
+// shaders/pathtrace.metal:4598-4948.  Factors only (no textures); restated line by line in the oracle as well.
+struct PbrMetal {
+    f3 f0, diffuseColor;
+    float roughness, transmission, reflectScale, pSpec, pDiff, pTrans;
+    bool valid;
+};
+
+__device__ __forceinline__ PbrMetal loadPbrMetal(const Mat& m) {   // :4656-4678 / 4789-4811
+    PbrMetal p;
+    const f3 base = m.baseColor();
+    const float metallic = clampf(m.v(kMatCoatTint).w, 0.0f, 1.0f);
+    p.roughness = m.roughness01();
+    const f3 d0 = mk3(dielectricF0Clamped(m.ior()));
+    p.f0 = d0 + (base - d0) * metallic;   // mix(dielectricF0, baseColor, metallic)
+    p.diffuseColor = base * (1.0f - metallic);
+    p.transmission = clampf(m.v(kMatDielectricSigmaA).w, 0.0f, 1.0f) * (1.0f - metallic);   // pbrExtras.z rides in this lane
+    p.reflectScale = 1.0f - p.transmission;
+    const float specWeightBase = clampf(smax(p.f0.x, smax(p.f0.y, p.f0.z)), 0.05f, 0.95f);
+    const float wSpec = specWeightBase * p.reflectScale, wDiff = (1.0f - specWeightBase) * p.reflectScale, wTrans = p.transmission;
+    const float sum = wSpec + wDiff + wTrans;
+    p.valid = sum > 0.0f;
+    p.pSpec = p.valid ? wSpec / sum : 0.0f;
+    p.pDiff = p.valid ? wDiff / sum : 0.0f;
+    p.pTrans = p.valid ? wTrans / sum : 0.0f;
+    return p;
+}
+
+__device__ __forceinline__ f3 transmissionTint(const Mat& m, float cosTheta) {   // :3295-3306
+    const float thickness = smax(m.v(kMatTypeEta).w, 0.0f);
+    if (thickness <= 0.0f) return mk3(1.0f);
+    const f3 sigmaA = m.sigmaA();
+    if (sigmaA.x <= 0.0f && sigmaA.y <= 0.0f && sigmaA.z <= 0.0f) return mk3(1.0f);
+    const float distance = thickness / smax(fabsf(cosTheta), 1.0e-3f);
+    return vclamp(vexp(-(sigmaA * distance)), 0.0f, 1.0f);
+}
+
+__device__ __forceinline__ float ggxVndfPdf(float alpha, f3 n, f3 wo, f3 wh) {   // :3741-3754
+    const float cosO = dot(n, wo), cosH = dot(n, wh);
+    if (cosO <= 0.0f || cosH <= 0.0f) return 0.0f;
+    return ggxD(alpha, cosH) * ggxG1(alpha, cosO) * cosH / smax(dot(wo, wh), 1.0e-6f);
+}
+
+// the rough transmission term shared by evaluation and sampling (:4729-4757 / 4906-4930); false = rejected
+__device__ bool roughTransmission(const Mat& m, const PbrMetal& p, f3 n, f3 wo, f3 wi, f3 wh, float eta, float etaI, float etaT, f3& ft,
+                                  float& pdfTrans) {
+    const float absCosO = fabsf(dot(n, wo)), absCosI = fabsf(dot(n, wi));
+    const float cosOWh = dot(wo, wh), cosIWh = dot(wi, wh);
+    if (cosOWh * cosIWh > 0.0f) return false;
+    const float alpha = smax(p.roughness * p.roughness, 1.0e-4f);
+    const float D = ggxD(alpha, smax(dot(n, wh), 0.0f));
+    const float G = ggxG1(alpha, absCosO) * ggxG1(alpha, absCosI);
+    float cosT = 0.0f;
+    const float F = fresnelDielectric(cosOWh, etaI, etaT, cosT);
+    const float denom = cosOWh + eta * cosIWh;
+    const float denomSq = denom * denom;
+    if (fabsf(denomSq) <= 1.0e-8f) return false;
+    float factor = (eta * eta) * fabsf(cosIWh) * fabsf(cosOWh);
+    factor /= smax(absCosO * absCosI * denomSq, 1.0e-6f);
+    ft = mk3((1.0f - F) * D * G * factor) * transmissionTint(m, absCosI);
+    ft = ft * p.transmission;
+    const float pdfWh = ggxVndfPdf(alpha, n, wo, wh);
+    const float dwhDwi = fabsf((eta * eta * cosIWh) / smax(denomSq, 1.0e-8f));
+    pdfTrans = pdfWh * dwhDwi;
+    return true;
+}
+
+__device__ BsdfEvalResult evalPbrMetal(const Mat& m, f3 n, f3 wo, f3 wi, const ClampCfg& cc) {   // :4632-4762
+    BsdfEvalResult r{mk3(0.0f), 0.0f, false};
+    const float cosO = dot(n, wo), cosI = dot(n, wi);
+    const float absCosO = fabsf(cosO), absCosI = fabsf(cosI);
+    if (absCosO <= 0.0f || absCosI <= 0.0f) return r;
+    const PbrMetal p = loadPbrMetal(m);
+    if (!p.valid) return r;
+    if (cosO * cosI > 0.0f) {
+        if (cosO <= 0.0f || cosI <= 0.0f) return r;
+        const float alpha = smax(p.roughness * p.roughness, 1.0e-4f);
+        const f3 wh = normalize(wo + wi);
+        if (dot(wh, n) <= 0.0f || dot(wo, wh) <= 0.0f || dot(wi, wh) <= 0.0f) return r;
+        const float D = ggxD(alpha, dot(n, wh));
+        const float G = ggxG1(alpha, cosO) * ggxG1(alpha, cosI);
+        f3 spec = schlick(p.f0, dot(wi, wh)) * (D * G / smax(4.0f * cosO * cosI, 1.0e-6f));
+        spec = spec * specularEnergyCompensation(p.f0, p.roughness, absCosO);
+        spec = clampSpecTail(spec, p.roughness, p.f0, cc);
+        spec = spec * p.reflectScale;
+        const float pdfSpec = ggxPdfVisible(alpha, n, wo, wi);
+        const f3 diffuse = (p.diffuseColor / kPi) * p.reflectScale;
+        const float pdf = p.pSpec * pdfSpec + p.pDiff * lambertPdf(n, wi);
+        if (pdf > 0.0f) {
+            r.value = vmax0(spec + diffuse);
+            r.pdf = clampSpecPdf(pdf, cc);
+        }
+        return r;
+    }
+    if (p.transmission <= 0.0f) return r;
+    float etaI = 1.0f, etaT = smax(m.ior(), 1.0f);
+    if (cosO < 0.0f) {
+        const float tmp = etaI;
+        etaI = etaT;
+        etaT = tmp;
+    }
+    const float eta = etaI / etaT;
+    f3 wh = wo + wi * eta;
+    if (!finite3(wh) || dot(wh, wh) <= 0.0f) return r;
+    wh = normalize(wh);
+    if (dot(wh, n) <= 0.0f) wh = -wh;
+    f3 ft;
+    float pdfTrans = 0.0f;
+    if (!roughTransmission(m, p, n, wo, wi, wh, eta, etaI, etaT, ft, pdfTrans)) return r;
+    const float pdf = p.pTrans * pdfTrans;
+    if (pdf > 0.0f) {
+        r.value = vmax0(ft);
+        r.pdf = clampSpecPdf(pdf, cc);
+    }
+    return r;
+}
+
 // SSS: compiled with the Metal subsurface semantics (PTR_METAL_SSS).  A template parameter, not a run-time flag: the extra
 // branch and the exit point it carries cost the default k_shade 3 % when they were merely predicated off.
 template <bool SSS = false>
 __device__ BsdfEvalResult evalBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 wi, const ClampCfg& cc) {
+    if (SSS && cc.metalPbr && m.type() == 7u) return evalPbrMetal(m, n, wo, wi, cc);   // before the same-side test below
     BsdfEvalResult r{mk3(0.0f), 0.0f, false};
     const float cosO = smax(dot(n, wo), 0.0f), cosI = smax(dot(n, wi), 0.0f);
     if (cosI <= 0.0f || cosO <= 0.0f) return r;
@@ -893,12 +1012,88 @@ __device__ int sssWalkStep(const Mat& m, uint32_t maxSteps, SssWalk& walk, bool 
     return kWalkSample;
 }
 
+__device__ BsdfSampleResult samplePbrMetal(const Mat& m, f3 n, f3 wo, f3 incident, uint32_t& rng, const ClampCfg& cc) {   // :4764-4948
+    BsdfSampleResult r{mk3(0.0f), mk3(0.0f), 0.0f, false, 0, false, mk3(0.0f)};
+    const PbrMetal p = loadPbrMetal(m);
+    if (!p.valid) return r;
+    const float choose = rngNext(rng);
+    f3 wi = mk3(0.0f), f = mk3(0.0f);
+    float pdfSpec = 0.0f, pdfDiffuse = 0.0f, pdfTrans = 0.0f;
+    bool isDelta = false;
+    if (choose < p.pSpec) {
+        if (p.roughness <= 1.0e-3f) {
+            wi = reflectDir(incident, n);
+            if (dot(n, wi) <= 0.0f) return r;
+            pdfSpec = 1.0f;
+            f = schlick(p.f0, smax(dot(n, wo), 0.0f)) * p.reflectScale;
+            isDelta = true;
+        } else {
+            const f3 wh = sampleGgxVndf(rng, p.roughness, n, wo);
+            wi = reflectDir(-wo, wh);
+            const float cosI = dot(n, wi);
+            if (cosI <= 0.0f) return r;
+            const float alpha = smax(p.roughness * p.roughness, 1.0e-4f);
+            const float cosO = smax(dot(n, wo), 0.0f);
+            const float D = ggxD(alpha, dot(n, wh));
+            const float G = ggxG1(alpha, cosO) * ggxG1(alpha, cosI);
+            f = schlick(p.f0, dot(wi, wh)) * (D * G / smax(4.0f * cosO * cosI, 1.0e-6f));
+            f = f * specularEnergyCompensation(p.f0, p.roughness, cosO);
+            f = clampSpecTail(f, p.roughness, p.f0, cc);
+            f = f * p.reflectScale;
+            pdfSpec = ggxPdfVisible(alpha, n, wo, wi);
+        }
+    } else if (choose < p.pSpec + p.pDiff) {
+        float unused = 0.0f;
+        wi = cosineHemisphere(rng, n, unused);
+        if (dot(n, wi) <= 0.0f) return r;
+        f = (p.diffuseColor / kPi) * p.reflectScale;
+        pdfDiffuse = lambertPdf(n, wi);
+    } else {
+        const float cosO = dot(n, wo), absCosO = fabsf(cosO);
+        float etaI = 1.0f, etaT = smax(m.ior(), 1.0f);
+        if (cosO < 0.0f) {
+            const float tmp = etaI;
+            etaI = etaT;
+            etaT = tmp;
+        }
+        const float eta = etaI / etaT;
+        if (p.roughness <= 1.0e-3f) {
+            wi = refractMetal(-wo, n, eta);
+            if (dot(wi, wi) <= 0.0f) return r;
+            wi = normalize(wi);
+            float cosT = 0.0f;
+            const float Fr = fresnelDielectric(cosO, etaI, etaT, cosT);
+            const float directionScale = ((etaT * etaT) / (etaI * etaI)) * (fabsf(cosT) / smax(absCosO, 1.0e-6f));
+            f = (mk3(smax(1.0f - Fr, 0.0f) * directionScale) * transmissionTint(m, fabsf(dot(n, wi)))) * p.transmission;
+            pdfTrans = 1.0f;
+            isDelta = true;
+        } else {
+            const f3 wh = sampleGgxVndf(rng, p.roughness, n, wo);
+            wi = refractMetal(-wo, wh, eta);
+            if (dot(wi, wi) <= 0.0f) return r;
+            wi = normalize(wi);
+            if (dot(wi, n) * cosO >= 0.0f) return r;
+            if (!roughTransmission(m, p, n, wo, wi, wh, eta, etaI, etaT, f, pdfTrans)) return r;
+        }
+    }
+    const float absCosI = fabsf(dot(n, wi));
+    if (absCosI <= 0.0f) return r;
+    const float pdf = p.pSpec * pdfSpec + p.pDiff * pdfDiffuse + p.pTrans * pdfTrans;
+    if (pdf <= 0.0f) return r;
+    r.dir = wi;
+    r.pdf = pdf;
+    r.isDelta = isDelta;
+    r.weight = vmax0(f * absCosI / pdf);
+    return r;
+}
+
 template <bool SSS = false>
 __device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 incident, bool frontFace,
                                        uint32_t& rng, const ClampCfg& cc) {
     BsdfSampleResult r{mk3(0.0f), mk3(0.0f), 0.0f, false, 0, false, mk3(0.0f)};
     const uint32_t type = m.type();
     if (SSS && type == 5u && cc.metalSss && sampleSeparableSss(m, position, n, wo, rng, cc, r)) return r;
+    if (SSS && type == 7u && cc.metalPbr) return samplePbrMetal(m, n, wo, incident, rng, cc);
     switch (type) {
         case 7u: {
             const Pbr p = loadPbr(m);

@@ -49,6 +49,7 @@ __device__ __forceinline__ ClampCfg clampCfg(const RenderParams& rp) {
     c.metalSpecular = (rp.mediaMode & PTR_METAL_SPECULAR) != 0u;
     c.metalSss = (rp.mediaMode & PTR_METAL_SSS) != 0u;
     c.sssMode = rp.sssMode;
+    c.metalPbr = (rp.mediaMode & PTR_METAL_PBR) != 0u;
     return c;
 }
 
@@ -524,7 +525,8 @@ __device__ __forceinline__ uint4 mediumWithEntry(uint4 ms, uint32_t i, uint32_t 
 #ifndef PTR_SHADE_WAVES
 #define PTR_SHADE_WAVES 5
 #endif
-#define PTR_SHADE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PTR_SHADE_WAVES, PTR_SHADE_WAVES)))
+// (the instantiation with the Metal-only subsurface / PBR models needs more registers: 4 waves)
+#define PTR_SHADE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SSS ? 4 : PTR_SHADE_WAVES, SSS ? 4 : PTR_SHADE_WAVES)))
 // SSS: the instantiation with the Metal subsurface semantics (launched when PTR_METAL_SSS is set)
 template <bool COUNT, bool SSS>
 __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(RenderParams rp, SceneView sc, PathPool pool, ShadeResets resets) {
@@ -733,7 +735,8 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
                     }
                     endPath = true;
                 } else {
-                    const bool surfaceDelta = materialIsDelta(mat);
+                    bool surfaceDelta = materialIsDelta(mat);
+                    if (SSS && cc.metalPbr && type == 7u) surfaceDelta = mat.roughness01() <= 1.0e-3f;   // pathtrace.metal:4578-4581
 
                     // ---- rectangle-light NEE (3 random numbers, drawn even if the sample is rejected) ----
                     if (!surfaceDelta && sc.rectLightCount > 0u) {
@@ -1447,7 +1450,7 @@ void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig&
 void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, bool count,
                  hipStream_t stream) {
     const uint32_t grid = ceilDiv(pool.slots, kShadeBlock);
-    const bool sss = (rp.mediaMode & PTR_METAL_SSS) != 0u;
+    const bool sss = (rp.mediaMode & (PTR_METAL_SSS | PTR_METAL_PBR)) != 0u;   // the instantiation that carries those Metal-only models
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, resets); };
     if (count) {
         if (sss) launch(k_shade<true, true>); else launch(k_shade<true, false>);

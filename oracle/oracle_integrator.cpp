@@ -726,6 +726,7 @@ ClampParams makeClampParams(const PtrSettings& s) {  // E:381-391
     p.metalSss = (s.metalSemantics & PTR_METAL_SSS) != 0u;
     p.sssMode = s.sssMode;
     p.sssMaxSteps = std::max(s.sssMaxSteps, 1u);
+    p.metalPbr = (s.metalSemantics & PTR_METAL_PBR) != 0u;
     return p;
 }
 
@@ -774,8 +775,13 @@ float environmentPdf(const EnvMap& env, float rotation, V3 direction) {  // E:88
     return (std::isfinite(value) && value > 0.0f) ? value : 0.0f;
 }
 
+namespace {
+BsdfEval evaluatePbrMetal(const PtrMaterial& m, V3 normal, V3 wo, V3 wi, const ClampParams& cp);
+}
+
 BsdfEval evaluateBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 wi, const ClampParams& cp) {  // E:1315-1491
     BsdfEval r;
+    if (matType(m) == PTR_MAT_PBR && cp.metalPbr) return evaluatePbrMetal(m, normal, wo, wi, cp);   // before the same-side test below
     const float cosO = std::max(dot(normal, wo), 0.0f);
     const float cosI = std::max(dot(normal, wi), 0.0f);
     if (cosI <= 0.0f || cosO <= 0.0f) return r;
@@ -1154,10 +1160,201 @@ WalkOutcome sssWalkStep(const PtrMaterial& m, uint32_t maxSteps, SssWalk& walk, 
 
 }  // namespace
 
+
+// ---- metallic-roughness model of the Metal integrator (PTR_METAL_PBR), evaluate_/sample_pbr_metallic_roughness M:4598-4948 ----
+namespace {
+
+struct PbrMetal {
+    V3 f0, diffuseColor;
+    float roughness = 0.0f, transmission = 0.0f, reflectScale = 1.0f, pSpec = 0.0f, pDiff = 0.0f, pTrans = 0.0f;
+    bool valid = false;
+};
+
+V3 mix3(V3 x, V3 y, float a) { return x + (y - x) * a; }
+
+PbrMetal loadPbrMetal(const PtrMaterial& m) {  // M:4656-4678 / 4789-4811
+    PbrMetal p;
+    const V3 base = baseColor(m);
+    const float metallic = clampf(m.pbrParams[0], 0.0f, 1.0f);
+    p.roughness = clampf(m.baseColorRoughness[3], 0.0f, 1.0f);
+    p.f0 = mix3(splat(dielectricF0FromIor(m.typeEta[1])), base, metallic);
+    p.diffuseColor = base * (1.0f - metallic);
+    p.transmission = clampf(m.pbrExtras[2], 0.0f, 1.0f) * (1.0f - metallic);
+    p.reflectScale = 1.0f - p.transmission;
+    const float specWeightBase = pbrSpecularWeight(p.f0);
+    const float wSpec = specWeightBase * p.reflectScale, wDiff = (1.0f - specWeightBase) * p.reflectScale, wTrans = p.transmission;
+    const float sum = wSpec + wDiff + wTrans;
+    if (sum <= 0.0f) return p;
+    p.pSpec = wSpec / sum;
+    p.pDiff = wDiff / sum;
+    p.pTrans = wTrans / sum;
+    p.valid = true;
+    return p;
+}
+
+V3 transmissionTint(const PtrMaterial& m, float cosTheta) {  // M:3295-3306
+    const float thickness = std::max(m.typeEta[3], 0.0f);
+    if (thickness <= 0.0f) return splat(1.0f);
+    const V3 sigmaA = vmax(V3(m.dielectricSigmaA), V3());
+    if (sigmaA.x <= 0.0f && sigmaA.y <= 0.0f && sigmaA.z <= 0.0f) return splat(1.0f);
+    const float distance = thickness / std::max(std::fabs(cosTheta), 1.0e-3f);
+    return vclamp01(vexp3(-(sigmaA * distance)));
+}
+
+float ggxVndfPdf(float alpha, V3 normal, V3 wo, V3 wh) {  // M:3741-3754
+    const float cosO = dot(normal, wo), cosH = dot(normal, wh);
+    if (cosO <= 0.0f || cosH <= 0.0f) return 0.0f;
+    return ggxDistribution(alpha, cosH) * ggxG1(alpha, cosO) * cosH / std::max(dot(wo, wh), 1.0e-6f);
+}
+
+// the rough transmission term shared by evaluation and sampling (M:4729-4757 / 4906-4930); false = rejected
+bool roughTransmission(const PtrMaterial& m, const PbrMetal& p, V3 normal, V3 wo, V3 wi, V3 wh, float eta, float etaI, float etaT, V3& ft,
+                       float& pdfTrans) {
+    const float absCosO = std::fabs(dot(normal, wo)), absCosI = std::fabs(dot(normal, wi));
+    const float cosOWh = dot(wo, wh), cosIWh = dot(wi, wh);
+    if (cosOWh * cosIWh > 0.0f) return false;
+    const float alpha = std::max(p.roughness * p.roughness, 1.0e-4f);
+    const float D = ggxDistribution(alpha, std::max(dot(normal, wh), 0.0f));
+    const float G = ggxG1(alpha, absCosO) * ggxG1(alpha, absCosI);
+    float cosT = 0.0f;
+    const float F = fresnelDielectricExact(cosOWh, etaI, etaT, cosT);
+    const float denom = cosOWh + eta * cosIWh;
+    const float denomSq = denom * denom;
+    if (std::fabs(denomSq) <= 1.0e-8f) return false;
+    float factor = (eta * eta) * std::fabs(cosIWh) * std::fabs(cosOWh);
+    factor /= std::max(absCosO * absCosI * denomSq, 1.0e-6f);
+    ft = splat((1.0f - F) * D * G * factor) * transmissionTint(m, absCosI);
+    ft = ft * p.transmission;
+    const float pdfWh = ggxVndfPdf(alpha, normal, wo, wh);
+    const float dwhDwi = std::fabs((eta * eta * cosIWh) / std::max(denomSq, 1.0e-8f));
+    pdfTrans = pdfWh * dwhDwi;
+    return true;
+}
+
+BsdfEval evaluatePbrMetal(const PtrMaterial& m, V3 normal, V3 wo, V3 wi, const ClampParams& cp) {  // M:4632-4762
+    BsdfEval r;
+    const float cosO = dot(normal, wo), cosI = dot(normal, wi);
+    const float absCosO = std::fabs(cosO), absCosI = std::fabs(cosI);
+    if (absCosO <= 0.0f || absCosI <= 0.0f) return r;
+    const PbrMetal p = loadPbrMetal(m);
+    if (!p.valid) return r;
+    if (cosO * cosI > 0.0f) {
+        if (cosO <= 0.0f || cosI <= 0.0f) return r;
+        const float alpha = std::max(p.roughness * p.roughness, 1.0e-4f);
+        const V3 wh = normalize(wo + wi);
+        if (dot(wh, normal) <= 0.0f || dot(wo, wh) <= 0.0f || dot(wi, wh) <= 0.0f) return r;
+        const float D = ggxDistribution(alpha, dot(normal, wh));
+        const float G = ggxG1(alpha, cosO) * ggxG1(alpha, cosI);
+        V3 spec = schlickFresnel(p.f0, dot(wi, wh)) * (D * G / std::max(4.0f * cosO * cosI, 1.0e-6f));
+        spec = spec * specularEnergyCompensation(p.f0, p.roughness, absCosO);
+        spec = clampSpecularTail(spec, p.roughness, p.f0, cp);
+        spec = spec * p.reflectScale;
+        const float pdfSpec = ggxPdfVisible(alpha, normal, wo, wi);
+        const V3 diffuse = (p.diffuseColor / kPi) * p.reflectScale;
+        const float pdf = p.pSpec * pdfSpec + p.pDiff * lambertPdf(normal, wi);
+        if (pdf > 0.0f) {
+            r.value = vmax(spec + diffuse, V3());
+            r.pdf = clampSpecularPdf(pdf, cp);
+        }
+        return r;
+    }
+    if (p.transmission <= 0.0f) return r;
+    float etaI = 1.0f, etaT = std::max(m.typeEta[1], 1.0f);
+    if (cosO < 0.0f) std::swap(etaI, etaT);
+    const float eta = etaI / etaT;
+    V3 wh = wo + wi * eta;
+    if (!finite3(wh) || dot(wh, wh) <= 0.0f) return r;
+    wh = normalize(wh);
+    if (dot(wh, normal) <= 0.0f) wh = -wh;
+    V3 ft;
+    float pdfTrans = 0.0f;
+    if (!roughTransmission(m, p, normal, wo, wi, wh, eta, etaI, etaT, ft, pdfTrans)) return r;
+    const float pdf = p.pTrans * pdfTrans;
+    if (pdf > 0.0f) {
+        r.value = vmax(ft, V3());
+        r.pdf = clampSpecularPdf(pdf, cp);
+    }
+    return r;
+}
+
+BsdfSample samplePbrMetal(const PtrMaterial& m, V3 normal, V3 wo, V3 incidentDir, Rng& rng, const ClampParams& cp) {  // M:4764-4948
+    BsdfSample r;
+    const PbrMetal p = loadPbrMetal(m);
+    if (!p.valid) return r;
+    const float choose = rng.nextFloat();
+    V3 wi, f;
+    float pdfSpec = 0.0f, pdfDiffuse = 0.0f, pdfTrans = 0.0f;
+    bool isDelta = false;
+    if (choose < p.pSpec) {
+        if (p.roughness <= 1.0e-3f) {
+            wi = reflect(incidentDir, normal);
+            if (dot(normal, wi) <= 0.0f) return r;
+            pdfSpec = 1.0f;
+            f = schlickFresnel(p.f0, std::max(dot(normal, wo), 0.0f)) * p.reflectScale;
+            isDelta = true;
+        } else {
+            const V3 wh = sampleGgxVndf(rng, p.roughness, normal, wo);
+            wi = reflect(-wo, wh);
+            const float cosI = dot(normal, wi);
+            if (cosI <= 0.0f) return r;
+            const float alpha = std::max(p.roughness * p.roughness, 1.0e-4f);
+            const float cosO = std::max(dot(normal, wo), 0.0f);
+            const float D = ggxDistribution(alpha, dot(normal, wh));
+            const float G = ggxG1(alpha, cosO) * ggxG1(alpha, cosI);
+            f = schlickFresnel(p.f0, dot(wi, wh)) * (D * G / std::max(4.0f * cosO * cosI, 1.0e-6f));
+            f = f * specularEnergyCompensation(p.f0, p.roughness, cosO);
+            f = clampSpecularTail(f, p.roughness, p.f0, cp);
+            f = f * p.reflectScale;
+            pdfSpec = ggxPdfVisible(alpha, normal, wo, wi);
+        }
+    } else if (choose < p.pSpec + p.pDiff) {
+        float unused = 0.0f;
+        wi = sampleCosineHemisphere(rng, normal, unused);
+        if (dot(normal, wi) <= 0.0f) return r;
+        f = (p.diffuseColor / kPi) * p.reflectScale;
+        pdfDiffuse = lambertPdf(normal, wi);
+    } else {
+        const float cosO = dot(normal, wo), absCosO = std::fabs(cosO);
+        float etaI = 1.0f, etaT = std::max(m.typeEta[1], 1.0f);
+        if (cosO < 0.0f) std::swap(etaI, etaT);
+        const float eta = etaI / etaT;
+        if (p.roughness <= 1.0e-3f) {
+            wi = refractMetal(-wo, normal, eta);
+            if (dot(wi, wi) <= 0.0f) return r;
+            wi = normalize(wi);
+            float cosT = 0.0f;
+            const float Fr = fresnelDielectricExact(cosO, etaI, etaT, cosT);
+            const float directionScale = ((etaT * etaT) / (etaI * etaI)) * (std::fabs(cosT) / std::max(absCosO, 1.0e-6f));
+            f = splat(std::max(1.0f - Fr, 0.0f) * directionScale) * transmissionTint(m, std::fabs(dot(normal, wi))) * p.transmission;
+            pdfTrans = 1.0f;
+            isDelta = true;
+        } else {
+            const V3 wh = sampleGgxVndf(rng, p.roughness, normal, wo);
+            wi = refractMetal(-wo, wh, eta);
+            if (dot(wi, wi) <= 0.0f) return r;
+            wi = normalize(wi);
+            if (dot(wi, normal) * cosO >= 0.0f) return r;
+            if (!roughTransmission(m, p, normal, wo, wi, wh, eta, etaI, etaT, f, pdfTrans)) return r;
+        }
+    }
+    const float absCosI = std::fabs(dot(normal, wi));
+    if (absCosI <= 0.0f) return r;
+    const float pdf = p.pSpec * pdfSpec + p.pDiff * pdfDiffuse + p.pTrans * pdfTrans;
+    if (pdf <= 0.0f) return r;
+    r.direction = wi;
+    r.pdf = pdf;
+    r.isDelta = isDelta;
+    r.weight = vmax(f * absCosI / pdf, V3());
+    return r;
+}
+
+}  // namespace
+
 BsdfSample sampleBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 incidentDir, bool frontFace, Rng& rng,
                       const ClampParams& cp) {  // E:1493-1918
     BsdfSample r;
     const uint32_t type = matType(m);
+    if (type == PTR_MAT_PBR && cp.metalPbr) return samplePbrMetal(m, normal, wo, incidentDir, rng, cp);
     if (type == PTR_MAT_SUBSURFACE && cp.metalSss && sampleSeparableSss(m, position, normal, wo, rng, cp, r)) return r;
 
     if (type == PTR_MAT_LAMBERTIAN || type == PTR_MAT_SUBSURFACE) {
@@ -1735,7 +1932,10 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
                     break;
                 }
 
-                const bool surfaceIsDelta = materialIsDelta(material);
+                bool surfaceIsDelta = materialIsDelta(material);
+                if (cp.metalPbr && matType(material) == PTR_MAT_PBR) {   // M:4578-4581
+                    surfaceIsDelta = clampf(material.baseColorRoughness[3], 0.0f, 1.0f) <= 1.0e-3f;
+                }
 
                 if (!surfaceIsDelta && rectLightCount > 0) {  // rect-light NEE, E:2710-2772
                     RectLightSample ls;

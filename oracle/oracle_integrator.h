@@ -78,6 +78,7 @@ struct ClampParams {  // FireflyClampParams, :136-144
     bool metalSss = false;          // PTR_METAL_SSS: type 5 evaluates to zero; separable diffusion sampling when sssMode == 1,
     uint32_t sssMode = 0;           // random walk when sssMode == 2 on materials that ask for it
     uint32_t sssMaxSteps = 32;
+    bool metalPbr = false;          // PTR_METAL_PBR: three-lobe metallic-roughness model of the Metal integrator
 };
 
 struct BsdfEval {

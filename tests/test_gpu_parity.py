@@ -406,6 +406,49 @@ def test_metal_subsurface_semantics(tmp_path):
     assert np.isfinite(wdev.render_image(sw0, 1)[0]).all()
 
 
+def test_metal_pbr_semantics():
+    # PTR_METAL_PBR: the three-lobe metallic-roughness model of the Metal integrator (shaders/pathtrace.metal:4598-4948;
+    # restated in the oracle too) on the config-3 stand-in, with one of its primitives made transmissive and another a
+    # perfect mirror-and-refractor (roughness 0: delta lobes, which then also make the surface delta for NEE)
+    host = pt.HostScene.load(os.path.join(SCENES, "helmet_env.scene"), SCENES)
+    d = host.desc
+    glassy, sharp = d.materials[1], d.materials[2]
+    glassy.pbrExtras[2], glassy.pbrParams[0], glassy.baseColorRoughness[3] = 0.7, 0.1, 0.35
+    glassy.typeEta[1], glassy.typeEta[3] = 1.45, 0.5
+    glassy.dielectricSigmaA[0], glassy.dielectricSigmaA[1], glassy.dielectricSigmaA[2] = 0.2, 0.5, 1.0
+    sharp.pbrExtras[2], sharp.pbrParams[0], sharp.baseColorRoughness[3] = 0.5, 0.0, 0.0
+    dev, osc = pt.DeviceScene(d, 0, keepalive=host), ol.OracleScene(host)
+    _image_parity(host, dev, osc, 160, 90, 8, 1, 32, 0.85, metalSemantics=32)
+    s0 = host.settings_for(width=160, height=90, max_depth=8, seed=1337)
+    s32 = s0.copy()
+    s32.metalSemantics = 32
+    assert _rmse(dev.render_image(s0, 32)[0], dev.render_image(s32, 32)[0]) > 0.005
+    rng = np.random.default_rng(4)
+    n = 4000
+    wo = rng.normal(size=(n, 3))
+    wo[:, 2] = np.abs(wo[:, 2]) + 0.1
+    wo = (wo / np.linalg.norm(wo, axis=1, keepdims=True)).astype(np.float32)
+    inp = np.concatenate([np.zeros((n, 3), np.float32), np.tile(np.array([0, 0, 1], np.float32), (n, 1)), wo], axis=1)
+    states = rng.integers(1, 2**32 - 1, size=n, dtype=np.uint64).astype(np.uint32)
+    front = np.ones(n, dtype=np.uint32)
+    for m in (glassy, sharp):
+        g, gs = pt.debug_sample_bsdf(m, s32, inp, front, states)
+        o, os_ = ol.sample_bsdf(m, s32, inp, front, states)
+        assert np.array_equal(gs, os_)
+        agree = (g[:, 6] > 0) == (o[:, 6] > 0)
+        assert agree.mean() > 0.995
+        both = agree & (o[:, 6] > 0)
+        assert (o[both, 2] < 0).mean() > 0.2                                        # the transmission lobe is exercised
+        assert np.allclose(g[both, :3], o[both, :3], atol=3e-4)
+        close = np.isclose(g[both, 3:7], o[both, 3:7], rtol=5e-3, atol=1e-4).all(axis=1)
+        assert close.mean() > 0.99, close.mean()                                    # rough refraction: ill-conditioned Jacobian in f32
+        wi = o[both, :3]
+        ge = pt.debug_eval_bsdf(m, s32, np.concatenate([inp[both], wi], axis=1))
+        oe = ol.eval_bsdf(m, s32, np.concatenate([inp[both], wi], axis=1))
+        ok = np.isclose(ge, oe, rtol=5e-3, atol=1e-5).all(axis=1)
+        assert ok.mean() > 0.99, ok.mean()
+
+
 def test_first_hit_aovs(materials_scene):
     # denoiser inputs: albedo = base colour of the first hit, normal = shading normal * 0.5 + 0.5, distance in normal.w
     host, dev, osc = materials_scene
