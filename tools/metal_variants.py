@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Metal-semantics variants of BASELINE configs 4 and 5 on one MI355X: throughput at full size and parity against the
+"""Metal-semantics variants of BASELINE configs 3, 4 and 5 on one MI355X: throughput at full size and parity against the
 oracle's restatement of the same Metal lines on a strip of the frame (same protocol as tools/full_configs.py).
 
   python tools/metal_variants.py [--out gpurun_out/metal_variants.json]
@@ -18,8 +18,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 VARIANTS = {
-    "4_absorbing_glass": dict(scene="knot_glass_absorbing.scene", assets=["torus_knot_871200.ply"], semantics=31, gpu_spp=256, parity_spp=64, strip=128),
-    "5_separable_sss": dict(scene="lucy_standin_sss.scene", assets=["lucy_standin_28005128.ply", "blob_1002528.ply"], semantics=31, gpu_spp=32,
+    "3_metal_pbr": dict(scene="helmet_env.scene", assets=[], semantics=63, gpu_spp=256, parity_spp=64, strip=128),
+    "4_absorbing_glass": dict(scene="knot_glass_absorbing.scene", assets=["torus_knot_871200.ply"], semantics=63, gpu_spp=256, parity_spp=64, strip=128),
+    "5_separable_sss": dict(scene="lucy_standin_sss.scene", assets=["lucy_standin_28005128.ply", "blob_1002528.ply"], semantics=63, gpu_spp=32,
                             parity_spp=16, strip=64),
 }
 
