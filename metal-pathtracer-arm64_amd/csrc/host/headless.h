@@ -14,36 +14,35 @@ namespace ptr {
 
 enum class HeadlessBackend { Hip = 0 };
 
+// What the caller hands over: where the scene came from and the parsed CPU-side arrays (the HIP backend, like the
+// reference's Embree backend, consumes `resources`; `source` / `isPath` are kept for messages).
 struct HeadlessScene {
+    const SceneResources* resources = nullptr;
     std::string source;
     bool isPath = false;
-    const SceneResources* resources = nullptr;
 };
 
-struct HeadlessCamera {  // passed for interface parity; backends rebuild the camera from settings (quirk Q5)
+// Orbit camera as the CLI resolved it.  Passed for interface parity only: both reference backends rebuild the camera
+// from the settings (quirk Q5), and so does this one.
+struct HeadlessCamera {
     float3 target{0.0f, 0.0f, 0.0f};
-    float distance = 0.0f;
-    float yaw = 0.0f;
-    float pitch = 0.0f;
-    float verticalFov = 0.0f;
-    float defocusAngle = 0.0f;
-    float focusDistance = 0.0f;
+    float distance = 0.0f, yaw = 0.0f, pitch = 0.0f;
+    float verticalFov = 0.0f, defocusAngle = 0.0f, focusDistance = 0.0f;
 };
 
+// Result: linear RGB, width*height*3 floats, row 0 = top, mean over the samples; timing of the integrate phase.
 struct HeadlessRenderOutput {
-    std::vector<float> linearRGB;  // W*H*3, row 0 = top, linear, mean over spp
-    uint32_t width = 0;
-    uint32_t height = 0;
-    uint32_t samples = 0;
-    double totalSeconds = 0.0;
-    double avgMsPerSample = 0.0;
+    uint32_t width = 0, height = 0, samples = 0;
+    double totalSeconds = 0.0, avgMsPerSample = 0.0;
+    std::vector<float> linearRGB;
 };
 
+// The plug-in interface: false + message on failure, no exceptions across it, called once from the main thread.
 class IHeadlessRenderer {
 public:
-    virtual ~IHeadlessRenderer() = default;
     virtual bool render(const HeadlessScene& scene, const HeadlessCamera& camera, const RenderSettings& settings,
                         uint32_t sppTotal, bool verbose, HeadlessRenderOutput& out, std::string& error) = 0;
+    virtual ~IHeadlessRenderer() = default;
 };
 
 // MI355X backend: wraps the C-ABI (ptr_render) behind the reference's interface.
