@@ -71,7 +71,9 @@ void printUsage(const char* exe) {
               << "Backend selection:\n"
               << "  --backend=<hip|metal>          Headless backend (default hip; metal = alias)\n"
               << "  --semantics=<embree|metal>     Integrator semantics: embree = parity with the reference's Embree backend\n"
-              << "                                 (default); metal = plus absorbing dielectric media, thin-walled glass, ray-facing glass normals\n"
+              << "                                 (default); metal = plus the Metal kernel's absorbing media, thin-walled glass, ray-facing\n"
+              << "                                 glass normals, rough-metal VNDF formulas, subsurface scattering (scene: renderer sss=...),\n"
+              << "                                 three-lobe PBR with transmission\n"
               << "  --assets=<dir>                 Directory for relative mesh/env paths\n\n"
               << "Tonemapping overrides (for LDR outputs):\n"
               << "  --tonemap=<1|2|3|4>           1=Linear, 2=ACES, 3=Reinhard, 4=Hable\n"
