@@ -450,7 +450,9 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     const uint64_t itemCount64 = static_cast<uint64_t>(localPixels) * rp.chunkCount;
     if (itemCount64 > 0xFFFF0000ull) throw HipError{"too many work items (reduce spp or resolution)"};
     rp.itemCount = static_cast<uint32_t>(itemCount64);
-    const uint64_t targetSlots = ds.poolSlots;   // enough to keep every CU's wave slots full several times over
+    // enough to keep every CU's wave slots full several times over - but never more than half the work items: a pool as
+    // large as the frame is all ramp-up and drain (config 1, 16.8 M samples: 16 Mi slots 16.2 ms, 8 Mi slots 10.0 ms)
+    const uint64_t targetSlots = std::min<uint64_t>(ds.poolSlots, std::max<uint64_t>(1ull << 20, itemCount64 / 2u));
     uint32_t slots = static_cast<uint32_t>(std::min<uint64_t>(targetSlots, itemCount64));
     if (slots < itemCount64) slots &= ~255u;   // item ranges start right after the pre-assigned items: keep them 64-aligned
     // items [0, slots) are pre-assigned by k_generate; the rest is split into kItemHeads ranges with one head each
