@@ -342,6 +342,9 @@ void fillRenderParams(const PtrSettings& s, uint32_t spp, RenderParams& rp) {
     rp.maxDepth = std::min(s.maxDepth, kFlagFieldMask);
     rp.seedBase = s.seed != 0 ? s.seed : 0x9e3779b9u;
     rp.spp = std::max(1u, spp);
+    rp.sampleBase = 0u;
+    rp.sppTotal = rp.spp;
+    rp.passFlags = 3u;   // one pass: first and last
     rp.enableRussianRoulette = s.enableRussianRoulette;
     rp.enableSpecularNee = s.enableSpecularNee;
     rp.enableMnee = s.enableMnee;
@@ -396,8 +399,10 @@ struct EventTimer {
     }
 };
 
-void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, uint32_t part, uint32_t parts, float* dOut,
-                 hipStream_t stream, int mode, PtrRenderStats* stats) {
+// One pass over `spp` samples per pixel starting at sample `sampleBase` of a frame of `sppTotal`; passFlags bit 0 = first pass of
+// the frame (output and counters start from zero), bit 1 = last pass (the running sum in dOut is divided by sppTotal).
+void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, uint32_t sampleBase, uint32_t sppTotal, uint32_t passFlags,
+                uint32_t part, uint32_t parts, float* dOut, hipStream_t stream, int mode, PtrRenderStats* stats) {
     const bool count = (mode & 1) != 0;         // counting instantiation of the kernels
     const bool soloGroup = (mode & 2) != 0;     // one pool group: kernels run alone, for clean per-kernel timings
     if (settings.width == 0 || settings.height == 0) throw HipError{"render size must be non-zero"};
@@ -406,6 +411,9 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
 
     RenderParams rp;
     fillRenderParams(settings, spp, rp);
+    rp.sampleBase = sampleBase;
+    rp.sppTotal = std::max(1u, sppTotal);
+    rp.passFlags = passFlags;
 
     if (ds.cachedW != settings.width || ds.cachedH != settings.height || ds.cachedPart != part || ds.cachedParts != parts) {
         std::vector<uint32_t> pixels;
@@ -420,7 +428,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     const uint32_t localPixels = ds.cachedLocalPixels;
     const uint32_t bandCount = ptr_part_band_count(settings.height, part, parts);
     const size_t outFloats = static_cast<size_t>(bandCount) * PTR_BAND_ROWS * settings.width * 3u;
-    HIP_CHECK(hipMemsetAsync(dOut, 0, outFloats * sizeof(float), stream));
+    if (passFlags & 1u) HIP_CHECK(hipMemsetAsync(dOut, 0, outFloats * sizeof(float), stream));
     if (localPixels == 0) {
         HIP_CHECK(hipStreamSynchronize(stream));
         return;
@@ -570,7 +578,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
         }
     };
 
-    if (count) HIP_CHECK(hipMemsetAsync(ds.counters.ptr, 0, sizeof(uint64_t) * kCounterSlots, stream));
+    if (count && (passFlags & 1u)) HIP_CHECK(hipMemsetAsync(ds.counters.ptr, 0, sizeof(uint64_t) * kCounterSlots, stream));   // counters add up over the passes
     HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * kScalarCount * kMaxPoolGroups, stream));
     {
         uint32_t* heads = ds.pinnedAlive + kPinnedHeadsOffset;
@@ -741,6 +749,67 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
                              100.0 * static_cast<double>(c[kCntExtendRefillTicks]) / std::max(static_cast<double>(c[kCntExtendWaveTicks]), 1.0));
             }
         }
+    }
+}
+
+// A frame.  One accumulator per sample has to fit in a quarter of the free device memory (at most 16 GiB); a frame with
+// more samples than that is rendered in several passes of equal sample counts whose per-pixel sums add up in the output
+// buffer.  (Folding C samples into one work item instead keeps one pass but lengthens the end-of-frame drain: 4096 spp of
+// config 2 as items of 9 samples ran at 1116 Msamples/s.)  The sample streams do not depend on the split.
+void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, uint32_t part, uint32_t parts, float* dOut,
+                 hipStream_t stream, int mode, PtrRenderStats* stats) {
+    if (settings.width == 0 || settings.height == 0) throw HipError{"render size must be non-zero"};
+    if (parts == 0 || part >= parts) throw HipError{"bad partition"};
+    HIP_CHECK(hipSetDevice(ds.device));
+    spp = std::max(1u, spp);
+    uint32_t passes = 1u;
+    if (!std::getenv("PTR_CHUNK_SIZE")) {
+        size_t freeBytes = 0, totalBytes = 0;
+        HIP_CHECK(hipMemGetInfo(&freeBytes, &totalBytes));
+        const uint64_t resident = ds.itemAccum.count * sizeof(float4);
+        const uint64_t budget = std::max<uint64_t>(64ull << 20, std::min<uint64_t>(16ull << 30, (freeBytes + resident) / 4u));
+        uint64_t maxItems = std::min<uint64_t>(budget / sizeof(float4), 0xFFFFFFF0ull);
+        if (const char* e = std::getenv("PTR_MAX_ITEMS")) maxItems = std::max<uint64_t>(1024u, std::strtoull(e, nullptr, 10));   // test knob
+        // counted on the whole frame, not on this partition: every partition then splits the samples the same way and the image
+        // stays bit-identical whatever the number of partitions
+        const uint64_t pixels = static_cast<uint64_t>(settings.width) * settings.height;
+        const uint64_t perPixel = std::max<uint64_t>(1u, maxItems / std::max<uint64_t>(pixels, 1u));   // samples per pixel that fit in one pass
+        passes = static_cast<uint32_t>((spp + perPixel - 1u) / perPixel);
+    }
+    if (passes <= 1u) {
+        renderPass(ds, settings, spp, 0u, spp, 3u, part, parts, dOut, stream, mode, stats);
+        return;
+    }
+    const uint32_t perPass = (spp + passes - 1u) / passes;
+    PtrRenderStats sum{};
+    uint32_t done = 0u;
+    for (uint32_t p = 0; done < spp; ++p) {
+        const uint32_t n = std::min(perPass, spp - done);
+        const uint32_t flags = (p == 0u ? 1u : 0u) | (done + n >= spp ? 2u : 0u);
+        PtrRenderStats one{};
+        renderPass(ds, settings, n, done, spp, flags, part, parts, dOut, stream, mode, stats ? &one : nullptr);
+        if (stats) {
+            sum.totalSeconds += one.totalSeconds;
+            sum.traceKernelMs += one.traceKernelMs;
+            sum.shadeKernelMs += one.shadeKernelMs;
+            sum.shadowKernelMs += one.shadowKernelMs;
+            sum.traceLaunches += one.traceLaunches;
+            sum.samples += one.samples;
+            const double keepSeconds = sum.totalSeconds, keepTrace = sum.traceKernelMs, keepShade = sum.shadeKernelMs, keepShadow = sum.shadowKernelMs;
+            const uint64_t keepLaunches = sum.traceLaunches, keepSamples = sum.samples;
+            sum = one;   // counters are cumulative on the device: the last pass reports the totals
+            sum.totalSeconds = keepSeconds;
+            sum.traceKernelMs = keepTrace;
+            sum.shadeKernelMs = keepShade;
+            sum.shadowKernelMs = keepShadow;
+            sum.traceLaunches = keepLaunches;
+            sum.samples = keepSamples;
+        }
+        done += n;
+    }
+    if (stats) {
+        sum.avgMsPerSample = sum.totalSeconds * 1000.0 / spp;
+        *stats = sum;
     }
 }
 

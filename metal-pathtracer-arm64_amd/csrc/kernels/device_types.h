@@ -82,7 +82,10 @@ struct RenderParams {
     uint32_t width, height;
     uint32_t maxDepth;
     uint32_t seedBase;
-    uint32_t spp;
+    uint32_t spp;                  // samples per pixel of THIS pass (all of them unless the frame is rendered in several passes)
+    uint32_t sampleBase;           // index of the pass's first sample: sample s of the pass draws the stream of sample sampleBase + s
+    uint32_t sppTotal;             // samples per pixel of the whole frame (the final division)
+    uint32_t passFlags;            // bit 0: first pass (the output is overwritten), bit 1: last pass (divide by sppTotal)
     uint32_t chunkSize;            // C: consecutive samples of one pixel rendered by one slot (a work item)
     uint32_t chunkCount;           // ceil(spp / C)
     uint32_t itemCount;            // localPixels * chunkCount; item w = chunk * localPixels + localPixel

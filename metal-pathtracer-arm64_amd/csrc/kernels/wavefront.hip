@@ -166,7 +166,7 @@ __device__ __forceinline__ void cameraRay(const RenderParams& rp, uint32_t x, ui
 
 // Start sample `s` of the slot's pixel: seed, primary ray, fresh path state.
 __device__ __forceinline__ void beginSample(const RenderParams& rp, uint32_t pixel, uint32_t s, uint32_t& rng, f3& org, f3& dir) {
-    rng = rngHash(rp.seedBase ^ pixel ^ (s * 0x9e3779b9u));
+    rng = rngHash(rp.seedBase ^ pixel ^ ((rp.sampleBase + s) * 0x9e3779b9u));
     cameraRay(rp, pixel % rp.width, pixel / rp.width, rng, org, dir);
 }
 
@@ -1274,14 +1274,16 @@ __global__ void __launch_bounds__(256) k_resolve(RenderParams rp, PathPool pool,
     if (lp >= rp.localPixels) return;
     f3 sum = mk3(0.0f);
     for (uint32_t c = 0; c < rp.chunkCount; ++c) sum += mk3(pool.itemAccum[static_cast<size_t>(c) * rp.localPixels + lp]);
-    const f3 avg = sum / static_cast<float>(rp.spp);
     const uint32_t pixel = pool.pixelOfLocal[lp];
     const uint32_t x = pixel % rp.width, y = pixel / rp.width;
     const uint32_t localBand = (y / PTR_BAND_ROWS) / partCount;
     float* o = out + (static_cast<size_t>(localBand * PTR_BAND_ROWS + (y % PTR_BAND_ROWS)) * rp.width + x) * 3u;
-    o[0] = avg.x;
-    o[1] = avg.y;
-    o[2] = avg.z;
+    // a frame rendered in several passes keeps its running sum in the output buffer between them
+    f3 total = (rp.passFlags & 1u) ? sum : mk3(o[0], o[1], o[2]) + sum;
+    if (rp.passFlags & 2u) total = total / static_cast<float>(rp.sppTotal);
+    o[0] = total.x;
+    o[1] = total.y;
+    o[2] = total.z;
 }
 
 // =====================================================================================================

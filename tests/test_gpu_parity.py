@@ -501,6 +501,26 @@ def test_partition_and_pool_size_invariance(cornell_small):
     assert np.array_equal(again, full)                                       # and run to run
 
 
+def test_frames_rendered_in_several_passes(cornell_small):
+    # a frame whose per-sample accumulators do not fit the memory budget is rendered in passes of equal sample counts that add up
+    # in the output buffer; the sample streams do not depend on the split, so only the order of the float additions differs
+    host, dev, osc = cornell_small
+    s = host.settings_for(width=64, height=64, max_depth=4, seed=1337)
+    whole, st_whole = dev.render_image(s, 24, count=True)
+    os.environ["PTR_MAX_ITEMS"] = str(64 * 64 * 5)            # 5 samples per pixel and pass -> 5 passes of 5, 5, 5, 5, 4
+    try:
+        split, st_split = dev.render_image(s, 24, count=True)
+        parts = [pt.assemble_bands([dev.render(s, 24, p, 3)[0] for p in range(3)], 64, 64)]   # passes x partitions
+    finally:
+        del os.environ["PTR_MAX_ITEMS"]
+    assert np.allclose(split, whole, rtol=2e-6, atol=1e-7) and not np.array_equal(split, np.zeros_like(split))
+    assert np.array_equal(parts[0], split)                    # still independent of the partition
+    assert st_split.extendRays == st_whole.extendRays and st_split.shadedHits == st_whole.shadedHits
+    assert st_split.samples == st_whole.samples == 64 * 64 * 24
+    ref, _, _ = osc.render(s, 24, threads=0)
+    assert _rmse(split, ref) < 2.0 * _rmse(whole, ref) + 1e-6
+
+
 def test_edge_cases(cornell_small, tmp_path):
     host, dev, osc = cornell_small
     # depth 1: only directly visible emission / background
