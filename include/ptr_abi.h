@@ -179,6 +179,12 @@ typedef struct PtrSettings {
     uint32_t metalSemantics;
     uint32_t sssMode;   /* RenderSettings::SssMode: 0 off, 1 separable, 2 random walk; read only with PTR_METAL_SSS */
     uint32_t sssMaxSteps;   /* RenderSettings::sssMaxSteps (32): closest-hit queries per random walk, at least 1 */
+    /* Test knob, 0 in every product render.  The reference measures the length of a rectangle-light shadow ray from the
+     * un-offset hit point (EmbreeHeadlessRenderer.mm:2745-2750, quirk Q9), so for a surface perpendicular to the light the
+     * ray ends 0.5e-4 before the light's own plane: the occlusion test is decided inside float rounding noise.  A value s
+     * in (0, 1) shortens those rays to distance * (1 - s) - 1e-4, which takes the decision out of the noise; the
+     * deterministic-stream tests use it (on both sides) to show what the pixels that differ at s = 0 come from. */
+    float debugShadowSlack;
 } PtrSettings;
 
 enum { PTR_METAL_MEDIA = 1u, PTR_METAL_THIN = 2u, PTR_METAL_FACE_NORMAL = 4u, PTR_METAL_SPECULAR = 8u, PTR_METAL_SSS = 16u, PTR_METAL_PBR = 32u };

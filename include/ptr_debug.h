@@ -24,6 +24,13 @@ int ptr_debug_sample_bsdf(const PtrMaterial* material, const PtrSettings* settin
 int ptr_debug_camera_rays(const PtrSettings* settings, const uint32_t* xys, uint64_t n, float* out,
                           uint32_t* out_states, char* err, size_t err_cap);
 
+/* One sample per pixel through the counting build of the render kernels, with every pixel's path signature
+ * (csrc/kernels/device_types.h kSig*: bits 0..15 = which path vertices received a rectangle-light sample that contributed,
+ * bits 16..31 = hash chain over the primitives hit).  The deterministic-stream tests compare it with the oracle's to say
+ * why a pixel differs.  out_rgb (width*height*3, may be NULL), out_signature (width*height). */
+int ptr_debug_render_signatures(PtrDeviceScene* scene, const PtrSettings* settings, float* out_rgb, uint32_t* out_signature,
+                                char* err, size_t err_cap);
+
 /* Host-side (no GPU): the environment importance tables the device sampler is fed
  * (src/renderer/EnvImportanceSampler.mm:70-171).  Outputs sized by the caller: texel_pdf, cond_alias,
  * cond_threshold: w*h; marg_alias, marg_threshold: h.  Returns non-zero if the map has no positive radiance. */

@@ -132,6 +132,7 @@ class PtrSettings(C.Structure):
         ("metalSemantics", C.c_uint32),
         ("sssMode", C.c_uint32),
         ("sssMaxSteps", C.c_uint32),
+        ("debugShadowSlack", C.c_float),
     ]
 
     def copy(self) -> "PtrSettings":
@@ -196,7 +197,7 @@ ABI_SYMBOLS = (
 )
 # include/ptr_debug.h (test-only device-function probes)
 DEBUG_SYMBOLS = ("ptr_debug_eval_bsdf", "ptr_debug_sample_bsdf", "ptr_debug_camera_rays", "ptr_debug_env_distribution",
-                 "ptr_debug_scene_geometry")
+                 "ptr_debug_scene_geometry", "ptr_debug_render_signatures")
 
 _lib: Optional[C.CDLL] = None
 
@@ -245,6 +246,7 @@ def load_library() -> C.CDLL:
     lib.ptr_debug_camera_rays.argtypes = [C.POINTER(PtrSettings), up, u64, fp, up, cp, sz]
     lib.ptr_debug_env_distribution.argtypes = [fp, u32, u32, fp, up, fp, up, fp, fp]
     lib.ptr_debug_scene_geometry.argtypes = [C.POINTER(PtrSceneDesc), u32, C.POINTER(u64), cp, sz]
+    lib.ptr_debug_render_signatures.argtypes = [vp, C.POINTER(PtrSettings), fp, up, cp, sz]
     _lib = lib
     return lib
 
@@ -384,6 +386,15 @@ class DeviceScene:
         err = _err_buf()
         _check(load_library().ptr_render_aovs(self._h, C.byref(settings), sample_index, _fptr(albedo), _fptr(normal), err, len(err)), err)
         return albedo, normal
+
+    def render_signatures(self, settings: PtrSettings) -> Tuple[np.ndarray, np.ndarray]:
+        """One sample per pixel with the path signature of every pixel (include/ptr_debug.h): ([H, W, 3] image, [H, W] uint32)."""
+        img = np.zeros((settings.height, settings.width, 3), dtype=np.float32)
+        sig = np.zeros((settings.height, settings.width), dtype=np.uint32)
+        err = _err_buf()
+        _check(load_library().ptr_debug_render_signatures(self._h, C.byref(settings), _fptr(img), sig.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                          err, len(err)), err)
+        return img, sig
 
     def trace_rays(self, rays: np.ndarray, any_hit: bool = False) -> Tuple[np.ndarray, PtrRenderStats]:
         """rays: [n, 8] float32 {ox,oy,oz,tmin,dx,dy,dz,tmax}; returns a structured array of PtrHit."""

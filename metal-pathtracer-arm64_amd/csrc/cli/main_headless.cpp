@@ -46,11 +46,16 @@ struct CliOptions {
     bool enableSoftwareRayTracing = false, enableSoftwareRayTracingSet = false;
     bool enableMnee = false, enableMneeSet = false;
     uint32_t metalSemantics = 0;
+    uint32_t backendSemantics = 0;   // what --backend / --enableEmbree imply; an explicit --semantics overrides it
+    bool semanticsSet = false;
     std::string formatString = "exr";
     ptr::ImageFileFormat format = ptr::ImageFileFormat::EXR;
     bool rgbaExr = false;
     bool verbose = false;
 };
+
+// PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL | PTR_METAL_SPECULAR | PTR_METAL_SSS | PTR_METAL_PBR
+constexpr uint32_t kMetalSemanticsAll = 63u;
 
 void printUsage(const char* exe) {
     std::cout << "Usage: " << exe << " [options]\n\n"
@@ -69,7 +74,8 @@ void printUsage(const char* exe) {
               << "  --envRotation=<deg>           Environment rotation in degrees\n"
               << "  --envIntensity=<float>        Environment intensity multiplier\n\n"
               << "Backend selection:\n"
-              << "  --backend=<hip|metal>          Headless backend (default hip; metal = alias)\n"
+              << "  --backend=<hip|embree|metal>   hip / embree: Embree-parity integrator (default); metal: as --semantics=metal\n"
+              << "  --enableEmbree[=0|1]           Same as --backend=embree (1) / --backend=metal (0)\n"
               << "  --semantics=<embree|metal>     Integrator semantics: embree = parity with the reference's Embree backend\n"
               << "                                 (default); metal = plus the Metal kernel's absorbing media, thin-walled glass, ray-facing\n"
               << "                                 glass normals, rough-metal VNDF formulas, subsurface scattering (scene: renderer sss=...),\n"
@@ -219,26 +225,40 @@ bool parseOptions(int argc, const char** argv, CliOptions& o, std::string& error
         } else if (arg == "--semantics") {
             if (!need("--semantics")) return false;
             if (value == "metal") {
-                o.metalSemantics = 63u;   // PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL | PTR_METAL_SPECULAR | PTR_METAL_SSS | PTR_METAL_PBR
+                o.metalSemantics = kMetalSemanticsAll;
             } else if (value == "embree") {
                 o.metalSemantics = 0u;
             } else {
                 error = "Invalid value for --semantics (expected embree or metal)";
                 return false;
             }
+            o.semanticsSet = true;
         } else if (arg == "--backend") {
+            // The reference picks between its two renderers here (main_headless.mm:344-362).  This build has one device
+            // path; what the reference's backends differ in is the integrator, so the names select its semantics:
+            // embree -> the Embree-parity integrator, metal -> the Metal kernel's.  An explicit --semantics wins.
             if (!need("--backend")) return false;
             std::string l;
             for (char c : value) l.push_back(static_cast<char>(std::tolower(static_cast<unsigned char>(c))));
-            if (l != "hip" && l != "metal") {
-                error = "Invalid value for --backend (expected hip)";
+            if (l == "metal") {
+                o.backendSemantics = kMetalSemanticsAll;
+            } else if (l == "embree" || l == "hip") {
+                o.backendSemantics = 0u;
+            } else {
+                error = "Invalid value for --backend (expected hip, embree or metal)";
                 return false;
             }
+        } else if (arg == "--enableEmbree") {
+            // main_headless.mm:363-371: --enableEmbree[=1] = --backend=embree, --enableEmbree=0 = --backend=metal
+            bool flag = true;
+            if (!boolArg("--enableEmbree", flag, nullptr)) return false;
+            o.backendSemantics = flag ? 0u : kMetalSemanticsAll;
         } else {
             error = "Unknown option: " + arg;
             return false;
         }
     }
+    if (!o.semanticsSet) o.metalSemantics = o.backendSemantics;
     if (!o.sceneProvided) {
         error = "--scene is required";
         return false;

@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <filesystem>
 #include <memory>
 #include <string>
@@ -27,29 +28,45 @@ void setErr(char* err, size_t cap, const std::string& msg) {
         std::snprintf(err, cap, "%s", msg.c_str());
     }
 }
+
+// Nothing may unwind across the C boundary (loaders allocate, parse and start threads): every entry point runs its
+// body through this guard and reports exceptions through the error string like any other failure.
+template <typename Fn>
+int guarded(char* err, size_t cap, Fn&& body) {
+    try {
+        return body();
+    } catch (const std::exception& e) {
+        setErr(err, cap, std::string("exception: ") + e.what());
+    } catch (...) {
+        setErr(err, cap, "unknown exception");
+    }
+    return 1;
+}
 }  // namespace
 
 extern "C" {
 
 int ptr_host_scene_load(const char* scene_path, const char* asset_dir, PtrHostScene** out, char* err, size_t err_cap) {
-    if (!scene_path || !out) {
-        setErr(err, err_cap, "ptr_host_scene_load: null argument");
-        return 1;
-    }
-    auto scene = std::make_unique<PtrHostScene>();
-    ptr::SceneManager manager(asset_dir ? std::string(asset_dir) : std::string());
-    std::string error;
-    if (!manager.loadSceneFromPath(scene_path, scene->resources, scene->settings, &error)) {
-        setErr(err, err_cap, error);
-        return 1;
-    }
-    scene->resources.fillSceneDesc(scene->desc);
-    ptr::FillPtrSettings(scene->settings, scene->podSettings);
-    // unlike render(), keep 0 when the scene gives no size so callers can apply the CLI default (1280x720)
-    if (scene->settings.renderWidth == 0) scene->podSettings.width = 0;
-    if (scene->settings.renderHeight == 0) scene->podSettings.height = 0;
-    *out = scene.release();
-    return 0;
+    return guarded(err, err_cap, [&]() -> int {
+        if (!scene_path || !out) {
+            setErr(err, err_cap, "ptr_host_scene_load: null argument");
+            return 1;
+        }
+        auto scene = std::make_unique<PtrHostScene>();
+        ptr::SceneManager manager(asset_dir ? std::string(asset_dir) : std::string());
+        std::string error;
+        if (!manager.loadSceneFromPath(scene_path, scene->resources, scene->settings, &error)) {
+            setErr(err, err_cap, error);
+            return 1;
+        }
+        scene->resources.fillSceneDesc(scene->desc);
+        ptr::FillPtrSettings(scene->settings, scene->podSettings);
+        // unlike render(), keep 0 when the scene gives no size so callers can apply the CLI default (1280x720)
+        if (scene->settings.renderWidth == 0) scene->podSettings.width = 0;
+        if (scene->settings.renderHeight == 0) scene->podSettings.height = 0;
+        *out = scene.release();
+        return 0;
+    });
 }
 
 void ptr_host_scene_free(PtrHostScene* scene) { delete scene; }
@@ -64,59 +81,63 @@ int ptr_host_scene_desc(const PtrHostScene* scene, PtrSceneDesc* out_desc, PtrSe
 int ptr_host_write_image(const char* path, const char* format, const float* linear_rgb, uint32_t width,
                          uint32_t height, int rgba_exr, uint32_t tonemap_mode, uint32_t aces_variant,
                          float exposure, float reinhard_white, char* err, size_t err_cap) {
-    if (!path || !format || !linear_rgb || width == 0 || height == 0) {
-        setErr(err, err_cap, "ptr_host_write_image: bad argument");
-        return 1;
-    }
-    ptr::ImageFileFormat fmt;
-    if (!ptr::ParseImageFileFormat(format, fmt)) {
-        setErr(err, err_cap, std::string("Unknown format: ") + format);
-        return 1;
-    }
-    std::string error;
-    bool ok;
-    if (fmt == ptr::ImageFileFormat::EXR && rgba_exr) {
-        std::vector<float> rgba(static_cast<size_t>(width) * height * 4u, 1.0f);
-        for (size_t i = 0; i < static_cast<size_t>(width) * height; ++i) {
-            rgba[i * 4 + 0] = linear_rgb[i * 3 + 0];
-            rgba[i * 4 + 1] = linear_rgb[i * 3 + 1];
-            rgba[i * 4 + 2] = linear_rgb[i * 3 + 2];
+    return guarded(err, err_cap, [&]() -> int {
+        if (!path || !format || !linear_rgb || width == 0 || height == 0) {
+            setErr(err, err_cap, "ptr_host_write_image: bad argument");
+            return 1;
         }
-        ok = ptr::WriteExrRgba(path, rgba.data(), width, height, "Linear sRGB", &error);
-    } else {
-        ptr::TonemapSettings tm;
-        tm.tonemapMode = tonemap_mode == 0 ? 1u : tonemap_mode;
-        tm.acesVariant = aces_variant;
-        tm.exposure = exposure;
-        tm.reinhardWhitePoint = reinhard_white;
-        ok = ptr::WriteImage(path, fmt, linear_rgb, width, height, tm, &error);
-    }
-    if (!ok) {
-        setErr(err, err_cap, error);
-        return 1;
-    }
-    return 0;
+        ptr::ImageFileFormat fmt;
+        if (!ptr::ParseImageFileFormat(format, fmt)) {
+            setErr(err, err_cap, std::string("Unknown format: ") + format);
+            return 1;
+        }
+        std::string error;
+        bool ok;
+        if (fmt == ptr::ImageFileFormat::EXR && rgba_exr) {
+            std::vector<float> rgba(static_cast<size_t>(width) * height * 4u, 1.0f);
+            for (size_t i = 0; i < static_cast<size_t>(width) * height; ++i) {
+                rgba[i * 4 + 0] = linear_rgb[i * 3 + 0];
+                rgba[i * 4 + 1] = linear_rgb[i * 3 + 1];
+                rgba[i * 4 + 2] = linear_rgb[i * 3 + 2];
+            }
+            ok = ptr::WriteExrRgba(path, rgba.data(), width, height, "Linear sRGB", &error);
+        } else {
+            ptr::TonemapSettings tm;
+            tm.tonemapMode = tonemap_mode == 0 ? 1u : tonemap_mode;
+            tm.acesVariant = aces_variant;
+            tm.exposure = exposure;
+            tm.reinhardWhitePoint = reinhard_white;
+            ok = ptr::WriteImage(path, fmt, linear_rgb, width, height, tm, &error);
+        }
+        if (!ok) {
+            setErr(err, err_cap, error);
+            return 1;
+        }
+        return 0;
+    });
 }
 
 int ptr_host_write_exr_multilayer(const char* path, const float* linear_rgb, uint32_t width, uint32_t height,
                                   const float* sample_counts, const char* colorspace, char* err, size_t err_cap) {
-    if (!path || !linear_rgb || width == 0 || height == 0) {
-        setErr(err, err_cap, "ptr_host_write_exr_multilayer: bad argument");
-        return 1;
-    }
-    const size_t n = static_cast<size_t>(width) * height;
-    std::vector<float> rgba(n * 4u, 1.0f);
-    for (size_t i = 0; i < n; ++i) {
-        rgba[i * 4 + 0] = linear_rgb[i * 3 + 0];
-        rgba[i * 4 + 1] = linear_rgb[i * 3 + 1];
-        rgba[i * 4 + 2] = linear_rgb[i * 3 + 2];
-    }
-    std::string error;
-    if (!ptr::WriteExrMultilayer(path, rgba.data(), width, height, sample_counts, colorspace, &error)) {
-        setErr(err, err_cap, error);
-        return 1;
-    }
-    return 0;
+    return guarded(err, err_cap, [&]() -> int {
+        if (!path || !linear_rgb || width == 0 || height == 0) {
+            setErr(err, err_cap, "ptr_host_write_exr_multilayer: bad argument");
+            return 1;
+        }
+        const size_t n = static_cast<size_t>(width) * height;
+        std::vector<float> rgba(n * 4u, 1.0f);
+        for (size_t i = 0; i < n; ++i) {
+            rgba[i * 4 + 0] = linear_rgb[i * 3 + 0];
+            rgba[i * 4 + 1] = linear_rgb[i * 3 + 1];
+            rgba[i * 4 + 2] = linear_rgb[i * 3 + 2];
+        }
+        std::string error;
+        if (!ptr::WriteExrMultilayer(path, rgba.data(), width, height, sample_counts, colorspace, &error)) {
+            setErr(err, err_cap, error);
+            return 1;
+        }
+        return 0;
+    });
 }
 
 int ptr_host_read_pfm(const char* path, float* out_rgb, uint32_t cap_floats, uint32_t* width, uint32_t* height) {
@@ -150,43 +171,47 @@ const char* ptr_version(void) { return "ptr-hip 0.1 (gfx950)"; }
 
 int ptr_debug_env_distribution(const float* rgba, uint32_t w, uint32_t h, float* texel_pdf, uint32_t* cond_alias,
                                float* cond_threshold, uint32_t* marg_alias, float* marg_threshold, float* total_weight) {
-    ptr::EnvImportanceDistribution d;
-    if (!ptr::BuildEnvImportanceDistribution(rgba, w, h, &d)) return 1;
-    const size_t n = static_cast<size_t>(w) * h;
-    for (size_t i = 0; i < n; ++i) {
-        texel_pdf[i] = d.texelPdf[i];
-        cond_alias[i] = d.conditional[i].alias;
-        cond_threshold[i] = d.conditional[i].threshold;
-    }
-    for (uint32_t y = 0; y < h; ++y) {
-        marg_alias[y] = d.marginal[y].alias;
-        marg_threshold[y] = d.marginal[y].threshold;
-    }
-    if (total_weight) *total_weight = d.totalWeight;
-    return 0;
+    return guarded(nullptr, 0, [&]() -> int {
+        ptr::EnvImportanceDistribution d;
+        if (!ptr::BuildEnvImportanceDistribution(rgba, w, h, &d)) return 1;
+        const size_t n = static_cast<size_t>(w) * h;
+        for (size_t i = 0; i < n; ++i) {
+            texel_pdf[i] = d.texelPdf[i];
+            cond_alias[i] = d.conditional[i].alias;
+            cond_threshold[i] = d.conditional[i].threshold;
+        }
+        for (uint32_t y = 0; y < h; ++y) {
+            marg_alias[y] = d.marginal[y].alias;
+            marg_threshold[y] = d.marginal[y].threshold;
+        }
+        if (total_weight) *total_weight = d.totalWeight;
+        return 0;
+    });
 }
 
 int ptr_debug_scene_geometry(const PtrSceneDesc* scene, uint32_t leaf_max, uint64_t out[16], char* err, size_t err_cap) {
-    if (!scene || !out) {
-        if (err && err_cap) std::snprintf(err, err_cap, "ptr_debug_scene_geometry: null argument");
-        return 1;
-    }
-    ptr::SceneGeometry geo;
-    std::string error;
-    if (!ptr::BuildSceneGeometry(*scene, leaf_max, geo, error)) {
-        if (err && err_cap) std::snprintf(err, err_cap, "%s", error.c_str());
-        return 1;
-    }
-    ptr::GeometryCheck c;
-    ptr::ValidateSceneGeometry(geo, c);
-    const float maxCell = std::max(std::max(geo.bvh.gridCell[0], geo.bvh.gridCell[1]), geo.bvh.gridCell[2]);
-    const uint64_t vals[16] = {c.nodes, c.leaves, c.trianglesReferenced, c.spheresReferenced, c.maxDepth, c.maxLeafSize,
-                               c.unreferenced, c.multiplyReferenced, c.boxViolations, c.quantViolations, c.badRefs,
-                               geo.triCount, geo.sphereCount, static_cast<uint64_t>(geo.bvh.sahCost * 1000.0),
-                               static_cast<uint64_t>((geo.gatherSeconds + geo.buildSeconds + geo.flattenSeconds) * 1000.0),
-                               (geo.bvh.nodeCount > 0 && maxCell * 8.0f <= geo.bvh.meanPrimExtent) ? 1u : 0u};
-    std::memcpy(out, vals, sizeof(vals));
-    return 0;
+    return guarded(err, err_cap, [&]() -> int {
+        if (!scene || !out) {
+            if (err && err_cap) std::snprintf(err, err_cap, "ptr_debug_scene_geometry: null argument");
+            return 1;
+        }
+        ptr::SceneGeometry geo;
+        std::string error;
+        if (!ptr::BuildSceneGeometry(*scene, leaf_max, geo, error)) {
+            if (err && err_cap) std::snprintf(err, err_cap, "%s", error.c_str());
+            return 1;
+        }
+        ptr::GeometryCheck c;
+        ptr::ValidateSceneGeometry(geo, c);
+        const float maxCell = std::max(std::max(geo.bvh.gridCell[0], geo.bvh.gridCell[1]), geo.bvh.gridCell[2]);
+        const uint64_t vals[16] = {c.nodes, c.leaves, c.trianglesReferenced, c.spheresReferenced, c.maxDepth, c.maxLeafSize,
+                                   c.unreferenced, c.multiplyReferenced, c.boxViolations, c.quantViolations, c.badRefs,
+                                   geo.triCount, geo.sphereCount, static_cast<uint64_t>(geo.bvh.sahCost * 1000.0),
+                                   static_cast<uint64_t>((geo.gatherSeconds + geo.buildSeconds + geo.flattenSeconds) * 1000.0),
+                                   (geo.bvh.nodeCount > 0 && maxCell * 8.0f <= geo.bvh.meanPrimExtent) ? 1u : 0u};
+        std::memcpy(out, vals, sizeof(vals));
+        return 0;
+    });
 }
 
 }  // extern "C"

@@ -41,6 +41,7 @@ void FillPtrSettings(const RenderSettings& s, PtrSettings& o) {
     o.metalSemantics = s.metalSemantics;
     o.sssMode = static_cast<uint32_t>(s.sssMode);
     o.sssMaxSteps = s.sssMaxSteps;
+    o.debugShadowSlack = 0.0f;
 }
 
 bool HipHeadlessRenderer::render(const HeadlessScene& scene, const HeadlessCamera&, const RenderSettings& settings,

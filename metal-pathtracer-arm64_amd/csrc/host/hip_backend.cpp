@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <string>
 #include <vector>
@@ -45,6 +46,22 @@ struct HipError {
 void setErr(char* err, size_t cap, const std::string& msg) {
     if (err && cap > 0) std::snprintf(err, cap, "%s", msg.c_str());
 }
+
+// Nothing may unwind across the C boundary: the BVH build allocates multi-GB vectors and starts threads
+// (std::bad_alloc, std::system_error), and the callers are ctypes / a C++ program built with another runtime.
+#define PTR_CATCH_ALL(err, cap)                                                                             \
+    catch (const HipError& e) {                                                                             \
+        setErr(err, cap, e.message);                                                                        \
+        return 1;                                                                                           \
+    }                                                                                                       \
+    catch (const std::exception& e) {                                                                       \
+        setErr(err, cap, std::string("exception: ") + e.what());                                            \
+        return 1;                                                                                           \
+    }                                                                                                       \
+    catch (...) {                                                                                           \
+        setErr(err, cap, "unknown exception");                                                              \
+        return 1;                                                                                           \
+    }
 
 template <typename T>
 struct DeviceBuffer {
@@ -100,17 +117,24 @@ struct PtrDeviceScene {
     SceneView view{};
     uint64_t info[8] = {0};
     double uploadSeconds = 0.0;
+    uint64_t deviceTotalBytes = 0;        // hipDeviceProp_t::totalGlobalMem
     bool hasRandomWalkMaterial = false;   // a type-5 material with sssParams.y >= 0.5 (Metal random-walk subsurface)
 
     // render-time resources, grown on demand and kept across calls
-    DeviceBuffer<float4> rayOrg, rayDir, hit, throughput, accum, recBuf, itemAccum;
+    DeviceBuffer<float4> ray0, ray1, thr, accum, recBuf, itemAccum;
+    DeviceBuffer<float2> hit;
+    DeviceBuffer<uint8_t> pending;
+    DeviceBuffer<uint32_t> flushItem, signature;
     uint64_t poolSlots = 16ull << 20;
     uint32_t poolGroups = 4;   // the pool is split into this many independent groups, one HIP stream each
     uint32_t feederChunk = 256, feederChunkSparse = 0;   // slots per work-head claim: full pool / mostly dead pool (0: slots per resident wave)
     std::vector<hipStream_t> groupStreams;   // streams of groups 1.. (group 0 runs on the caller's stream)
     std::vector<hipEvent_t> groupEvents;
     int refillBelow = 40;
-    DeviceBuffer<uint4> state, medium;
+    bool dualTraversal = true;   // two rays per lane in k_extend / k_connect (kernels/traverse_dual.h); PTR_TRAVERSAL=classic for the one-ray loop
+    uint32_t dualGrid = 0;
+    int dualRefillAt = 32;
+    DeviceBuffer<uint4> medium;
     DeviceBuffer<uint32_t> scalars, pixelOfLocal, spill;
     DeviceBuffer<uint2> itemReserve;
     DeviceBuffer<uint32_t> itemHeads, zeros;
@@ -139,6 +163,14 @@ constexpr uint32_t kAliveBase = 4;
 constexpr uint32_t kScalarCount = kAliveBase + kAliveRing;
 constexpr uint32_t kMaxPoolGroups = 8;        // one block of scalars / one spill area per group
 constexpr uint32_t kPinnedHeadsOffset = 16;   // pinned staging: [0..15] per-group live-slot counts, then kItemHeads range heads
+
+// Stack spill area of one pool group: the larger of the one-ray layout (levels beyond kLdsStackLevels, one column per thread of
+// the persistent grid) and the two-ray layout (levels beyond kDualLdsLevels, two columns per thread).
+size_t spillWordsPerGroup(const PtrDeviceScene& ds) {
+    const size_t classic = static_cast<size_t>(kTraversalStackDepth - kLdsStackLevels) * ds.traceGrid * kTraceBlock;
+    const size_t dual = static_cast<size_t>(kDualSpillLevels) * ds.dualGrid * kTraceBlock * 2u;
+    return std::max(classic, dual);
+}
 
 // 576 B MaterialData -> the 13 float4 the integrator reads (kernels/device_types.h MaterialSlot).
 void compactMaterial(const PtrMaterial& m, std::vector<float>& out) {
@@ -267,6 +299,7 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
 
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, ds.device));
+    ds.deviceTotalBytes = prop.totalGlobalMem;
     const uint32_t cus = prop.multiProcessorCount > 0 ? static_cast<uint32_t>(prop.multiProcessorCount) : 256u;
     ds.traceGrid = cus * 8u;   // 8 blocks of 256 threads per CU: fills the wave slots, grid-stride the rest
     if (const char* e = std::getenv("PTR_REFILL_BELOW")) {   // tuning knob
@@ -276,6 +309,16 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     if (const char* e = std::getenv("PTR_TRACE_BLOCKS_PER_CU")) {   // tuning knob
         const int v = std::atoi(e);
         if (v >= 1 && v <= 16) ds.traceGrid = cus * static_cast<uint32_t>(v);
+    }
+    ds.dualGrid = cus * 5u;      // PTR_DUAL_WAVES blocks of 256 threads per CU (kernels/wavefront.hip)
+    if (const char* e = std::getenv("PTR_TRAVERSAL")) ds.dualTraversal = std::string(e) != "classic";   // A/B knob
+    if (const char* e = std::getenv("PTR_DUAL_BLOCKS_PER_CU")) {   // tuning knob
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 16) ds.dualGrid = cus * static_cast<uint32_t>(v);
+    }
+    if (const char* e = std::getenv("PTR_DUAL_REFILL_AT")) {   // tuning knob
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 128) ds.dualRefillAt = v;
     }
     if (const char* e = std::getenv("PTR_POOL_SLOTS")) {   // tuning knob: resident path slots
         const unsigned long long v = std::strtoull(e, nullptr, 10);
@@ -287,7 +330,7 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= static_cast<int>(kMaxPoolGroups)) ds.poolGroups = static_cast<uint32_t>(v);
     }
-    ds.spill.ensure(static_cast<size_t>(kTraversalStackDepth - kLdsStackLevels) * ds.traceGrid * kTraceBlock * kMaxPoolGroups);
+    ds.spill.ensure(spillWordsPerGroup(ds) * kMaxPoolGroups);
     ds.scalars.ensure(static_cast<size_t>(kScalarCount) * kMaxPoolGroups);
     ds.counters.ensure(kCounterSlots);
     ds.zeros.ensure(16);
@@ -340,6 +383,7 @@ void fillRenderParams(const PtrSettings& s, uint32_t spp, RenderParams& rp) {
     rp.width = s.width;
     rp.height = s.height;
     rp.maxDepth = std::min(s.maxDepth, kFlagFieldMask);
+    rp.shadowSlack = (s.debugShadowSlack > 0.0f && s.debugShadowSlack < 1.0f) ? s.debugShadowSlack : 0.0f;
     rp.seedBase = s.seed != 0 ? s.seed : 0x9e3779b9u;
     rp.spp = std::max(1u, spp);
     rp.sampleBase = 0u;
@@ -399,6 +443,13 @@ struct EventTimer {
     }
 };
 
+// Bytes the per-sample accumulators of one pass may take: a quarter of the device's TOTAL memory, at most 16 GiB.  Taken
+// from the device's size, never from what happens to be free: every rank of a multi-GPU render has to split a frame
+// into the same passes (k_resolve adds the per-pass sums in pass order), whatever else lives on its card.
+uint64_t itemBudgetBytes(const PtrDeviceScene& ds) {
+    return std::max<uint64_t>(64ull << 20, std::min<uint64_t>(16ull << 30, ds.deviceTotalBytes / 4u));
+}
+
 // One pass over `spp` samples per pixel starting at sample `sampleBase` of a frame of `sppTotal`; passFlags bit 0 = first pass of
 // the frame (output and counters start from zero), bit 1 = last pass (the running sum in dOut is divided by sppTotal).
 void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, uint32_t sampleBase, uint32_t sppTotal, uint32_t passFlags,
@@ -434,29 +485,14 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         return;
     }
 
-    // Work items = (pixel, chunk of C consecutive samples).  Slots claim items from a global counter, so the
-    // pool stays full until the last chunks regardless of how path length varies over the image.
-    // Chunk size 1 keeps the end-of-frame tail short (once the item queue is dry every slot still finishes its item:
-    // C samples x up to maxDepth bounces at falling occupancy; C = 4 cost 12 % on config 2).  Each item owns a 16 B
-    // accumulator, so C grows only when one accumulator per sample would not fit: at most a quarter of the free
-    // device memory and never more than 16 GiB.
-    uint32_t chunkSize = 1u;
-    {
-        size_t freeBytes = 0, totalBytes = 0;
-        HIP_CHECK(hipMemGetInfo(&freeBytes, &totalBytes));
-        const uint64_t resident = ds.itemAccum.count * sizeof(float4);   // our own previous allocation is reusable
-        const uint64_t budget = std::max<uint64_t>(64ull << 20, std::min<uint64_t>(16ull << 30, (freeBytes + resident) / 4u));
-        const uint64_t perSample = static_cast<uint64_t>(localPixels) * rp.spp;
-        const uint64_t maxItems = std::min<uint64_t>(budget / sizeof(float4), 0xFFFFFFF0ull);
-        chunkSize = static_cast<uint32_t>(std::max<uint64_t>(1u, (perSample + maxItems - 1u) / maxItems));
-        chunkSize = std::min(chunkSize, 255u);   // sample-in-chunk lives in 8 bits of the slot state
-    }
-    if (const char* e = std::getenv("PTR_CHUNK_SIZE")) chunkSize = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 255));   // tuning knob
-    rp.chunkSize = chunkSize;
-    rp.chunkCount = (rp.spp + chunkSize - 1) / chunkSize;
+    // Work items = single pixel samples: item w = sample * localPixels + localPixel.  Slots claim items from 64 range heads,
+    // so the pool stays full until the last items regardless of how path length varies over the image.  (Items of C > 1
+    // consecutive samples lengthen the end of the frame - once the queue is dry every slot still finishes its item, C = 4
+    // cost 12 % on config 2 - so a frame whose per-sample accumulators do not fit is rendered in passes instead, see
+    // renderBands.)
     rp.localPixels = localPixels;
-    const uint64_t itemCount64 = static_cast<uint64_t>(localPixels) * rp.chunkCount;
-    if (itemCount64 > 0xFFFF0000ull) throw HipError{"too many work items (reduce spp or resolution)"};
+    const uint64_t itemCount64 = static_cast<uint64_t>(localPixels) * rp.spp;
+    if (itemCount64 > 0xFFFF0000ull) throw HipError{"too many work items for one pass (reduce spp or resolution)"};
     rp.itemCount = static_cast<uint32_t>(itemCount64);
     // enough to keep every CU's wave slots full several times over - but never more than half the work items: a pool as
     // large as the frame is all ramp-up and drain (config 1, 16.8 M samples: 16 Mi slots 16.2 ms, 8 Mi slots 10.0 ms)
@@ -467,12 +503,14 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
     rp.itemHeadFirst = slots;
     rp.itemsPerHead = static_cast<uint32_t>(((itemCount64 - slots + kItemHeads - 1u) / kItemHeads + 63u) & ~63ull);
 
-    ds.rayOrg.ensure(slots);
-    ds.rayDir.ensure(slots);
+    ds.ray0.ensure(slots);
+    ds.ray1.ensure(slots);
     ds.hit.ensure(slots);
-    ds.throughput.ensure(slots);
+    ds.thr.ensure(slots);
     ds.accum.ensure(slots);
-    ds.state.ensure(slots);
+    ds.pending.ensure(slots);
+    ds.flushItem.ensure(slots);
+    if (count) ds.signature.ensure(slots);
     ds.itemAccum.ensure(rp.itemCount);
     ds.recBuf.ensure(static_cast<size_t>(slots) * kRecSlots * 4u);
     ds.itemReserve.ensure((slots + 63u) / 64u);
@@ -480,12 +518,14 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
 
     PathPool pool;
     std::memset(&pool, 0, sizeof(pool));
-    pool.rayOrg = ds.rayOrg.ptr;
-    pool.rayDir = ds.rayDir.ptr;
+    pool.ray0 = ds.ray0.ptr;
+    pool.ray1 = ds.ray1.ptr;
     pool.hit = ds.hit.ptr;
-    pool.throughput = ds.throughput.ptr;
+    pool.thr = ds.thr.ptr;
     pool.accum = ds.accum.ptr;
-    pool.state = ds.state.ptr;
+    pool.pending = ds.pending.ptr;
+    pool.flushItem = ds.flushItem.ptr;
+    pool.signature = count ? ds.signature.ptr : nullptr;
     pool.medium = (rp.mediaMode & PTR_METAL_MEDIA) ? ds.medium.ptr : nullptr;
     pool.itemAccum = ds.itemAccum.ptr;
     ds.itemHeads.ensure(kItemHeadWords);
@@ -530,18 +570,20 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ds.groupEvents.push_back(e);
     }
-    const size_t spillWords = static_cast<size_t>(kTraversalStackDepth - kLdsStackLevels) * ds.traceGrid * kTraceBlock;
+    const size_t spillWords = spillWordsPerGroup(ds);
     std::vector<Group> groups(groupCount);
     for (uint32_t g = 0; g < groupCount; ++g) {
         Group& gr = groups[g];
         const uint32_t first = g * groupSlots;
         gr.pool = pool;
-        gr.pool.rayOrg += first;
-        gr.pool.rayDir += first;
+        gr.pool.ray0 += first;
+        gr.pool.ray1 += first;
         gr.pool.hit += first;
-        gr.pool.throughput += first;
+        gr.pool.thr += first;
         gr.pool.accum += first;
-        gr.pool.state += first;
+        gr.pool.pending += first;
+        gr.pool.flushItem += first;
+        if (gr.pool.signature) gr.pool.signature += first;
         if (gr.pool.medium) gr.pool.medium += first;
         for (uint32_t k = 0; k < kRecSlots; ++k) {
             gr.pool.rec[k].org += first;
@@ -553,6 +595,9 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         gr.pool.slots = std::min(groupSlots, slots - first);
         gr.scalars = ds.scalars.ptr + static_cast<size_t>(g) * kScalarCount;
         gr.cfg = LaunchConfig{ds.traceGrid, ds.spill.ptr + g * spillWords, gr.scalars + 1, ds.refillBelow};
+        gr.cfg.dual = ds.dualTraversal;
+        gr.cfg.dualGrid = ds.dualGrid;
+        gr.cfg.dualRefillAt = ds.dualRefillAt;
         gr.stream = g == 0 ? stream : ds.groupStreams[g - 1];
         gr.done = false;
         gr.feederChunk = ds.feederChunk;
@@ -595,13 +640,14 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
 
     const auto wall0 = std::chrono::steady_clock::now();
     launchGenerate(rp, pool, stream);
+    HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(ds.groupEvents[0], stream));
     for (uint32_t g = 1; g < groupCount; ++g) HIP_CHECK(hipStreamWaitEvent(groups[g].stream, ds.groupEvents[0], 0));
     uint64_t iterations = 0;
     // Worst case: every sample runs maxDepth bounces in sequence on its slot.
     // (a subsurface random walk adds up to sssMaxSteps iterations to a bounce)
     const uint64_t perBounce = ((rp.mediaMode & PTR_METAL_SSS) && rp.sssMode == 2u && ds.hasRandomWalkMaterial) ? 1ull + rp.sssMaxSteps : 1ull;
-    const uint64_t maxIterations = static_cast<uint64_t>(rp.maxDepth) * perBounce * ((itemCount64 + slots - 1) / slots + 1) * chunkSize + 8;
+    const uint64_t maxIterations = static_cast<uint64_t>(rp.maxDepth) * perBounce * ((itemCount64 + slots - 1) / slots + 1) + 8;
     // Phase 1: while unclaimed work items remain nobody needs to count survivors; the host looks at the item head
     // only when it expects it to be nearly exhausted (items are claimed at a steady rate, so after the first look the
     // next one is scheduled at 3/4 of the predicted remaining iterations).  Phase 2 (queue dry): k_shade counts live
@@ -629,6 +675,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         }
         ++iterations;
         if (iterations >= nextCheck || iterations >= maxIterations) {
+            HIP_CHECK(hipGetLastError());   // a launch that failed (bad configuration, out of resources) must not pass for a slow frame
             bool headsCopied = false;
             for (uint32_t g = 0; g < groupCount; ++g) {
                 Group& gr = groups[g];
@@ -657,7 +704,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
                     // up to the point where the static first chunks of the resident waves cover the whole list and
                     // the head is not touched at all
                     const uint32_t thin = gr.pool.slots / std::max(ds.pinnedAlive[g], 1u);
-                    const uint32_t waves = std::max(gr.cfg.traceGrid * (kTraceBlock / 64u), 1u);
+                    const uint32_t waves = std::max((gr.cfg.dual ? gr.cfg.dualGrid : gr.cfg.traceGrid) * (kTraceBlock / 64u), 1u);
                     const uint32_t perWave = ((gr.pool.slots + waves - 1u) / waves + 63u) / 64u * 64u;
                     const uint32_t cap = ds.feederChunkSparse ? ds.feederChunkSparse : std::max(perWave, ds.feederChunk);
                     gr.feederChunk = std::min(cap, ds.feederChunk * std::max(thin, 1u));
@@ -692,6 +739,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         HIP_CHECK(hipStreamWaitEvent(stream, ds.groupEvents[g], 0));
     }
     launchResolve(rp, pool, parts, dOut, stream);
+    HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(stream));
     const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
 
@@ -763,11 +811,8 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     HIP_CHECK(hipSetDevice(ds.device));
     spp = std::max(1u, spp);
     uint32_t passes = 1u;
-    if (!std::getenv("PTR_CHUNK_SIZE")) {
-        size_t freeBytes = 0, totalBytes = 0;
-        HIP_CHECK(hipMemGetInfo(&freeBytes, &totalBytes));
-        const uint64_t resident = ds.itemAccum.count * sizeof(float4);
-        const uint64_t budget = std::max<uint64_t>(64ull << 20, std::min<uint64_t>(16ull << 30, (freeBytes + resident) / 4u));
+    {
+        const uint64_t budget = itemBudgetBytes(ds);
         uint64_t maxItems = std::min<uint64_t>(budget / sizeof(float4), 0xFFFFFFF0ull);
         if (const char* e = std::getenv("PTR_MAX_ITEMS")) maxItems = std::max<uint64_t>(1024u, std::strtoull(e, nullptr, 10));   // test knob
         // counted on the whole frame, not on this partition: every partition then splits the samples the same way and the image
@@ -844,10 +889,8 @@ int ptr_scene_upload(const PtrSceneDesc* scene, int device, PtrDeviceScene** out
         buildScene(*scene, *ds);
         *out_scene = ds.release();
         return 0;
-    } catch (const HipError& e) {
-        setErr(err, err_cap, e.message);
-        return 1;
     }
+    PTR_CATCH_ALL(err, err_cap)
 }
 
 void ptr_scene_release(PtrDeviceScene* scene) {
@@ -873,10 +916,8 @@ int ptr_render_bands_device(PtrDeviceScene* scene, const PtrSettings* settings, 
         renderBands(*scene, *settings, spp, part_index, part_count, static_cast<float*>(d_out_rgb),
                     static_cast<hipStream_t>(stream), count_traversal, stats);
         return 0;
-    } catch (const HipError& e) {
-        setErr(err, err_cap, e.message);
-        return 1;
     }
+    PTR_CATCH_ALL(err, err_cap)
 }
 
 int ptr_render_bands(PtrDeviceScene* scene, const PtrSettings* settings, uint32_t spp, uint32_t part_index,
@@ -893,10 +934,8 @@ int ptr_render_bands(PtrDeviceScene* scene, const PtrSettings* settings, uint32_
         renderBands(*scene, *settings, spp, part_index, part_count, scene->outBands.ptr, nullptr, count_traversal, stats);
         HIP_CHECK(hipMemcpy(out_rgb_bands, scene->outBands.ptr, floats * sizeof(float), hipMemcpyDeviceToHost));
         return 0;
-    } catch (const HipError& e) {
-        setErr(err, err_cap, e.message);
-        return 1;
     }
+    PTR_CATCH_ALL(err, err_cap)
 }
 
 int ptr_render(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t spp, int verbose, float* out_rgb,
@@ -909,7 +948,14 @@ int ptr_render(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t 
     int rc = ptr_scene_upload(scene, 0, &ds, err, err_cap);
     if (rc != 0) return rc;
     const uint32_t bands = (settings->height + PTR_BAND_ROWS - 1u) / PTR_BAND_ROWS;
-    std::vector<float> banded(static_cast<size_t>(bands) * PTR_BAND_ROWS * settings->width * 3u);
+    std::vector<float> banded;
+    try {
+        banded.resize(static_cast<size_t>(bands) * PTR_BAND_ROWS * settings->width * 3u);
+    } catch (const std::exception& e) {
+        ptr_scene_release(ds);
+        setErr(err, err_cap, std::string("exception: ") + e.what());
+        return 1;
+    }
     PtrRenderStats local{};
     rc = ptr_render_bands(ds, settings, spp, 0, 1, banded.data(), 0, &local, err, err_cap);
     if (rc == 0) {
@@ -954,10 +1000,8 @@ int ptr_trace_rays(PtrDeviceScene* scene, const float* rays, uint64_t n, int any
             stats->shadowRays = any_hit ? n : 0;
         }
         return 0;
-    } catch (const HipError& e) {
-        setErr(err, err_cap, e.message);
-        return 1;
     }
+    PTR_CATCH_ALL(err, err_cap)
 }
 
 int ptr_render_aovs(PtrDeviceScene* scene, const PtrSettings* settings, uint32_t sample_index, float* out_albedo, float* out_normal,
@@ -982,13 +1026,39 @@ int ptr_render_aovs(PtrDeviceScene* scene, const PtrSettings* settings, uint32_t
         if (out_albedo) HIP_CHECK(hipMemcpy(out_albedo, albedo.ptr, pixels * sizeof(float4), hipMemcpyDeviceToHost));
         if (out_normal) HIP_CHECK(hipMemcpy(out_normal, normal.ptr, pixels * sizeof(float4), hipMemcpyDeviceToHost));
         return 0;
-    } catch (const HipError& e) {
-        setErr(err, err_cap, e.message);
-        return 1;
     }
+    PTR_CATCH_ALL(err, err_cap)
 }
 
 // ---- test-only entry points (include/ptr_debug.h) ----
+
+int ptr_debug_render_signatures(PtrDeviceScene* scene, const PtrSettings* settings, float* out_rgb, uint32_t* out_signature, char* err,
+                                size_t err_cap) {
+    if (!scene || !settings || !out_signature) {
+        setErr(err, err_cap, "ptr_debug_render_signatures: null argument");
+        return 1;
+    }
+    try {
+        const size_t pixels = static_cast<size_t>(settings->width) * settings->height;
+        const size_t floats = static_cast<size_t>(ptr_part_band_count(settings->height, 0, 1)) * PTR_BAND_ROWS * settings->width * 3u;
+        HIP_CHECK(hipSetDevice(scene->device));
+        scene->outBands.ensure(floats);
+        PtrRenderStats stats{};
+        renderBands(*scene, *settings, 1u, 0u, 1u, scene->outBands.ptr, nullptr, 1, &stats);   // counting build, 1 spp: item = local pixel
+        if (out_rgb) HIP_CHECK(hipMemcpy(out_rgb, scene->outBands.ptr, pixels * 3u * sizeof(float), hipMemcpyDeviceToHost));
+        std::vector<float4> items(pixels);
+        std::vector<uint32_t> pixelOfLocal(pixels);
+        HIP_CHECK(hipMemcpy(items.data(), scene->itemAccum.ptr, pixels * sizeof(float4), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(pixelOfLocal.data(), scene->pixelOfLocal.ptr, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t lp = 0; lp < pixels; ++lp) {
+            uint32_t bits;
+            std::memcpy(&bits, &items[lp].w, sizeof(bits));
+            out_signature[pixelOfLocal[lp]] = bits;
+        }
+        return 0;
+    }
+    PTR_CATCH_ALL(err, err_cap)
+}
 
 int ptr_debug_eval_bsdf(const PtrMaterial* material, const PtrSettings* settings, const float* in, uint64_t n, float* out,
                         char* err, size_t err_cap) {
@@ -1008,10 +1078,8 @@ int ptr_debug_eval_bsdf(const PtrMaterial* material, const PtrSettings* settings
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpy(out, dout.ptr, n * 5 * sizeof(float), hipMemcpyDeviceToHost));
         return 0;
-    } catch (const HipError& e) {
-        setErr(err, err_cap, e.message);
-        return 1;
     }
+    PTR_CATCH_ALL(err, err_cap)
 }
 
 int ptr_debug_sample_bsdf(const PtrMaterial* material, const PtrSettings* settings, const float* in, const uint32_t* front_face,
@@ -1037,10 +1105,8 @@ int ptr_debug_sample_bsdf(const PtrMaterial* material, const PtrSettings* settin
         HIP_CHECK(hipMemcpy(out, dout.ptr, n * 8 * sizeof(float), hipMemcpyDeviceToHost));
         HIP_CHECK(hipMemcpy(out_states, drngOut.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
         return 0;
-    } catch (const HipError& e) {
-        setErr(err, err_cap, e.message);
-        return 1;
     }
+    PTR_CATCH_ALL(err, err_cap)
 }
 
 int ptr_debug_camera_rays(const PtrSettings* settings, const uint32_t* xys, uint64_t n, float* out, uint32_t* out_states,
@@ -1060,10 +1126,8 @@ int ptr_debug_camera_rays(const PtrSettings* settings, const uint32_t* xys, uint
         HIP_CHECK(hipMemcpy(out, dout.ptr, n * 6 * sizeof(float), hipMemcpyDeviceToHost));
         HIP_CHECK(hipMemcpy(out_states, drng.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
         return 0;
-    } catch (const HipError& e) {
-        setErr(err, err_cap, e.message);
-        return 1;
     }
+    PTR_CATCH_ALL(err, err_cap)
 }
 
 }  // extern "C"

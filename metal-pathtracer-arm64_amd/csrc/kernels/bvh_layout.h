@@ -18,6 +18,14 @@ constexpr uint32_t kMaxLeafPrims = 8u;
 constexpr uint32_t kTraversalStackDepth = 48u;   // builder bounds tree depth below this
 constexpr uint32_t kLdsStackLevels = 16u;        // stack levels kept in LDS; deeper levels spill to HBM
 constexpr uint32_t kTraceBlock = 256u;           // threads per block of the traversal kernels
+// two-rays-per-lane kernels (traverse_dual.h): stack levels per ray kept in LDS - 2 rays x 14 levels x 256 lanes x 4 B = 28 KB per
+// block, 140 KB for the 5 blocks a CU holds (the kernels need 93-96 VGPRs: 5 waves per SIMD)
+#ifndef PTR_DUAL_LDS_LEVELS
+#define PTR_DUAL_LDS_LEVELS 14
+#endif
+constexpr uint32_t kDualLdsLevels = PTR_DUAL_LDS_LEVELS;
+constexpr uint32_t kDualLdsWords = kDualLdsLevels * 2u * kTraceBlock;
+constexpr uint32_t kDualSpillLevels = kTraversalStackDepth - kDualLdsLevels;   // per ray column, in HBM
 constexpr uint32_t kHitMiss = 0xFFFFFFFFu;
 constexpr uint32_t kHitSphereBit = 0x80000000u;
 

@@ -86,9 +86,7 @@ struct RenderParams {
     uint32_t sampleBase;           // index of the pass's first sample: sample s of the pass draws the stream of sample sampleBase + s
     uint32_t sppTotal;             // samples per pixel of the whole frame (the final division)
     uint32_t passFlags;            // bit 0: first pass (the output is overwritten), bit 1: last pass (divide by sppTotal)
-    uint32_t chunkSize;            // C: consecutive samples of one pixel rendered by one slot (a work item)
-    uint32_t chunkCount;           // ceil(spp / C)
-    uint32_t itemCount;            // localPixels * chunkCount; item w = chunk * localPixels + localPixel
+    uint32_t itemCount;            // localPixels * spp; work item w = sample * localPixels + localPixel (one sample each)
     uint32_t localPixels;          // pixels owned by this partition
     uint32_t mediaMode;            // PTR_METAL_* bits (0 = Embree-parity integrator)
     uint32_t sssMode;              // RenderSettings::SssMode, read only with PTR_METAL_SSS
@@ -102,6 +100,7 @@ struct RenderParams {
     // FireflyClampParams
     float clampFactor, clampFloor, throughputClamp, tailClampBase, tailClampRoughnessScale, minSpecularPdf, clampEnabled;
     float emissionScale;
+    float shadowSlack;             // test knob (PtrSettings.debugShadowSlack): 0 = the reference's shadow-ray length (quirk Q9)
 };
 
 // One pending light-connection ray of a path slot.
@@ -129,14 +128,19 @@ constexpr uint32_t kItemHeadWords = kItemHeads * kItemHeadStride + 1u;   // + th
 constexpr uint32_t kRecSlots = 5u;
 
 struct PathPool {
-    float4* rayOrg;        // xyz origin
-    float4* rayDir;        // xyz direction
-    float4* hit;           // (t, u, v, bits(primRef))
-    float4* throughput;    // xyz throughput, w lastBsdfPdf
-    float4* accum;         // xyz radiance sum of the slot's current work item; w = bits(item to flush)
-    uint4* state;          // x rng, y work item, z flags, w = pending mask (bits 0..4) | sample-in-chunk << 8
+    // Per-slot path state.  Every field a kernel does not need stays out of its loads: k_extend reads the two ray
+    // words and writes 8 B; k_connect reads one byte per slot plus the records that are pending; k_shade streams
+    // 72 B in and 64 B out per live slot (it was 96 / 80 with one 16 B state word, a 16 B hit and padded rays).
+    float4* ray0;          // (origin.xyz, direction.x)
+    float4* ray1;          // (direction.y, direction.z, pdf of the last BSDF sample, bits(flags))
+    float2* hit;           // (t, bits(primRef)) - barycentrics are recomputed by k_shade from the same operands
+    float4* thr;           // (throughput.xyz, bits(rng state))
+    float4* accum;         // (radiance sum of the slot's current work item, bits(work item))
+    uint8_t* pending;      // light-connection records of this bounce (bits 0..4): what k_connect walks
+    uint32_t* flushItem;   // valid while kFlagFlush: the finished item whose sum is published once its last records have landed
     uint4* medium;         // media mode only: stack of up to 8 dielectric material ids (16 bit each), depth in the flags
-    float4* itemAccum;     // [itemCount] finished work items (summed per pixel, in chunk order, by k_resolve)
+    uint32_t* signature;   // counting build only: per-slot path signature (see kSig* below); null otherwise
+    float4* itemAccum;     // [itemCount] finished work items (summed per pixel, in sample order, by k_resolve); w = signature
     uint32_t* nextItem;    // [kItemHeadWords] head k at [k * kItemHeadStride]: next unclaimed item of range k (k_shade)
     ShadowRecordView rec[kRecSlots];
     uint2* itemReserve;        // [slots/64] per-wave reservation {next, end} of work items (one atomic per 64 items)
@@ -147,16 +151,30 @@ struct PathPool {
     uint32_t recStride;        // slots of the WHOLE pool: distance between the fields / record slots of `rec`
 };
 
-// flags word
+// flags word (ray1.w)
 constexpr uint32_t kFlagAlive = 1u << 0;
 constexpr uint32_t kFlagLastDelta = 1u << 1;
-constexpr uint32_t kFlagFlush = 1u << 2;        // accumulator belongs to a finished item: store it, then zero
-constexpr uint32_t kFlagMediumShift = 3u;       // 4 bits: depth of the medium stack (0..8)
-constexpr uint32_t kFlagWalk = 1u << 7;         // the slot's ray is a step of a subsurface random walk (state in record slot 4)
+constexpr uint32_t kFlagFlush = 1u << 2;        // a finished item waits for its last records: publish it at the next visit
+constexpr uint32_t kFlagWalk = 1u << 3;         // the slot's ray is a step of a subsurface random walk (state in record slot 4)
+constexpr uint32_t kFlagMediumShift = 4u;       // 4 bits: depth of the medium stack (0..8)
 constexpr uint32_t kMaxMediumStack = 8u;
-constexpr uint32_t kFlagDepthShift = 8u;        // 12 bits
-constexpr uint32_t kFlagSpecDepthShift = 20u;   // 12 bits
-constexpr uint32_t kFlagFieldMask = 0xFFFu;
+constexpr uint32_t kFlagDepthShift = 8u;        // 9 bits
+constexpr uint32_t kFlagSpecDepthShift = 17u;   // 9 bits
+constexpr uint32_t kFlagFieldMask = 0x1FFu;     // path depth is limited to 511 bounces
+constexpr uint32_t kFlagPendingShift = 26u;     // 5 bits: the records queued at the last visit (same as pending[])
+constexpr uint32_t kFlagPendingMask = (1u << kRecSlots) - 1u;
+
+// Path signature (counting build, 1 spp): what the deterministic-stream tests use to say WHY a pixel differs from the
+// oracle's.  bits 0..15: bit d set when the rectangle-light sample taken at path vertex d contributed (it was evaluated,
+// non-zero and found unoccluded); bits 16..31: hash chain over the primitives hit, vertex by vertex (a miss included).
+constexpr uint32_t kSigNeeBits = 16u;
+__host__ __device__ inline uint32_t sigHashStep(uint32_t h, uint32_t primType, uint32_t geomIndex, uint32_t primIndex) {
+    uint32_t x = (h * 0x9e3779b1u) ^ (primType * 0x85ebca6bu) ^ (geomIndex * 0xc2b2ae35u) ^ primIndex;
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    return x & 0xFFFFu;
+}
 
 enum CounterSlot : uint32_t {
     kCntExtendRays = 0,

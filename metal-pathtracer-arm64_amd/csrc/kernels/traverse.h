@@ -84,8 +84,11 @@ __device__ __forceinline__ float4 load16f(__amdgpu_buffer_rsrc_t r, uint32_t byt
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// The hit record is distance + primitive only: the barycentrics a shader needs are recomputed from the same operands
+// by triangleUv (bit-identical to what the traversal's own test produced), so they cost neither registers in the
+// step loop nor 8 B per ray in the path-state stream.
 struct TraceHit {
-    float t, u, v;
+    float t;
     uint32_t prim;   // kHitMiss, or leaf-order index (| kHitSphereBit for spheres)
 };
 
@@ -122,6 +125,21 @@ __device__ __forceinline__ bool triangleTest(f3 v0, f3 e1, f3 e2, f3 org, f3 dir
     u = U * rcpAbsDen;
     v = V * rcpAbsDen;
     return true;
+}
+
+// Barycentrics of a triangle hit: the same expressions, in the same order, as triangleTest above.
+__device__ __forceinline__ void triangleUv(f3 v0, f3 e1, f3 e2, f3 org, f3 dir, float& u, float& v) {
+    const f3 Ng = cross(e2, e1);
+    const f3 C = v0 - org;
+    const f3 R = cross(C, dir);
+    const float den = dot(Ng, dir);
+    const float absDen = fabsf(den);
+    const float sgn = signbit(den) ? -1.0f : 1.0f;
+    const float U = dot(R, e2) * sgn;
+    const float V = dot(R, e1) * sgn;
+    const float rcpAbsDen = 1.0f / absDen;
+    u = U * rcpAbsDen;
+    v = V * rcpAbsDen;
 }
 
 __device__ __forceinline__ bool sphereTest(float4 s, f3 org, f3 dir, float tnear, float tfar, float& t) {
@@ -183,8 +201,6 @@ __device__ __forceinline__ bool travBegin(const SceneView& sc, Trav& t, f3 org, 
     }
     t.tnear = tnear;
     t.hit.t = tfar;
-    t.hit.u = 0.0f;
-    t.hit.v = 0.0f;
     t.hit.prim = kHitMiss;
     t.anyHit = anyHit;
     t.cur = sc.rootRef;
@@ -260,8 +276,6 @@ __device__ __forceinline__ bool travPrimStep(const SceneView& sc, const SceneMem
         float tt;
         if (sphereTest(sc.spheres[index], t.org, t.dir, t.tnear, t.hit.t, tt)) {
             t.hit.t = tt;
-            t.hit.u = 0.0f;
-            t.hit.v = 0.0f;
             t.hit.prim = index | kHitSphereBit;
             if (t.anyHit) return false;
         }
@@ -271,8 +285,6 @@ __device__ __forceinline__ bool travPrimStep(const SceneView& sc, const SceneMem
         float tt, u, v;
         if (triangleTest(mk3(a), mk3(b), mk3(c), t.org, t.dir, t.tnear, t.hit.t, tt, u, v)) {
             t.hit.t = tt;
-            t.hit.u = u;
-            t.hit.v = v;
             t.hit.prim = index;
             if (t.anyHit) return false;
         }

@@ -21,6 +21,7 @@
 #include "device_types.h"
 #include "launch.h"
 #include "traverse.h"
+#include "traverse_dual.h"
 #include "vec.h"
 
 namespace ptrk {
@@ -255,10 +256,11 @@ struct Surface {
     uint32_t material;
     uint32_t primType;    // 0 mesh, 1 sphere, 2 rectangle
     uint32_t primIndex;   // rectangle index for primType 2
+    uint32_t geomIndex;   // mesh index for primType 0
     bool frontFace, twoSided;
 };
 
-__device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 dir, float t, float u, float v, uint32_t prim) {
+__device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 dir, float t, uint32_t prim) {
     Surface s;
     s.t = t;
     s.position = org + t * dir;
@@ -274,6 +276,7 @@ __device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 d
         s.frontFace = dot(dir, n) < 0.0f;
         s.twoSided = true;
         s.primType = 1u;
+        s.geomIndex = 0u;
         s.primIndex = info.x;
         s.material = info.y;
         return s;
@@ -290,9 +293,13 @@ __device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 d
     f3 shading = adjusted;
     const uint32_t meta = __float_as_uint(b.w);
     s.material = __float_as_uint(a.w);
+    s.geomIndex = 0u;
     if ((meta >> 30) == 0u) {
         s.primType = 0u;
         s.primIndex = __float_as_uint(c.w);
+        s.geomIndex = meta & 0x3FFFFFFFu;
+        float u, v;   // the traversal kernels store distance and primitive only
+        triangleUv(mk3(a), mk3(b), mk3(c), org, dir, u, v);
         const float w = 1.0f - u - v;
         const f3 interp = (w * mk3(n0) + u * mk3(n1)) + v * mk3(n2);
         if (dot(interp, interp) > 0.0f) {
@@ -401,21 +408,18 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams rp, PathPool pool
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= pool.slots) return;
     // slot i starts with work item i; later items are claimed from pool.nextItem (initialised to `slots`)
-    uint4 st = make_uint4(0u, slot, 0u, 0u);
-    pool.accum[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t flags = 0u, rng = 0u;
+    f3 o = mk3(0.0f), d = mk3(0.0f);
     if (slot < rp.itemCount && rp.maxDepth > 0u) {
-        const uint32_t lp = slot % rp.localPixels;
-        const uint32_t chunk = slot / rp.localPixels;
-        uint32_t rng;
-        f3 o, d;
-        beginSample(rp, pool.pixelOfLocal[lp], chunk * rp.chunkSize, rng, o, d);
-        st.x = rng;
-        st.z = kFlagAlive | kFlagLastDelta;
-        pool.rayOrg[slot] = mk4(o, 0.0f);
-        pool.rayDir[slot] = mk4(d, 0.0f);
-        pool.throughput[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        beginSample(rp, pool.pixelOfLocal[slot % rp.localPixels], slot / rp.localPixels, rng, o, d);
+        flags = kFlagAlive | kFlagLastDelta;
     }
-    pool.state[slot] = st;
+    pool.ray0[slot] = mk4(o, d.x);
+    pool.ray1[slot] = make_float4(d.y, d.z, 1.0f, __uint_as_float(flags));
+    pool.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng));
+    pool.accum[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(slot));
+    pool.pending[slot] = 0u;
+    if (pool.signature) pool.signature[slot] = 0u;
 }
 
 // =====================================================================================================
@@ -454,13 +458,15 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
             if (COUNT) ++refills;
             const long long refillStart = COUNT ? clock64() : 0ll;
             const uint32_t idx = feeder.take(!active);
-            const bool live = idx != WaveFeeder::kNone && (pool.state[idx].z & kFlagAlive);
+            const uint32_t at = idx != WaveFeeder::kNone ? idx : 0u;
+            const float4 r0 = pool.ray0[at], r1 = pool.ray1[at];   // both in flight before the liveness test
+            const bool live = idx != WaveFeeder::kNone && (__float_as_uint(r1.w) & kFlagAlive);
             if (ALIVE) aliveSeen += static_cast<uint32_t>(__popcll(__ballot(live)));   // wave-uniform: stays in an SGPR
             if (live) {
                 mySlot = idx;
                 if (COUNT) ++rays;
-                active = travBegin(sc, t, mk3(pool.rayOrg[idx]), mk3(pool.rayDir[idx]), kEps, INFINITY, false, stack);
-                if (!active) pool.hit[idx] = make_float4(INFINITY, 0.0f, 0.0f, __uint_as_float(kHitMiss));
+                active = travBegin(sc, t, mk3(r0), mk3(r0.w, r1.x, r1.y), kEps, INFINITY, false, stack);
+                if (!active) pool.hit[idx] = make_float2(INFINITY, __uint_as_float(kHitMiss));
             }
             if (COUNT) {
                 // make the loaded values "used" here so the pass is timed with its memory waits, as it runs
@@ -477,7 +483,7 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
         }
         if (!travVote<COUNT>(sc, mem, t, active, stack, cnt)) {
             active = false;
-            pool.hit[mySlot] = make_float4(t.hit.t, t.hit.u, t.hit.v, __uint_as_float(t.hit.prim));
+            pool.hit[mySlot] = make_float2(t.hit.t, __uint_as_float(t.hit.prim));
         }
     }
     if (ALIVE) {
@@ -498,6 +504,120 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
         addCounter(pool.counters, kCntExtendVoteIterations, voteIterations);
         addCounter(pool.counters, kCntExtendRefillTicks, refillCycles >> 4);
         addCounter(pool.counters, kCntExtendWaveTicks, static_cast<uint32_t>((clock64() - kernelStart) >> 4));
+    }
+}
+
+// ---- k_extend, two rays per lane (traverse_dual.h) ------------------------------------------------------
+// PTR_DUAL_PRIM_BIAS: a primitive step is taken once the lanes that could take one exceed 1/BIAS of the lanes that could take
+// a node step.  kRefillAt: a refill pass runs once this many of the wave's 128 ray register sets are empty.
+#ifndef PTR_DUAL_PRIM_BIAS
+#define PTR_DUAL_PRIM_BIAS 2
+#endif
+#ifndef PTR_DUAL_WAVES
+#define PTR_DUAL_WAVES 5
+#endif
+#define PTR_DUAL_ATTR __attribute__((amdgpu_waves_per_eu(PTR_DUAL_WAVES, PTR_DUAL_WAVES)))
+
+// One vote + exchange: decides the kind of this iteration's step and makes A the ray to step in every lane that has
+// one of that kind.  Returns (wave-uniform) whether it is a node step; `stepping` = this lane takes part.
+__device__ __forceinline__ bool dualVote(RayRegs& A, RayRegs& B, bool& stepping) {
+    const bool aLive = !rayIdle(A), bLive = !rayIdle(B);
+    const bool aLeaf = aLive && rayAtLeaf(A), bLeaf = bLive && rayAtLeaf(B);
+    const bool aNode = aLive && !aLeaf, bNode = bLive && !bLeaf;
+    const int nodeLanes = __popcll(__ballot(aNode | bNode));
+    const int primLanes = __popcll(__ballot(aLeaf | bLeaf));
+    const bool nodeStep = nodeLanes >= primLanes * PTR_DUAL_PRIM_BIAS;
+    const bool wantA = nodeStep ? aNode : aLeaf;
+    const bool wantB = nodeStep ? bNode : bLeaf;
+    const bool exchange = !wantA && wantB;
+    if (__ballot(exchange) != 0ull) {
+        if (exchange) swapRays(A, B);
+    }
+    stepping = wantA | wantB;
+    return nodeStep;
+}
+
+template <bool COUNT, bool QUANT>
+__global__ void __launch_bounds__(kTraceBlock) PTR_DUAL_ATTR k_extend_dual(SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride,
+                                                                            uint32_t* workCounter, int refillAt, uint32_t feederChunk, uint32_t* aliveOut) {
+    __shared__ uint32_t ldsStack[kDualLdsWords];
+    DualStack stack;
+    stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
+    stack.spill = spill;
+    stack.spillStride = spillStride;
+    TraceCounters cnt{0u, 0u};
+    uint32_t rays = 0u, aliveSeen = 0u, refills = 0u, voteIterations = 0u, activeLanes = 0u, leafLanes = 0u;
+
+    const SceneMem mem = sceneMem(sc);
+    WaveFeeder feeder;
+    feeder.init(workCounter, pool.slots, feederChunk);
+    RayRegs A, B;
+    A.cur = kRayIdle;
+    B.cur = kRayIdle;
+    A.column = 0u;
+    B.column = 1u;
+    A.sp = B.sp = 0u;
+    A.tag = B.tag = 0u;
+    A.tfar = B.tfar = 0.0f;
+    A.prim = B.prim = kHitMiss;
+    A.org = A.dir = A.inv = A.oi = mk3(0.0f);
+    B.org = B.dir = B.inv = B.oi = mk3(0.0f);
+    while (true) {
+        const int empty = __popcll(__ballot(rayIdle(A))) + __popcll(__ballot(rayIdle(B)));
+        if (empty >= refillAt && !feeder.exhausted) {
+            // refill pass: the idle register set of every lane that has one becomes B and receives a new ray (a lane with both
+            // sets empty gets its second ray in the next pass)
+            if (COUNT) ++refills;
+            const bool exchange = rayIdle(A) && !rayIdle(B);
+            if (__ballot(exchange) != 0ull) {
+                if (exchange) swapRays(A, B);
+            }
+            const uint32_t idx = feeder.take(rayIdle(B));
+            const uint32_t at = idx != WaveFeeder::kNone ? idx : 0u;
+            const float4 r0 = pool.ray0[at], r1 = pool.ray1[at];   // both in flight before the liveness test
+            const bool live = idx != WaveFeeder::kNone && (__float_as_uint(r1.w) & kFlagAlive);
+            aliveSeen += static_cast<uint32_t>(__popcll(__ballot(live)));   // wave-uniform: stays in an SGPR
+            if (live) {
+                if (COUNT) ++rays;
+                if (!rayBegin<QUANT>(sc, B, mk3(r0), mk3(r0.w, r1.x, r1.y), INFINITY, false, idx)) {
+                    pool.hit[idx] = make_float2(INFINITY, __uint_as_float(kHitMiss));
+                }
+            }
+            continue;
+        }
+        if (empty == 128) break;
+        bool stepping;
+        const bool nodeStep = dualVote(A, B, stepping);
+        if (COUNT) {
+            ++voteIterations;
+            activeLanes += static_cast<uint32_t>(__popcll(__ballot(stepping)));
+            leafLanes += nodeStep ? 0u : static_cast<uint32_t>(__popcll(__ballot(stepping)));
+        }
+        bool more = true;
+        if (nodeStep) {
+            if (COUNT) ++cnt.waveNodeSteps;
+            if (stepping) more = rayNodeStep<QUANT, COUNT>(mem, A, kEps, stack, cnt);
+        } else {
+            if (COUNT) ++cnt.wavePrimSteps;
+            if (stepping) more = rayPrimStep<COUNT>(sc, mem, A, kEps, stack, cnt);
+        }
+        if (!more) pool.hit[A.tag] = make_float2(A.tfar, __uint_as_float(A.prim));
+    }
+    if (aliveOut) {
+        // one atomic per persistent wave: the host's termination check at the end of the frame
+        if (laneId() == 0 && aliveSeen != 0u) atomicAdd(aliveOut, aliveSeen);
+    }
+    if (COUNT) {
+        addCounter(pool.counters, kCntExtendRays, rays);
+        addCounter(pool.counters, kCntExtendNodes, cnt.nodes);
+        addCounter(pool.counters, kCntExtendPrims, cnt.prims);
+        addCounter(pool.counters, kCntExtendLeaves, cnt.leaves);
+        addCounter(pool.counters, kCntExtendWaveNodeSteps, cnt.waveNodeSteps);
+        addCounter(pool.counters, kCntExtendWavePrimSteps, cnt.wavePrimSteps);
+        addCounter(pool.counters, kCntExtendRefillPasses, refills);
+        addCounter(pool.counters, kCntExtendActiveLanes, activeLanes >> 6);
+        addCounter(pool.counters, kCntExtendLeafLanes, leafLanes >> 6);
+        addCounter(pool.counters, kCntExtendVoteIterations, voteIterations);
     }
 }
 
@@ -543,39 +663,40 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
     // zero word when the record is not pending, so the kernel has ~11 loads in flight per lane after ONE dependent
     // step (the state word) instead of walking a chain of ten load-wait pairs at 5 waves per SIMD.
     const uint32_t at = inRange ? slot : 0u;
+    float4 ray1v = pool.ray1[at];
     if (resets.drained) {
-        // end of the frame: most waves cover 64 dead slots, and the loads below would still stream 96 B per slot
-        const uint4 peek = pool.state[at];
-        const bool busy = inRange && ((peek.z & (kFlagAlive | kFlagFlush)) != 0u || (peek.w & 0xFFu) != 0u);
+        // end of the frame: most waves cover 64 dead slots, and the loads below would still stream 56 B per slot
+        const uint32_t peek = __float_as_uint(ray1v.w);
+        const bool busy = inRange && (peek & (kFlagAlive | kFlagFlush | (kFlagPendingMask << kFlagPendingShift))) != 0u;
         if (__ballot(busy) == 0ull) return;
     }
-    uint4 st = pool.state[at];
+    const float4 ray0v = pool.ray0[at];
+    const float2 hitv = pool.hit[at];
+    const float4 thr4 = pool.thr[at];
     const float4 acc4 = pool.accum[at];
-    const float4 rayO4 = pool.rayOrg[at], rayD4 = pool.rayDir[at];
-    const float4 hitv = pool.hit[at];
-    const float4 thr4 = pool.throughput[at];
-    if (!inRange) st = make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t flagsIn = inRange ? __float_as_uint(ray1v.w) : 0u;
+    const uint32_t pendingIn = (flagsIn >> kFlagPendingShift) & kFlagPendingMask;
     float4 landed[kRecSlots];
 #pragma unroll
     for (uint32_t k = 0; k < kRecSlots; ++k) {
-        const float4* src = (st.w & (1u << k)) ? pool.rec[k].a + at : pool.zero;
+        const float4* src = (pendingIn & (1u << k)) ? pool.rec[k].a + at : pool.zero;
         landed[k] = *src;
     }
-    asm volatile("" ::"v"(acc4.x), "v"(rayO4.x), "v"(rayD4.x), "v"(hitv.x), "v"(thr4.x), "v"(landed[0].x), "v"(landed[1].x), "v"(landed[2].x),
+    asm volatile("" ::"v"(acc4.x), "v"(ray0v.x), "v"(hitv.x), "v"(thr4.x), "v"(landed[0].x), "v"(landed[1].x), "v"(landed[2].x),
                  "v"(landed[3].x), "v"(landed[4].x));   // keep the loads here: the compiler would sink each one next to its use
-    const bool active = inRange && (st.z & kFlagAlive);
-    const bool touched = inRange && (active || (st.w & 0xFFu) != 0u || (st.z & kFlagFlush));   // state/accum rewritten
+    const bool active = inRange && (flagsIn & kFlagAlive);
+    const bool touched = inRange && (active || pendingIn != 0u || (flagsIn & kFlagFlush));   // state/accum rewritten
 
     bool want[kRecSlots] = {false, false, false, false, false};
     bool stillAlive = false, needItem = false, walkFlag = false;
     uint32_t shadedHit = 0u, triHit = 0u, primary = 0u;
-    uint32_t sampleInChunk = (st.w >> 8) & 0xFFu;
-    uint32_t rng = st.x;
+    uint32_t rng = __float_as_uint(thr4.w);
+    uint32_t item = __float_as_uint(acc4.w);
     uint32_t depth = 0u, specDepth = 0u, mediumDepth = 0u;
     bool lastDelta = true, flushNext = false;
     f3 acc = mk3(0.0f), thr = mk3(1.0f), nextO = mk3(0.0f), nextD = mk3(0.0f);
     float lastPdf = 1.0f;
-    uint32_t flushItem = 0u;
+    uint32_t sig = 0u;   // counting build: path signature of the slot's current item
 
     if (touched) {
         const ClampCfg cc = clampCfg(rp);
@@ -583,24 +704,34 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
         // light connections queued last bounce have been resolved by k_connect: add them in slot order
 #pragma unroll
         for (uint32_t k = 0; k < kRecSlots; ++k) {
-            if (st.w & (1u << k)) acc += mk3(landed[k]);
+            if (pendingIn & (1u << k)) acc += mk3(landed[k]);
         }
-        if (st.z & kFlagFlush) {
+        if (COUNT && pool.signature) {
+            sig = pool.signature[slot];
+            // a surviving rectangle-light sample carries the depth of its vertex in a.w (k_connect zeroes the whole record
+            // when the ray is occluded)
+            if ((pendingIn & 1u) && (landed[0].x > 0.0f || landed[0].y > 0.0f || landed[0].z > 0.0f)) {
+                const uint32_t d = static_cast<uint32_t>(landed[0].w);
+                if (d < kSigNeeBits) sig |= 1u << d;
+            }
+        }
+        if (flagsIn & kFlagFlush) {
             // the previous work item of this slot is complete (its last connections just landed): publish it
-            pool.itemAccum[__float_as_uint(acc4.w)] = mk4(acc, 0.0f);
+            pool.itemAccum[pool.flushItem[slot]] = mk4(acc, __uint_as_float(sig));
             acc = mk3(0.0f);
+            sig = 0u;
         }
 
         if (active) {
-            depth = (st.z >> kFlagDepthShift) & kFlagFieldMask;
-            specDepth = (st.z >> kFlagSpecDepthShift) & kFlagFieldMask;
-            mediumDepth = (st.z >> kFlagMediumShift) & 0xFu;
-            lastDelta = (st.z & kFlagLastDelta) != 0u;
-            const f3 rayO = mk3(rayO4);
-            const f3 rayD = mk3(rayD4);
+            depth = (flagsIn >> kFlagDepthShift) & kFlagFieldMask;
+            specDepth = (flagsIn >> kFlagSpecDepthShift) & kFlagFieldMask;
+            mediumDepth = (flagsIn >> kFlagMediumShift) & 0xFu;
+            lastDelta = (flagsIn & kFlagLastDelta) != 0u;
+            const f3 rayO = mk3(ray0v);
+            const f3 rayD = mk3(ray0v.w, ray1v.x, ray1v.y);
             thr = mk3(thr4);
-            lastPdf = thr4.w;
-            const uint32_t prim = __float_as_uint(hitv.w);
+            lastPdf = ray1v.z;
+            const uint32_t prim = __float_as_uint(hitv.y);
             if (COUNT && depth == 0u) primary = 1u;
 
             bool endPath = false;
@@ -608,7 +739,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
             nextD = rayD;
             bool walking = false;   // SSS: the slot stays in (or enters) a subsurface random walk: no bounce bookkeeping this visit
 
-            if (SSS && (st.z & kFlagWalk)) {
+            if (SSS && (flagsIn & kFlagWalk)) {
                 // ---- one step of a subsurface random walk: this ray was the walk's boundary query (bsdf.h: sssWalkStep) ----
                 const ShadowRecordView& wr = pool.rec[4];
                 const float4 w0 = wr.org[slot], w1 = wr.dir[slot], w2 = wr.a[slot], w3 = wr.b[slot];
@@ -617,7 +748,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
                 SssWalk walk{rayO, rayD, mk3(w2), __float_as_uint(w2.w)};
                 f3 hitPoint = rayO, outward = mk3(0.0f);
                 if (prim != kHitMiss) {
-                    const Surface bsf = reconstruct(sc, rayO, rayD, hitv.x, hitv.y, hitv.z, prim);
+                    const Surface bsf = reconstruct(sc, rayO, rayD, hitv.x, prim);
                     hitPoint = bsf.position;
                     outward = bsf.normal;   // the geometric normal as stored = the reference's face-forwarded normal turned back
                 }
@@ -684,14 +815,16 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
                     mis = clampf(mis, kMisMin, kMisMax);
                 }
                 acc += clampFirefly(thr, bg * mis, cc);
+                if (COUNT) sig = (sig & 0xFFFFu) | (sigHashStep(sig >> 16, 7u, 0u, 0u) << 16);
                 endPath = true;
             } else if (sc.materialCount == 0u) {
                 endPath = true;
             } else {
-                const Surface sf = reconstruct(sc, rayO, rayD, hitv.x, hitv.y, hitv.z, prim);
+                const Surface sf = reconstruct(sc, rayO, rayD, hitv.x, prim);
                 if (COUNT) {
                     shadedHit = 1u;
                     triHit = sf.primType == 0u ? 1u : 0u;
+                    sig = (sig & 0xFFFFu) | (sigHashStep(sig >> 16, sf.primType, sf.geomIndex, sf.primIndex) << 16);
                 }
                 if ((rp.mediaMode & PTR_METAL_MEDIA) && mediumDepth > 0u) {
                     // Beer-Lambert over the segment just travelled inside the innermost medium (pathtrace.metal:5869-5876)
@@ -770,8 +903,11 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
                                             const f3 clamped = clampFirefly(thr, contrib, cc);
                                             if (clamped.x > 0.0f || clamped.y > 0.0f || clamped.z > 0.0f) {
                                                 // tfar is measured from the un-offset hit point (reference quirk Q9)
-                                                const float shadowMax = smax(distance - kEps, kEps);
-                                                storeRecord(pool, slot, 0u, 0u, offsetOrigin(sf, ldir), shadowMax, ldir, clamped, 0.0f, mk3(0.0f));
+                                                // (rp.shadowSlack is a test knob, 0 in every product render: x * 1.0f is x)
+                                                const float shadowMax = smax(distance * (1.0f - rp.shadowSlack) - kEps, kEps);
+                                                // a.w: depth of this vertex, for the path signature of the counting build
+                                                storeRecord(pool, slot, 0u, 0u, offsetOrigin(sf, ldir), shadowMax, ldir, clamped,
+                                                            static_cast<float>(depth), mk3(0.0f));
                                                 want[0] = true;
                                             }
                                         }
@@ -915,23 +1051,21 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
             }
 
             if (endPath) {
-                // next sample of the same work item, or (below, wave-wide) a new work item
-                ++sampleInChunk;
-                const uint32_t chunk = st.y / rp.localPixels;
-                const uint32_t s = chunk * rp.chunkSize + sampleInChunk;
+                // the item (one sample) is finished: ask for a new one (below, wave-wide)
                 thr = mk3(1.0f);
                 lastPdf = 1.0f;
                 lastDelta = true;
                 depth = 0u;
                 specDepth = 0u;
                 mediumDepth = 0u;
-                if (sampleInChunk < rp.chunkSize && s < rp.spp) {
-                    beginSample(rp, pool.pixelOfLocal[st.y % rp.localPixels], s, rng, nextO, nextD);
-                    stillAlive = true;
-                } else {
-                    needItem = true;
+                needItem = true;
+                if (want[0] | want[1] | want[2] | want[3] | want[4]) {
                     flushNext = true;       // publish this item after its last connections have been added
-                    flushItem = st.y;
+                    pool.flushItem[slot] = item;
+                } else {
+                    pool.itemAccum[item] = mk4(acc, __uint_as_float(sig));   // nothing outstanding: publish it now
+                    acc = mk3(0.0f);
+                    sig = 0u;
                 }
             } else {
                 stillAlive = true;
@@ -987,7 +1121,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
             // exhausted, or for the last few items of the frame (ranges are multiples of kItemReserve, only the final
             // one is clipped)
             const uint32_t fresh = newEnd - newBase;   // 0 when every range is exhausted
-            const uint32_t item = (rank < avail) ? (resOld + rank) : ((rank - avail < fresh) ? newBase + (rank - avail) : rp.itemCount);
+            const uint32_t claimed = (rank < avail) ? (resOld + rank) : ((rank - avail < fresh) ? newBase + (rank - avail) : rp.itemCount);
             if (avail < n) {
                 res.x = newBase + min(n - avail, fresh);
                 res.y = newEnd;
@@ -995,10 +1129,9 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
                 res.x += n;
             }
             if (laneId() == firstLane) pool.itemReserve[waveId] = res;
-            if (needItem && item < rp.itemCount) {
-                st.y = item;
-                sampleInChunk = 0u;
-                beginSample(rp, pool.pixelOfLocal[item % rp.localPixels], (item / rp.localPixels) * rp.chunkSize, rng, nextO, nextD);
+            if (needItem && claimed < rp.itemCount) {
+                item = claimed;
+                beginSample(rp, pool.pixelOfLocal[claimed % rp.localPixels], claimed / rp.localPixels, rng, nextO, nextD);
                 stillAlive = true;
             }
         }
@@ -1011,17 +1144,17 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
         if (want[k]) pendingMask |= 1u << k;
     }
     if (touched) {
-        st.x = rng;
-        st.z = (stillAlive ? kFlagAlive : 0u) | (lastDelta ? kFlagLastDelta : 0u) | (flushNext ? kFlagFlush : 0u) | (walkFlag ? kFlagWalk : 0u) |
-               (depth << kFlagDepthShift) | (specDepth << kFlagSpecDepthShift) | (mediumDepth << kFlagMediumShift);
-        st.w = pendingMask | (sampleInChunk << 8);
-        pool.state[slot] = st;
-        pool.accum[slot] = mk4(acc, __uint_as_float(flushItem));
+        const uint32_t flags = (stillAlive ? kFlagAlive : 0u) | (lastDelta ? kFlagLastDelta : 0u) | (flushNext ? kFlagFlush : 0u) |
+                               (walkFlag ? kFlagWalk : 0u) | (depth << kFlagDepthShift) | (specDepth << kFlagSpecDepthShift) |
+                               (mediumDepth << kFlagMediumShift) | (pendingMask << kFlagPendingShift);
+        pool.ray1[slot] = make_float4(nextD.y, nextD.z, lastPdf, __uint_as_float(flags));
+        pool.accum[slot] = mk4(acc, __uint_as_float(item));
+        if (pendingMask != 0u || pendingIn != 0u) pool.pending[slot] = static_cast<uint8_t>(pendingMask);
         if (stillAlive) {
-            pool.rayOrg[slot] = mk4(nextO, 0.0f);
-            pool.rayDir[slot] = mk4(nextD, 0.0f);
-            pool.throughput[slot] = mk4(thr, lastPdf);
+            pool.ray0[slot] = mk4(nextO, nextD.x);
+            pool.thr[slot] = mk4(thr, __uint_as_float(rng));
         }
+        if (COUNT && pool.signature) pool.signature[slot] = sig;
     }
 
     if (COUNT) {
@@ -1041,7 +1174,7 @@ __device__ __forceinline__ f3 alongRect(const RenderParams& rp, const SceneView&
                                         float bsdfPdfIn, f3 thr, LaneStack& stack, TraceCounters& cnt) {
     const TraceHit h = traverse<false, COUNT>(sc, org, dir, kEps, INFINITY, stack, cnt);
     if (h.prim == kHitMiss) return mk3(0.0f);
-    const Surface ls = reconstruct(sc, org, dir, h.t, h.u, h.v, h.prim);
+    const Surface ls = reconstruct(sc, org, dir, h.t, h.prim);
     f3 emission;
     float pdf;
     if (!rectLightHit(sc, ls, org, rp.emissionScale, emission, pdf)) return mk3(0.0f);
@@ -1077,7 +1210,7 @@ __device__ __forceinline__ f3 alongEnv(const RenderParams& rp, const SceneView& 
 __device__ __forceinline__ f3 rectContribution(const RenderParams& rp, const SceneView& sc, const ClampCfg& cc, f3 org, f3 dir,
                                                const TraceHit& h, f3 weight, float bsdfPdfIn, f3 thr) {
     if (h.prim == kHitMiss) return mk3(0.0f);
-    const Surface ls = reconstruct(sc, org, dir, h.t, h.u, h.v, h.prim);
+    const Surface ls = reconstruct(sc, org, dir, h.t, h.prim);
     f3 emission;
     float pdf;
     if (!rectLightHit(sc, ls, org, rp.emissionScale, emission, pdf)) return mk3(0.0f);
@@ -1101,7 +1234,7 @@ __device__ f3 mneeChain(const RenderParams& rp, const SceneView& sc, const Clamp
     if (COUNT) ++raysClosest;
     const TraceHit h = traverse<false, COUNT>(sc, org, dir, kEps, INFINITY, stack, cntClosest);
     if (h.prim == kHitMiss || sc.materialCount == 0u) return result;
-    const Surface cs = reconstruct(sc, org, dir, h.t, h.u, h.v, h.prim);
+    const Surface cs = reconstruct(sc, org, dir, h.t, h.prim);
     f3 tmpE;
     float tmpP;
     if (sc.rectLightCount > 0u && rectLightHit(sc, cs, org, rp.emissionScale, tmpE, tmpP)) return result;
@@ -1166,7 +1299,7 @@ __global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_e
                 const uint32_t idx = feeder.take(!active && bits == 0u);
                 if (idx != WaveFeeder::kNone) {
                     mySlot = idx;
-                    bits = pool.state[idx].w & ((1u << kRecSlots) - 1u);
+                    bits = pool.pending[idx] & kFlagPendingMask;
                 }
             }
             if (!active && bits != 0u) {
@@ -1218,6 +1351,110 @@ __global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_e
     }
 }
 
+// k_connect with two rays per lane (traverse_dual.h).  A lane walks the records of one slot at a time (`bits`); each of its two
+// register sets carries the address of the record it is resolving.
+template <bool COUNT, bool QUANT>
+__global__ void __launch_bounds__(kTraceBlock) PTR_DUAL_ATTR k_connect_dual(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill,
+                                                                             uint32_t spillStride, uint32_t* workCounter, int refillAt,
+                                                                             uint32_t feederChunk) {
+    __shared__ uint32_t ldsStack[kDualLdsWords];
+    DualStack stack;
+    stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
+    stack.spill = spill;
+    stack.spillStride = spillStride;
+    TraceCounters cnt{0u, 0u}, cntClosest{0u, 0u};
+    uint32_t rays = 0u, raysClosest = 0u, early = 0u;
+    const ClampCfg cc = clampCfg(rp);
+
+    const SceneMem mem = sceneMem(sc);
+    WaveFeeder feeder;
+    feeder.init(workCounter, pool.slots, feederChunk);
+    RayRegs A, B;
+    A.cur = kRayIdle;
+    B.cur = kRayIdle;
+    A.column = 0u;
+    B.column = 1u;
+    A.sp = B.sp = 0u;
+    A.tag = B.tag = 0u;
+    A.tfar = B.tfar = 0.0f;
+    A.prim = B.prim = kHitMiss;
+    A.org = A.dir = A.inv = A.oi = mk3(0.0f);
+    B.org = B.dir = B.inv = B.oi = mk3(0.0f);
+    uint32_t mySlot = 0u, bits = 0u;
+    // the record arrays are one allocation: field f of record slot k lives at recBase[(k*4 + f)*slots + slot]
+    float4* const recBase = pool.rec[0].org;
+    const uint32_t slots = pool.recStride;   // field stride (whole pool), not the slot count of this group
+    while (true) {
+        const int empty = __popcll(__ballot(rayIdle(A))) + __popcll(__ballot(rayIdle(B)));
+        const bool lanesWithRecords = __ballot(bits != 0u && (rayIdle(A) || rayIdle(B))) != 0ull;
+        if (empty >= refillAt && (lanesWithRecords || !feeder.exhausted)) {
+            const bool exchange = rayIdle(A) && !rayIdle(B);
+            if (__ballot(exchange) != 0ull) {
+                if (exchange) swapRays(A, B);
+            }
+            if (!feeder.exhausted) {
+                const uint32_t idx = feeder.take(rayIdle(B) && bits == 0u);
+                if (idx != WaveFeeder::kNone) {
+                    mySlot = idx;
+                    bits = pool.pending[idx] & kFlagPendingMask;
+                }
+            }
+            if (rayIdle(B) && bits != 0u) {
+                const uint32_t rec = static_cast<uint32_t>(__ffs(static_cast<int>(bits))) - 1u;
+                bits &= bits - 1u;
+                const uint32_t recAt = rec * 4u * slots + mySlot;
+                const float4 o4 = recBase[recAt], d4 = recBase[recAt + slots];
+                const uint32_t kind = __float_as_uint(d4.w);
+                if (kind != 2u) {   // kind 2 (MNEE chains) is resolved by k_connect_chain
+                    if (COUNT) { if (kind == 0u) ++rays; else ++raysClosest; }
+                    if (!rayBegin<QUANT>(sc, B, mk3(o4), mk3(d4), kind == 0u ? o4.w : INFINITY, kind == 0u, recAt)) {
+                        if (kind != 0u) recBase[recAt + 2u * slots] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    }
+                }
+            }
+            continue;
+        }
+        if (empty == 128) break;
+        bool stepping;
+        const bool nodeStep = dualVote(A, B, stepping);
+        bool more = true;
+        TraceCounters step{0u, 0u};
+        const bool any = rayAnyHit(A);
+        if (nodeStep) {
+            if (stepping) more = rayNodeStep<QUANT, COUNT>(mem, A, kEps, stack, step);
+        } else {
+            if (stepping) more = rayPrimStep<COUNT>(sc, mem, A, kEps, stack, step);
+        }
+        if (COUNT) {
+            // counting build: nodes/prims of closest-hit (kind 1) rays are booked with the extend counters
+            TraceCounters& dst = any ? cnt : cntClosest;
+            dst.nodes += step.nodes;
+            dst.prims += step.prims;
+        }
+        if (!more) {
+            float4* const a = recBase + A.tag + 2u * slots;
+            if (any) {
+                if (COUNT) early += (A.prim != kHitMiss) ? 1u : 0u;
+                if (A.prim != kHitMiss) *a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            } else {
+                const float4 a4 = *a;
+                const TraceHit h{A.tfar, A.prim};
+                const f3 c = rectContribution(rp, sc, cc, A.org, A.dir, h, mk3(a4), a4.w, mk3(recBase[A.tag + 3u * slots]));
+                *a = mk4(c, 0.0f);
+            }
+        }
+    }
+    if (COUNT) {
+        addCounter(pool.counters, kCntShadowRays, rays);
+        addCounter(pool.counters, kCntShadowNodes, cnt.nodes);
+        addCounter(pool.counters, kCntShadowPrims, cnt.prims);
+        addCounter(pool.counters, kCntShadowEarlyExit, early);
+        addCounter(pool.counters, kCntExtendRays, raysClosest);
+        addCounter(pool.counters, kCntExtendNodes, cntClosest.nodes);
+        addCounter(pool.counters, kCntExtendPrims, cntClosest.prims);
+    }
+}
+
 // MNEE two-bounce chains (record slot 4, kind 2; only launched when enableMnee && enableMneeSecondary).
 template <bool COUNT>
 __global__ void __launch_bounds__(kTraceBlock) k_connect_chain(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride) {
@@ -1232,7 +1469,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect_chain(RenderParams rp, 
     uint32_t rays = 0u, raysClosest = 0u;
     const ClampCfg cc = clampCfg(rp);
     for (uint32_t slot = gtid; slot < pool.slots; slot += gridDim.x * kTraceBlock) {
-        if (!(pool.state[slot].w & (1u << 4))) continue;
+        if (!(pool.pending[slot] & (1u << 4))) continue;
         const ShadowRecordView& r = pool.rec[4];
         const float4 d4 = r.dir[slot];
         if (__float_as_uint(d4.w) != 2u) continue;
@@ -1255,17 +1492,21 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect_chain(RenderParams rp, 
 // k_resolve: fixed-order per-pixel reduction
 // =====================================================================================================
 __global__ void __launch_bounds__(256) k_flush(RenderParams rp, PathPool pool) {
-    // after the last bounce: add the connections still outstanding and publish unfinished/unflushed items
+    // after the last bounce: add the connections still outstanding and publish the items that were waiting for them
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= pool.slots) return;
-    const uint4 st = pool.state[slot];
-    if (!(st.z & kFlagFlush)) return;
-    const float4 acc4 = pool.accum[slot];
-    f3 acc = mk3(acc4);
+    const uint32_t flags = __float_as_uint(pool.ray1[slot].w);
+    if (!(flags & kFlagFlush)) return;
+    const uint32_t pendingIn = (flags >> kFlagPendingShift) & kFlagPendingMask;
+    f3 acc = mk3(pool.accum[slot]);
+    uint32_t sig = pool.signature ? pool.signature[slot] : 0u;
     for (uint32_t k = 0; k < kRecSlots; ++k) {
-        if (st.w & (1u << k)) acc += mk3(pool.rec[k].a[slot]);
+        if (!(pendingIn & (1u << k))) continue;
+        const float4 a = pool.rec[k].a[slot];
+        acc += mk3(a);
+        if (k == 0u && (a.x > 0.0f || a.y > 0.0f || a.z > 0.0f) && static_cast<uint32_t>(a.w) < kSigNeeBits) sig |= 1u << static_cast<uint32_t>(a.w);
     }
-    pool.itemAccum[__float_as_uint(acc4.w)] = mk4(acc, 0.0f);
+    pool.itemAccum[pool.flushItem[slot]] = mk4(acc, __uint_as_float(sig));
     (void)rp;
 }
 
@@ -1273,7 +1514,7 @@ __global__ void __launch_bounds__(256) k_resolve(RenderParams rp, PathPool pool,
     const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
     if (lp >= rp.localPixels) return;
     f3 sum = mk3(0.0f);
-    for (uint32_t c = 0; c < rp.chunkCount; ++c) sum += mk3(pool.itemAccum[static_cast<size_t>(c) * rp.localPixels + lp]);
+    for (uint32_t c = 0; c < rp.spp; ++c) sum += mk3(pool.itemAccum[static_cast<size_t>(c) * rp.localPixels + lp]);
     const uint32_t pixel = pool.pixelOfLocal[lp];
     const uint32_t x = pixel % rp.width, y = pixel / rp.width;
     const uint32_t localBand = (y / PTR_BAND_ROWS) / partCount;
@@ -1309,7 +1550,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_aovs(RenderParams rp, SceneView
         const TraceHit h = traverse<false, false>(sc, org, dir, kEps, INFINITY, stack, cnt);
         float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n = make_float4(0.5f, 0.5f, 0.5f, 0.0f);
         if (h.prim != kHitMiss && sc.materialCount > 0u) {
-            const Surface sf = reconstruct(sc, org, dir, h.t, h.u, h.v, h.prim);
+            const Surface sf = reconstruct(sc, org, dir, h.t, h.prim);
             const Mat mat{sc.materials + static_cast<size_t>(min(sf.material, sc.materialCount - 1u)) * kMaterialVec4};
             f3 sn = sf.hitShadingNormal;
             if (dot(sn, sn) <= 0.0f) sn = sf.normal;
@@ -1340,6 +1581,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace_rays(SceneView sc, const 
         const float4 a = rays[i * 2u], b = rays[i * 2u + 1u];
         const f3 org = mk3(a), dir = mk3(b);
         const TraceHit h = traverse<ANY, true>(sc, org, dir, a.w, b.w, stack, cnt);
+        float hu = 0.0f, hv = 0.0f;
         PtrHit r;
         r.t = -1.0f;
         r.u = 0.0f;
@@ -1352,15 +1594,16 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace_rays(SceneView sc, const 
         if (h.prim != kHitMiss) {
             r.t = ANY ? 0.0f : h.t;
             if (!ANY) {
-                r.u = h.u;
-                r.v = h.v;
                 if (h.prim & kHitSphereBit) {
                     r.primType = 1u;
                     r.primIndex = sc.sphereInfo[h.prim & ~kHitSphereBit].x;
                 } else {
                     const float4* tp = sc.tris + static_cast<size_t>(h.prim) * 3u;
-                    const float4 t1 = tp[1], t2 = tp[2];
+                    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
                     const uint32_t meta = __float_as_uint(t1.w);
+                    triangleUv(mk3(t0), mk3(t1), mk3(t2), org, dir, hu, hv);
+                    r.u = hu;
+                    r.v = hv;
                     const f3 ng = cross(mk3(t2), mk3(t1));
                     r.ng[0] = ng.x;
                     r.ng[1] = ng.y;
@@ -1435,6 +1678,21 @@ void launchGenerate(const RenderParams& rp, const PathPool& pool, hipStream_t st
 }
 
 void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, uint32_t* aliveOut, bool count, hipStream_t stream) {
+    if (cfg.dual) {
+        // two rays per lane: PTR_DUAL_WAVES blocks per CU are resident, each thread owns two spill columns
+        const uint32_t stride = cfg.dualGrid * kTraceBlock * 2u;
+        const uint32_t grid = std::min(cfg.dualGrid, ceilDiv(pool.slots, kTraceBlock));
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters, cfg.dualRefillAt,
+                               cfg.feederChunk, aliveOut);
+        };
+        if (count) {
+            if (sc.useQuantized) launch(k_extend_dual<true, true>); else launch(k_extend_dual<true, false>);
+        } else {
+            if (sc.useQuantized) launch(k_extend_dual<false, true>); else launch(k_extend_dual<false, false>);
+        }
+        return;
+    }
     const uint32_t stride = cfg.traceGrid * kTraceBlock;
     const uint32_t grid = std::min(cfg.traceGrid, ceilDiv(pool.slots, kTraceBlock));
     // the live-slot count is a separate instantiation so the common launch carries no extra register
@@ -1462,12 +1720,26 @@ void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& po
 }
 
 void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count, hipStream_t stream) {
-    const uint32_t stride = cfg.traceGrid * kTraceBlock;
-    if (count) {
-        hipLaunchKernelGGL(k_connect<true>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1, cfg.refillBelow, cfg.feederChunk);
+    if (cfg.dual) {
+        const uint32_t stride = cfg.dualGrid * kTraceBlock * 2u;
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(cfg.dualGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1,
+                               cfg.dualRefillAt, cfg.feederChunk);
+        };
+        if (count) {
+            if (sc.useQuantized) launch(k_connect_dual<true, true>); else launch(k_connect_dual<true, false>);
+        } else {
+            if (sc.useQuantized) launch(k_connect_dual<false, true>); else launch(k_connect_dual<false, false>);
+        }
     } else {
-        hipLaunchKernelGGL(k_connect<false>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1, cfg.refillBelow, cfg.feederChunk);
+        const uint32_t stride = cfg.traceGrid * kTraceBlock;
+        if (count) {
+            hipLaunchKernelGGL(k_connect<true>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1, cfg.refillBelow, cfg.feederChunk);
+        } else {
+            hipLaunchKernelGGL(k_connect<false>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1, cfg.refillBelow, cfg.feederChunk);
+        }
     }
+    const uint32_t stride = cfg.traceGrid * kTraceBlock;
     if (rp.enableMnee && rp.enableMneeSecondary) {
         if (count) {
             hipLaunchKernelGGL(k_connect_chain<true>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride);

@@ -52,6 +52,14 @@ double oracle_render(const OracleScene* s, const PtrSettings* settings, uint32_t
     return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// As oracle_render, plus per-pixel path signatures and "marginal shadow decision" flags (W*H each; see render()).
+double oracle_render_signatures(const OracleScene* s, const PtrSettings* settings, uint32_t spp, uint32_t threads, uint32_t y0,
+                                uint32_t y1, float* out_rgb, uint32_t* out_signature, uint8_t* out_marginal) {
+    const auto t0 = std::chrono::steady_clock::now();
+    render(s->scene, s->desc, *settings, spp, threads, y0, y1, out_rgb, nullptr, out_signature, out_marginal);
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 // rays: n * 8 floats {ox,oy,oz,tmin,dx,dy,dz,tmax}
 void oracle_trace_rays(const OracleScene* s, const float* rays, uint64_t n, int any_hit, int brute_force, PtrHit* out) {
     for (uint64_t i = 0; i < n; ++i) {

@@ -1746,6 +1746,7 @@ bool intersectScene(const Scene& scene, const Ray& ray, HitInfo& out, Counters* 
     uint32_t material = g.materialIndex;
     out.primitiveType = g.type;
     out.primitiveIndex = rh.primId;
+    out.geomIndex = g.type == GeomType::Mesh ? g.meshIndex : 0u;
     out.twoSided = false;
     if (g.type == GeomType::Mesh && !g.indices.empty() && !g.normals.empty()) {
         const uint32_t base = rh.primId * 3u;
@@ -1787,8 +1788,19 @@ bool intersectScene(const Scene& scene, const Ray& ray, HitInfo& out, Counters* 
 // ---------------------------------------------------------------------------------------------
 // render loop                                                                         E:2443-3214
 // ---------------------------------------------------------------------------------------------
+// Path signature of a sample (the HIP counting build computes the same word, csrc/kernels/device_types.h kSig*):
+// bits 0..15: bit d set when the rectangle-light sample taken at path vertex d contributed; bits 16..31: hash chain over the
+// primitives hit, vertex by vertex (a miss included).
+static uint32_t sigHashStep(uint32_t h, uint32_t primType, uint32_t geomIndex, uint32_t primIndex) {
+    uint32_t x = (h * 0x9e3779b1u) ^ (primType * 0x85ebca6bu) ^ (geomIndex * 0xc2b2ae35u) ^ primIndex;
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    return x & 0xFFFFu;
+}
+
 void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& settings, uint32_t spp, uint32_t threads,
-            uint32_t yBegin, uint32_t yEnd, float* outRgb, RenderCounters* outCounters) {
+            uint32_t yBegin, uint32_t yEnd, float* outRgb, RenderCounters* outCounters, uint32_t* outSignature, uint8_t* outMarginal) {
     const uint32_t width = settings.width, height = settings.height;
     const PtrMaterial* materials = desc.materials;
     const uint32_t materialCount = desc.materialCount;
@@ -1842,9 +1854,15 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
     std::atomic<uint64_t> cExtend{0}, cShadow{0}, cNodes{0}, cPrims{0}, cShaded{0}, cTri{0};
     const bool counting = outCounters != nullptr;
 
+    // test knob (PtrSettings.debugShadowSlack): 0 = the reference's shadow-ray length, quirk Q9
+    const float shadowSlack = (settings.debugShadowSlack > 0.0f && settings.debugShadowSlack < 1.0f) ? settings.debugShadowSlack : 0.0f;
+    const bool wantSignature = outSignature != nullptr || outMarginal != nullptr;
+
     auto renderPixel = [&](uint32_t x, uint32_t y, RenderCounters& rc) -> V3 {
         V3 pixelRadiance;
         const uint32_t pixelIndex = y * width + x;
+        uint32_t sig = 0u;        // signature of the pixel's last sample
+        bool marginal = false;    // some rectangle-light shadow test of that sample flips within +-2e-6 (relative) of its ray length
         Counters tc;
         Counters* tcp = counting ? &tc : nullptr;
         auto trace = [&](const Ray& r, HitInfo& h) {
@@ -1861,6 +1879,8 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
             rng.state = Rng::hash(seedBase ^ pixelIndex ^ (s * 0x9e3779b9u));
             Ray ray = generateCameraRay(camera, width, height, x, y, rng);
             V3 throughput(1.0f, 1.0f, 1.0f), radiance;
+            sig = 0u;
+            marginal = false;
             float lastBsdfPdf = 1.0f;
             bool lastScatterWasDelta = true;
             uint32_t specularDepth = 0;
@@ -1874,6 +1894,7 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
             for (uint32_t depth = 0; depth < settings.maxDepth; ++depth) {
                 HitInfo hit;
                 if (!trace(ray, hit)) {
+                    if (wantSignature) sig = (sig & 0xFFFFu) | (sigHashStep(sig >> 16, 7u, 0u, 0u) << 16);
                     const V3 background = evaluateBackground(settings, env, ray.direction);
                     float misWeight = 1.0f;
                     const bool useSpecularMis = (!lastScatterWasDelta) || settings.enableSpecularNee || settings.enableMnee;
@@ -1890,6 +1911,10 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
                 if (counting) {
                     ++rc.shadedHits;
                     if (hit.primitiveType == GeomType::Mesh) ++rc.triangleHits;
+                }
+                if (wantSignature) {
+                    const uint32_t ptype = hit.primitiveType == GeomType::Mesh ? 0u : (hit.primitiveType == GeomType::Spheres ? 1u : 2u);
+                    sig = (sig & 0xFFFFu) | (sigHashStep(sig >> 16, ptype, ptype == 0u ? hit.geomIndex : 0u, hit.primitiveIndex) << 16);
                 }
                 if (media && mediumDepth > 0) {  // Beer-Lambert over the segment inside the innermost medium, M:5869-5876
                     const PtrMaterial& inside = materials[std::min(mediumStack[mediumDepth - 1], materialCount - 1)];
@@ -1942,14 +1967,25 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
                     if (sampleRectLight(rectLights, env, settings, hit, rng, ls)) {
                         const float nDotL = std::max(dot(shadingNormal, ls.direction), 0.0f);
                         if (ls.pdf > 0.0f && nDotL > 0.0f) {
-                            const float shadowMax = std::max(ls.distance - kEpsilon, kEpsilon);
+                            const float shadowMax = std::max(ls.distance * (1.0f - shadowSlack) - kEpsilon, kEpsilon);
+                            if (outMarginal) {
+                                const V3 so = offsetRayOrigin(hit, ls.direction);
+                                if (scene.occluded(so, ls.direction, kEpsilon, shadowMax * (1.0f - 2.0e-6f), false, nullptr) !=
+                                    scene.occluded(so, ls.direction, kEpsilon, shadowMax * (1.0f + 2.0e-6f), false, nullptr)) {
+                                    marginal = true;
+                                }
+                            }
                             if (!occluded(offsetRayOrigin(hit, ls.direction), ls.direction, shadowMax)) {
                                 const BsdfEval be = evaluateBsdf(material, hit.position, shadingNormal, wo, ls.direction, cp);
                                 if (!be.isDelta && be.pdf > 0.0f) {
                                     const float weight = ls.pdf / (ls.pdf + be.pdf);  // unclamped balance heuristic
                                     V3 contribution = (ls.emission * be.value) * nDotL;
                                     contribution *= weight / ls.pdf;
-                                    if (finite3(contribution)) radiance += clampFireflyContribution(throughput, contribution, cp);
+                                    if (finite3(contribution)) {
+                                        const V3 clamped = clampFireflyContribution(throughput, contribution, cp);
+                                        radiance += clamped;
+                                        if (wantSignature && depth < 16u && (clamped.x > 0.0f || clamped.y > 0.0f || clamped.z > 0.0f)) sig |= 1u << depth;
+                                    }
                                 }
                             }
                         }
@@ -2109,6 +2145,8 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
             rc.nodes += tc.nodes;
             rc.prims += tc.prims;
         }
+        if (outSignature) outSignature[pixelIndex] = sig;
+        if (outMarginal) outMarginal[pixelIndex] = marginal ? 1u : 0u;
         return pixelRadiance / static_cast<float>(targetSamples);
     };
 

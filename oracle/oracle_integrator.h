@@ -104,6 +104,7 @@ struct HitInfo {  // :97-107
     bool frontFace = true, twoSided = false;
     GeomType primitiveType = GeomType::Mesh;
     uint32_t primitiveIndex = 0;
+    uint32_t geomIndex = 0;   // mesh index of a mesh hit (path signatures only)
 };
 
 struct RenderCounters {
@@ -124,7 +125,10 @@ BsdfSample sampleBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 in
 bool intersectScene(const Scene& scene, const Ray& ray, HitInfo& out, Counters* counters = nullptr);
 
 // Renders pixels with y in [y0, y1) (full width); out_rgb is the full W*H*3 image, other rows untouched.
+// out_signature / out_marginal (optional, W*H each): path signature of every pixel's last sample and whether one of its
+// rectangle-light shadow tests is decided within rounding noise of the ray length (deterministic-stream diagnostics).
 void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& settings, uint32_t spp,
-            uint32_t threads, uint32_t y0, uint32_t y1, float* out_rgb, RenderCounters* counters);
+            uint32_t threads, uint32_t y0, uint32_t y1, float* out_rgb, RenderCounters* counters,
+            uint32_t* out_signature = nullptr, uint8_t* out_marginal = nullptr);
 
 }  // namespace oracle

@@ -9,6 +9,13 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# Tuning / debugging knobs of the library (csrc/host/hip_backend.cpp reads them at upload and render time).  A value
+# left in the caller's environment (a sweep, an A/B run) must not reach the tests: they pin the library's defaults.
+_KEEP = {"PTR_TEST_VERBOSE"}
+for _name in [k for k in os.environ if k.startswith("PTR_") and k not in _KEEP]:
+    del os.environ[_name]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
 
@@ -20,7 +27,8 @@ def repo_root():
 
 @pytest.fixture(scope="session", autouse=True)
 def _built_artifacts():
-    """Build the HIP library, the CLI and the oracle once per session if they are missing (no GPU needed)."""
+    """Bring the HIP library, the CLI and the oracle up to date once per session (incremental make; no GPU needed), so
+    the tests never run against a stale binary."""
     import __graft_entry__ as entry
 
     entry.ensure_built()

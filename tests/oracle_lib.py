@@ -28,6 +28,8 @@ def lib():
         l.oracle_scene_info.argtypes = [vp, C.POINTER(u64)]
         l.oracle_render.argtypes = [vp, C.POINTER(pt.PtrSettings), u32, u32, u32, u32, fp, C.POINTER(u64)]
         l.oracle_render.restype = C.c_double
+        l.oracle_render_signatures.argtypes = [vp, C.POINTER(pt.PtrSettings), u32, u32, u32, u32, fp, up, C.POINTER(C.c_uint8)]
+        l.oracle_render_signatures.restype = C.c_double
         l.oracle_trace_rays.argtypes = [vp, fp, u64, C.c_int, C.c_int, vp]
         l.oracle_rng_hash.argtypes = [u32]
         l.oracle_rng_hash.restype = u32
@@ -70,6 +72,16 @@ class OracleScene:
         secs = lib().oracle_render(self._h, C.byref(settings), spp, threads, y0, y1, _f(img), counters if count else None)
         keys = ("extendRays", "shadowRays", "nodes", "prims", "shadedHits", "triangleHits")
         return img, secs, dict(zip(keys, [int(c) for c in counters]))
+
+    def render_signatures(self, settings, threads=0):
+        """1 spp image plus, per pixel, the path signature (as the HIP counting build computes it) and whether one of the
+        path's rectangle-light shadow tests flips within +-2e-6 (relative) of the shadow ray's length."""
+        h, w = settings.height, settings.width
+        img = np.zeros((h, w, 3), dtype=np.float32)
+        sig = np.zeros((h, w), dtype=np.uint32)
+        marginal = np.zeros((h, w), dtype=np.uint8)
+        lib().oracle_render_signatures(self._h, C.byref(settings), 1, threads, 0, h, _f(img), _u(sig), marginal.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return img, sig, marginal.astype(bool)
 
     def trace_rays(self, rays, any_hit=False, brute_force=False):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)

@@ -24,6 +24,9 @@ SCENES = os.path.join(ROOT, "scenes")
 
 pytestmark = pytest.mark.gpu
 
+# worker threads of the CPU oracle (test infrastructure): bounded, a GPU box gives one card's share of its host cores
+ORACLE_THREADS = min(32, os.cpu_count() or 1)
+
 
 def _rel(a, b):
     return np.abs(a - b) / (np.abs(b) + 1e-2)
@@ -560,3 +563,107 @@ def test_cli_smoke_script_equivalent(tmp_path):
     r = subprocess.run([pt.CLI_PATH, "--scene", os.path.join(GOLDEN, "smoke.scene"), "--sppTotal=4", "--seed=1337", "--rgbaExr=1", "--output", str(exr)],
                        capture_output=True, text=True)
     assert r.returncode == 0 and exr.stat().st_size == 66925       # the byte count the paper publishes
+
+
+# --------------------------------------------------------------------------- BASELINE configurations at their defining sizes
+def test_config1_cornell_box_at_full_size():
+    # BASELINE configs[0]: scenes/cornell.scene (analytic spheres + rectangles, Lambertian + emissive), 512x512, depth 4,
+    # 64 spp, seed 1337: SURVEY.md section 8(d) protocol on the whole frame (the noise floor on a 128-row strip)
+    host = pt.HostScene.load(os.path.join(SCENES, "cornell.scene"))
+    dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
+    s = host.settings_for(seed=1337)
+    assert (s.width, s.height, s.maxDepth) == (512, 512, 4)
+    info = dev.info()
+    assert info["spheres"] == 2 and info["triangles"] == 12 and info["rect_lights"] == 1
+    img, st = dev.render_image(s, 64, count=True)
+    ref, _, c = osc.render(s, 64, threads=ORACLE_THREADS, count=True)
+    assert st.samples == 512 * 512 * 64 and np.isfinite(img).all() and img.min() >= 0
+    assert abs(st.extendRays - c["extendRays"]) <= 0.002 * c["extendRays"]
+    s2 = s.copy()
+    s2.seed = 1338
+    rows = (192, 320)
+    other, _, _ = osc.render(s2, 64, threads=ORACLE_THREADS, rows=rows)
+    noise = _rmse(ref[rows[0]:rows[1]], other[rows[0]:rows[1]])
+    err = _rmse(img, ref)
+    lum = np.array([0.2126, 0.7152, 0.0722])
+    ratio = float((img @ lum).mean() / (ref @ lum).mean())
+    assert err <= 1.25 * noise and abs(ratio - 1.0) <= 0.005, (err, noise, ratio)
+    assert err < 0.25 * noise                # same sample streams: far below the seed-to-seed noise
+
+
+def test_config5_lucy_standin_at_full_size():
+    # BASELINE configs[4]: scenes/lucy_standin.scene, 28,005,128 + 1,002,528 mesh triangles (BVH > 1 GB: nodes, triangles and
+    # normals do not fit any cache), 3840x2160, depth 12.  Scene facts, 200 k ray queries bit-equal to the oracle's, and the
+    # image protocol on a strip of the full-resolution frame.
+    from scenes.gen_assets import ensure_large_asset
+    for a in ("lucy_standin_28005128.ply", "blob_1002528.ply"):
+        ensure_large_asset(a)
+    host = pt.HostScene.load(os.path.join(SCENES, "lucy_standin.scene"), SCENES)
+    dev = pt.DeviceScene(host.desc, 0, keepalive=host)
+    info = dev.info()
+    assert info["triangles"] == 28005128 + 1002528 + 4 and info["max_depth"] < 48 and info["max_leaf"] <= 4 and info["rect_lights"] == 1
+    assert info["nodes"] * 32 > (1 << 28)                                  # node array alone beyond 256 MiB
+    osc = ol.OracleScene(host)
+    rays = _random_rays(200_000, -400.0, 400.0, 17)
+    rays[:, 1] = np.abs(rays[:, 1]) + 1.0
+    g, stats = dev.trace_rays(rays)
+    o = osc.trace_rays(rays)
+    assert np.array_equal(g["t"], o["t"]) and (o["t"] >= 0).mean() > 0.5
+    hit = o["t"] >= 0
+    same = (g["primType"][hit] == o["primType"][hit]) & (g["primIndex"][hit] == o["primIndex"][hit]) & (g["geomIndex"][hit] == o["geomIndex"][hit])
+    assert same.mean() > 0.999
+    ga, _ = dev.trace_rays(rays, any_hit=True)
+    oa = osc.trace_rays(rays, any_hit=True)
+    assert np.array_equal(ga["t"] >= 0, oa["t"] >= 0)
+    s = host.settings_for(seed=1337)
+    assert (s.width, s.height, s.maxDepth) == (3840, 2160, 12)
+    rows = (1040, 1104)
+    img1, _ = dev.render_image(s, 1)
+    ref1, _, _ = osc.render(s, 1, threads=ORACLE_THREADS, rows=rows)
+    frac = float((_rel(img1[rows[0]:rows[1]], ref1[rows[0]:rows[1]]).max(axis=2) <= 1e-3).mean())
+    assert frac >= 0.99, frac
+    img, st = dev.render_image(s, 8)
+    assert st.samples == 3840 * 2160 * 8 and np.isfinite(img).all()
+    ref, _, _ = osc.render(s, 8, threads=ORACLE_THREADS, rows=rows)
+    s2 = s.copy()
+    s2.seed = 1338
+    other, _, _ = osc.render(s2, 8, threads=ORACLE_THREADS, rows=rows)
+    sl = slice(rows[0], rows[1])
+    noise, err = _rmse(ref[sl], other[sl]), _rmse(img[sl], ref[sl])
+    lum = np.array([0.2126, 0.7152, 0.0722])
+    ratio = float((img[sl] @ lum).mean() / (ref[sl] @ lum).mean())
+    assert err <= 1.25 * noise and abs(ratio - 1.0) <= 0.005, (err, noise, ratio)
+    dev.close()
+    osc.close()
+
+
+def test_ray_queries_against_the_reference_bvh_library():
+    # the HIP traversal against tinybvh 1.6.7 itself (oracle/_ref, built from /root/reference/external/tinybvh by oracle/Makefile):
+    # the library the reference's software path builds its trees with, traversed by the library's own intersector
+    import ref_tinybvh as rt
+    if not rt.available():
+        pytest.skip("oracle/_ref/libref_tinybvh.so not built")
+    host = pt.HostScene.load(os.path.join(SCENES, "cornell_mesh.scene"), SCENES)
+    dev = pt.DeviceScene(host.desc, 0, keepalive=host)
+    tris = rt.mesh_world_triangles(host.desc, 0)
+    ref = rt.RefBvh(tris)
+    rng = np.random.default_rng(21)
+    centre = tris.reshape(-1, 3).mean(axis=0)
+    radius = float(np.linalg.norm(tris.reshape(-1, 3) - centre, axis=1).max())
+    n = 100_000
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    org = centre + radius * d * rng.uniform(1.25, 1.7, size=(n, 1))
+    dirs = (centre + radius * 0.7 * rng.uniform(-1, 1, size=(n, 3))) - org
+    dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True).astype(np.float32)
+    rays = np.concatenate([org.astype(np.float32), np.full((n, 1), 1e-4, np.float32), dirs, np.full((n, 1), np.inf, np.float32)], axis=1)
+    g, _ = dev.trace_rays(rays)
+    rt_t, rt_prim, _ = ref.intersect(rays)
+    mesh_hit = (g["t"] >= 0) & (g["primType"] == 0)
+    assert mesh_hit.mean() > 0.3 and (rt_t[mesh_hit] >= 0).all()
+    rel = np.abs(rt_t[mesh_hit] - g["t"][mesh_hit]) / np.maximum(g["t"][mesh_hit], 1.0)
+    assert rel.max() < 2e-5, rel.max()
+    assert (rt_prim[mesh_hit] == g["primIndex"][mesh_hit]).mean() > 0.999
+    other = ~mesh_hit
+    assert not ((rt_t[other] >= 0) & ((g["t"][other] < 0) | (rt_t[other] < g["t"][other] * (1 - 1e-5)))).any()

@@ -57,10 +57,21 @@ def test_smoke_scene_exr_size_matches_paper(tmp_path):
     data = out.read_bytes()
     assert len(data) == 66925
     assert data[:4] == (20000630).to_bytes(4, "little")
-    # content pin (informational): Apple libm / real Embree produce different low bits
-    assert isinstance(hashlib.sha256(data).hexdigest() == PAPER_SHA256, bool)
     # background pixels are exactly the solid colour of the scene file
     assert np.allclose(img[0, 0], [0.7, 0.8, 1.0])
+
+
+@pytest.mark.xfail(strict=False, reason="parity unpinned: the paper's sha256 was taken on Apple Silicon (Apple libm, real Embree 4.4 SIMD "
+                   "kernels); the oracle restates that code path with glibc libm and a scalar ray caster, so low-order bits differ")
+def test_smoke_scene_exr_sha256_matches_paper(tmp_path):
+    """The reference's one content-level pin (paper/paper.md:183-188).  Kept as a visible expected failure: it shows that
+    the oracle is pinned by structure (byte count, header, exact background) but not by content."""
+    host = pt.HostScene.load(os.path.join(GOLDEN, "smoke.scene"))
+    s = host.settings_for(width=64, height=64, max_depth=4, seed=1337)
+    img, _, _ = ol.OracleScene(host).render(s, 4, threads=1)
+    out = tmp_path / "smoke.ppm"
+    pt.write_image(str(out), img, "exr", rgba_exr=True)
+    assert hashlib.sha256(out.read_bytes()).hexdigest() == PAPER_SHA256
 
 
 def test_render_is_independent_of_thread_count_and_rows():
