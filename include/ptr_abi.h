@@ -175,7 +175,12 @@ typedef struct PtrSettings {
      * (:4598-4948): specular, diffuse and transmission lobes picked by weight (KHR_materials_transmission factor in
      * pbrExtras.z, thickness tint :3295-3306), visible-normal sampling with the G1 pdf, energy compensation on the
      * specular lobe, rough refraction with the Walter et al. Jacobian, delta mirror / delta refraction at roughness
-     * <= 1e-3 (which then also counts as a delta surface, :4570-4586); factors only - textures are not covered. */
+     * <= 1e-3 (which then also counts as a delta surface, :4570-4586); factors only - textures are not covered.
+     * Bit 6 (PTR_METAL_CLAMPS): the Metal kernel's variants of the luminance clamps (shaders/pathtrace.metal:3550-3633; SURVEY.md
+     * Appendix A rows 4-6): the firefly limit is raised to fireflyClampMaxContribution when that is positive (default 1000: far
+     * looser than the Embree backend's max(32 lum(throughput), 4)); clamp_specular_tail is skipped while base and roughness
+     * scale are both zero (the default - the Embree backend then still caps the lobe's luminance at the clamp floor);
+     * clamp_specular_pdf returns 0 for a non-finite or non-positive pdf and the pdf itself while minSpecularPdf <= 0. */
     uint32_t metalSemantics;
     uint32_t sssMode;   /* RenderSettings::SssMode: 0 off, 1 separable, 2 random walk; read only with PTR_METAL_SSS */
     uint32_t sssMaxSteps;   /* RenderSettings::sssMaxSteps (32): closest-hit queries per random walk, at least 1 */
@@ -187,7 +192,8 @@ typedef struct PtrSettings {
     float debugShadowSlack;
 } PtrSettings;
 
-enum { PTR_METAL_MEDIA = 1u, PTR_METAL_THIN = 2u, PTR_METAL_FACE_NORMAL = 4u, PTR_METAL_SPECULAR = 8u, PTR_METAL_SSS = 16u, PTR_METAL_PBR = 32u };
+enum { PTR_METAL_MEDIA = 1u, PTR_METAL_THIN = 2u, PTR_METAL_FACE_NORMAL = 4u, PTR_METAL_SPECULAR = 8u, PTR_METAL_SSS = 16u, PTR_METAL_PBR = 32u,
+       PTR_METAL_CLAMPS = 64u };
 
 typedef struct PtrRenderStats {
     double totalSeconds;                /* integrate phase only (reference: out.totalSeconds) */
@@ -209,6 +215,7 @@ typedef struct PtrRenderStats {
     uint64_t shadedHits;
     uint64_t triangleHits;
     uint64_t shadowEarlyExits;
+    double tailKernelMs;                /* end-of-frame kernels (k_tail_collect + k_tail_run): the last paths, one lane each */
 } PtrRenderStats;
 
 typedef struct PtrHit {                 /* result of ptr_trace_rays */
@@ -239,6 +246,14 @@ int ptr_scene_info(const PtrDeviceScene* scene, uint64_t out[8]);
 /* Render the whole image, result copied to host `out_rgb` (width*height*3, row 0 = top). */
 int ptr_render(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t spp, int verbose,
                float* out_rgb, PtrRenderStats* stats, char* err, size_t err_cap);
+
+/* The same frame on `n_devices` devices of this node (0 = all visible): the scene is prepared once, uploaded to every device,
+ * device k renders the bands b = k (mod n) (see below), the band buffers are handed to device 0 over the fabric and
+ * interleaved there.  Pixel for pixel the image is the one ptr_render produces (every pixel's sample streams and sums are
+ * independent of the partition).  Extends the one call site of the reference, src/main_headless.mm:524-545, which drives one
+ * device.  stats->totalSeconds = the slowest device's integrate + hand-over time. */
+int ptr_render_multi(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t spp, int n_devices, int verbose,
+                     float* out_rgb, PtrRenderStats* stats, char* err, size_t err_cap);
 
 /* Rows per image band, the unit the frame is partitioned in.  8 keeps the largest partition of a 1080-row frame
  * within 0.7 % of the mean for 2/4/8 partitions (16-row bands left 6.7 % at 8) and is one row of the 8x8 pixel
@@ -301,6 +316,11 @@ int ptr_host_write_image(const char* path, const char* format, const float* line
  * src/renderer/ImageWriter.mm:657-684).  sample_counts: width*height floats, or NULL for plain RGBA. */
 int ptr_host_write_exr_multilayer(const char* path, const float* linear_rgb, uint32_t width, uint32_t height,
                                   const float* sample_counts, const char* colorspace, char* err, size_t err_cap);
+/* Beauty image + the first-hit feature buffers of ptr_render_aovs as layers of one scanline EXR (channels R G B, albedo.R/G/B,
+ * normal.X/Y/Z decoded to unit vectors, depth.Z): the inputs the reference gives its denoiser (src/renderer/Accumulation.mm:130,
+ * shaders/pathtrace.metal:9813-9815), written with the layer convention of ImageWriter::WriteEXR_Multilayer (ImageWriter.mm:657-684). */
+int ptr_host_write_exr_aovs(const char* path, const float* linear_rgb, const float* albedo_rgba, const float* normal_rgba,
+                            uint32_t width, uint32_t height, char* err, size_t err_cap);
 int ptr_host_read_pfm(const char* path, float* out_rgb, uint32_t cap_floats, uint32_t* width, uint32_t* height);
 
 const char* ptr_version(void);

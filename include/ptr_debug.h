@@ -31,6 +31,11 @@ int ptr_debug_camera_rays(const PtrSettings* settings, const uint32_t* xys, uint
 int ptr_debug_render_signatures(PtrDeviceScene* scene, const PtrSettings* settings, float* out_rgb, uint32_t* out_signature,
                                 char* err, size_t err_cap);
 
+/* ptr_render_multi on an explicit list of devices; an id may appear more than once, which lets a one-GPU box run the whole
+ * multi-device path (threads, partitions, hand-over, interleave). */
+int ptr_debug_render_multi_on(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t spp, const int* device_ids, int n,
+                              float* out_rgb, PtrRenderStats* stats, char* err, size_t err_cap);
+
 /* Host-side (no GPU): the environment importance tables the device sampler is fed
  * (src/renderer/EnvImportanceSampler.mm:70-171).  Outputs sized by the caller: texel_pdf, cond_alias,
  * cond_threshold: w*h; marg_alias, marg_threshold: h.  Returns non-zero if the map has no positive radiance. */
@@ -42,7 +47,7 @@ int ptr_debug_env_distribution(const float* rgba, uint32_t w, uint32_t h, float*
  * out[0..15]: nodes, leaves, triangles referenced, spheres referenced, max depth, max leaf size, unreferenced
  * primitives, multiply referenced primitives, box containment violations, quantised-box violations, bad child
  * references, triangle count, sphere count, SAH cost * 1000, build milliseconds (gather+build+flatten), quantised
- * nodes usable (grid fine enough).  leaf_max = 0 uses the default.  Returns non-zero with a message on bad input. */
+ * nodes usable (grid fine enough; bits 8..: triangles kept out of the tree so that it is).  leaf_max = 0 uses the default.  Returns non-zero with a message on bad input. */
 int ptr_debug_scene_geometry(const PtrSceneDesc* scene, uint32_t leaf_max, uint64_t out[16], char* err, size_t err_cap);
 
 #ifdef __cplusplus

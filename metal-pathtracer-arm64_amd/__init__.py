@@ -161,6 +161,7 @@ class PtrRenderStats(C.Structure):
         ("shadedHits", C.c_uint64),
         ("triangleHits", C.c_uint64),
         ("shadowEarlyExits", C.c_uint64),
+        ("tailKernelMs", C.c_double),
     ]
 
     def as_dict(self) -> dict:
@@ -193,11 +194,11 @@ ABI_SYMBOLS = (
     "ptr_device_count", "ptr_scene_upload", "ptr_scene_release", "ptr_scene_info", "ptr_render",
     "ptr_render_bands_device", "ptr_part_band_count", "ptr_render_bands", "ptr_trace_rays", "ptr_render_aovs",
     "ptr_host_scene_load", "ptr_host_scene_free", "ptr_host_scene_desc", "ptr_host_write_image", "ptr_host_write_exr_multilayer",
-    "ptr_host_read_pfm", "ptr_version",
+    "ptr_host_read_pfm", "ptr_version", "ptr_render_multi", "ptr_host_write_exr_aovs",
 )
 # include/ptr_debug.h (test-only device-function probes)
 DEBUG_SYMBOLS = ("ptr_debug_eval_bsdf", "ptr_debug_sample_bsdf", "ptr_debug_camera_rays", "ptr_debug_env_distribution",
-                 "ptr_debug_scene_geometry", "ptr_debug_render_signatures")
+                 "ptr_debug_scene_geometry", "ptr_debug_render_signatures", "ptr_debug_render_multi_on")
 
 _lib: Optional[C.CDLL] = None
 
@@ -247,6 +248,10 @@ def load_library() -> C.CDLL:
     lib.ptr_debug_env_distribution.argtypes = [fp, u32, u32, fp, up, fp, up, fp, fp]
     lib.ptr_debug_scene_geometry.argtypes = [C.POINTER(PtrSceneDesc), u32, C.POINTER(u64), cp, sz]
     lib.ptr_debug_render_signatures.argtypes = [vp, C.POINTER(PtrSettings), fp, up, cp, sz]
+    lib.ptr_render_multi.argtypes = [C.POINTER(PtrSceneDesc), C.POINTER(PtrSettings), u32, C.c_int, C.c_int, fp, C.POINTER(PtrRenderStats), cp, sz]
+    lib.ptr_debug_render_multi_on.argtypes = [C.POINTER(PtrSceneDesc), C.POINTER(PtrSettings), u32, C.POINTER(C.c_int), C.c_int, fp,
+                                              C.POINTER(PtrRenderStats), cp, sz]
+    lib.ptr_host_write_exr_aovs.argtypes = [cp, fp, fp, fp, u32, u32, cp, sz]
     _lib = lib
     return lib
 
@@ -419,6 +424,32 @@ class DeviceScene:
             pass
 
 
+def render_multi(desc: PtrSceneDesc, settings: PtrSettings, spp: int, n_devices: int = 0, device_ids=None, verbose: bool = False
+                 ) -> Tuple[np.ndarray, PtrRenderStats]:
+    """The frame spread over several devices of this node (ptr_render_multi): [H, W, 3] float32 + stats.  `device_ids` (tests) names the
+    devices explicitly; an id may repeat, so a one-GPU box can run the whole multi-device path."""
+    lib = load_library()
+    img = np.zeros((settings.height, settings.width, 3), dtype=np.float32)
+    stats = PtrRenderStats()
+    err = _err_buf()
+    if device_ids is not None:
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        _check(lib.ptr_debug_render_multi_on(C.byref(desc), C.byref(settings), spp, ids, len(device_ids), _fptr(img), C.byref(stats), err, len(err)), err)
+    else:
+        _check(lib.ptr_render_multi(C.byref(desc), C.byref(settings), spp, n_devices, int(verbose), _fptr(img), C.byref(stats), err, len(err)), err)
+    return img, stats
+
+
+def write_exr_aovs(path: str, rgb: np.ndarray, albedo: np.ndarray, normal: np.ndarray) -> None:
+    """Beauty + first-hit albedo / normal / depth layers in one EXR (ptr_host_write_exr_aovs)."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    albedo = np.ascontiguousarray(albedo, dtype=np.float32)
+    normal = np.ascontiguousarray(normal, dtype=np.float32)
+    h, w = rgb.shape[0], rgb.shape[1]
+    err = _err_buf()
+    _check(load_library().ptr_host_write_exr_aovs(os.fsencode(path), _fptr(rgb), _fptr(albedo), _fptr(normal), w, h, err, len(err)), err)
+
+
 def assemble_bands(parts_out, width: int, height: int) -> np.ndarray:
     """Interleave per-partition band buffers ([bands*BAND_ROWS, W, 3] each, band b of part p = image band p + b*P)."""
     parts = len(parts_out)
@@ -534,4 +565,7 @@ def debug_scene_geometry(desc: PtrSceneDesc, leaf_max: int = 0) -> dict:
     out = (C.c_uint64 * 16)()
     err = _err_buf()
     _check(load_library().ptr_debug_scene_geometry(C.byref(desc), leaf_max, out, err, len(err)), err)
-    return dict(zip(GEOMETRY_FIELDS, [int(v) for v in out]))
+    g = dict(zip(GEOMETRY_FIELDS, [int(v) for v in out]))
+    g["oversize"] = g["quantized_usable"] >> 8          # triangles kept out of the tree (tested first by every ray)
+    g["quantized_usable"] &= 0xFF
+    return g

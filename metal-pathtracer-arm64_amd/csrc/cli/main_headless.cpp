@@ -46,6 +46,8 @@ struct CliOptions {
     bool enableSoftwareRayTracing = false, enableSoftwareRayTracingSet = false;
     bool enableMnee = false, enableMneeSet = false;
     uint32_t metalSemantics = 0;
+    uint32_t devices = 1;            // --devices: GPUs of this node the frame is spread over (0 = all visible)
+    std::string aovExrPath;          // --aovExr: also write the first-hit feature layers
     uint32_t backendSemantics = 0;   // what --backend / --enableEmbree imply; an explicit --semantics overrides it
     bool semanticsSet = false;
     std::string formatString = "exr";
@@ -54,8 +56,8 @@ struct CliOptions {
     bool verbose = false;
 };
 
-// PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL | PTR_METAL_SPECULAR | PTR_METAL_SSS | PTR_METAL_PBR
-constexpr uint32_t kMetalSemanticsAll = 63u;
+// PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL | PTR_METAL_SPECULAR | PTR_METAL_SSS | PTR_METAL_PBR | PTR_METAL_CLAMPS
+constexpr uint32_t kMetalSemanticsAll = 127u;
 
 void printUsage(const char* exe) {
     std::cout << "Usage: " << exe << " [options]\n\n"
@@ -79,7 +81,8 @@ void printUsage(const char* exe) {
               << "  --semantics=<embree|metal>     Integrator semantics: embree = parity with the reference's Embree backend\n"
               << "                                 (default); metal = plus the Metal kernel's absorbing media, thin-walled glass, ray-facing\n"
               << "                                 glass normals, rough-metal VNDF formulas, subsurface scattering (scene: renderer sss=...),\n"
-              << "                                 three-lobe PBR with transmission\n"
+              << "                                 three-lobe PBR with transmission, the Metal kernel's clamp variants\n"
+              << "  --devices=<int>                GPUs of this node to spread the frame over (default 1, 0 = all visible)\n"
               << "  --assets=<dir>                 Directory for relative mesh/env paths\n\n"
               << "Tonemapping overrides (for LDR outputs):\n"
               << "  --tonemap=<1|2|3|4>           1=Linear, 2=ACES, 3=Reinhard, 4=Hable\n"
@@ -88,6 +91,7 @@ void printUsage(const char* exe) {
               << "  --output=<path>               Output filename\n"
               << "  --format=<exr|pfm|ppm>        Output format (default exr)\n"
               << "  --rgbaExr[=0|1]               Write RGBA EXR with colorspace attribute (Embree-backend layout)\n"
+              << "  --aovExr=<path>               Also write beauty + first-hit albedo / normal / depth layers (denoiser inputs) as one EXR\n"
               << "  --verbose                     Print progress\n"
               << "  --help                        Show this message\n";
 }
@@ -222,6 +226,11 @@ bool parseOptions(int argc, const char** argv, CliOptions& o, std::string& error
         } else if (arg == "--format") {
             if (!need("--format")) return false;
             o.formatString = value;
+        } else if (arg == "--devices") {
+            if (!intArg("--devices", 0, o.devices, nullptr)) return false;
+        } else if (arg == "--aovExr") {
+            if (!need("--aovExr")) return false;
+            o.aovExrPath = value;
         } else if (arg == "--semantics") {
             if (!need("--semantics")) return false;
             if (value == "metal") {
@@ -344,7 +353,11 @@ int main(int argc, const char** argv) {
     camera.defocusAngle = settings.cameraDefocusAngle;
     camera.focusDistance = settings.cameraFocusDistance;
 
-    std::unique_ptr<ptr::IHeadlessRenderer> renderer = std::make_unique<ptr::HipHeadlessRenderer>();
+    auto hipRenderer = std::make_unique<ptr::HipHeadlessRenderer>();
+    hipRenderer->setDeviceCount(static_cast<int>(options.devices));
+    hipRenderer->setCaptureAovs(!options.aovExrPath.empty());
+    const ptr::HipHeadlessRenderer* const hip = hipRenderer.get();
+    std::unique_ptr<ptr::IHeadlessRenderer> renderer = std::move(hipRenderer);
     ptr::HeadlessRenderOutput output;
     std::string renderError;
     if (!renderer->render(scene, camera, settings, options.sppTotal, options.verbose, output, renderError)) {
@@ -386,6 +399,19 @@ int main(int argc, const char** argv) {
     if (!ok) {
         std::cerr << "Failed to write output image: " << writeError << std::endl;
         return 1;
+    }
+    if (!options.aovExrPath.empty()) {
+        const fs::path aovFs(options.aovExrPath);
+        if (!aovFs.parent_path().empty()) {
+            std::error_code ec;
+            fs::create_directories(aovFs.parent_path(), ec);
+        }
+        if (!ptr::WriteExrAovs(options.aovExrPath, output.linearRGB.data(), hip->aovAlbedo().data(), hip->aovNormal().data(), output.width,
+                               output.height, &writeError)) {
+            std::cerr << "Failed to write AOV image: " << writeError << std::endl;
+            return 1;
+        }
+        std::cout << "Feature layers written to: " << aovFs << std::endl;
     }
 
     std::cout << "Rendered " << output.samples << " spp at " << output.width << "x" << output.height << " in "

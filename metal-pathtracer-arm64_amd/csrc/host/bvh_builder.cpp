@@ -286,15 +286,82 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
     const uint32_t n = static_cast<uint32_t>(prims.size());
     if (n == 0) return;
 
+    // ---- oversize primitives ------------------------------------------------------------------------------------------
+    // The 32 B nodes store boxes on ONE 16-bit grid over the bounds of the tree.  A handful of triangles far larger than the
+    // rest (the floor and the light of a room around a finely tessellated statue) stretch that grid until a cell is coarse
+    // next to the small triangles, and the scene falls back to 64 B float nodes - on exactly the scenes whose node array
+    // does not fit any cache.  If taking at most kMaxOversize of the largest triangles out of the tree makes the grid fine
+    // enough (same gate as the device side: cell <= 1/8 of the mean primitive extent), they are kept out: appended after the
+    // leaf-order triangles and tested first by every ray.
+    constexpr uint32_t kMaxOversize = 16u;   // one leaf reference holds up to 16 primitives
+    std::vector<uint8_t> oversize(n, 0);
+    uint32_t oversizeCount = 0;
+    if (n > 64u && std::getenv("PTR_NO_OVERSIZE") == nullptr) {
+        auto extentOf = [&](uint32_t i) { return std::max(std::max(prims[i].hi[0] - prims[i].lo[0], prims[i].hi[1] - prims[i].lo[1]), prims[i].hi[2] - prims[i].lo[2]); };
+        // candidates: the kMaxOversize largest triangles, largest first
+        std::vector<uint32_t> tris;
+        tris.reserve(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!prims[i].isSphere) tris.push_back(i);
+        }
+        const size_t top = std::min<size_t>(kMaxOversize, tris.size());
+        std::partial_sort(tris.begin(), tris.begin() + static_cast<std::ptrdiff_t>(top), tris.end(), [&](uint32_t a, uint32_t b_) {
+            const float ea = extentOf(a), eb = extentOf(b_);
+            return ea > eb || (ea == eb && a < b_);
+        });
+        std::vector<uint8_t> candidate(n, 0);
+        for (size_t k = 0; k < top; ++k) candidate[tris[k]] = 1;
+        // bounds and extent sum of everything that is not a candidate: one pass over the primitives
+        Aabb restBox;
+        restBox.reset();
+        double restSum = 0.0;
+        uint64_t restCount = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (candidate[i]) continue;
+            restBox.grow(prims[i].lo, prims[i].hi);
+            restSum += extentOf(i);
+            ++restCount;
+        }
+        // grid gate with the first k candidates out of the tree (k = 0: the tree as it would be built anyway)
+        auto gridIsFine = [&](size_t k) {
+            Aabb box = restBox;
+            double sum = restSum;
+            uint64_t kept = restCount;
+            for (size_t c = k; c < top; ++c) {
+                box.grow(prims[tris[c]].lo, prims[tris[c]].hi);
+                sum += extentOf(tris[c]);
+                ++kept;
+            }
+            if (kept == 0) return false;
+            double maxCell = 0.0;
+            for (int a = 0; a < 3; ++a) maxCell = std::max(maxCell, (static_cast<double>(box.hi[a]) - box.lo[a]) / 65531.0);
+            return maxCell * 8.0 <= sum / static_cast<double>(kept);
+        };
+        if (!gridIsFine(0)) {
+            for (size_t k = 1; k <= top; ++k) {
+                // only whole groups of equally large triangles (the two halves of a rectangle go together)
+                if (k < top && extentOf(tris[k]) == extentOf(tris[k - 1])) continue;
+                if (gridIsFine(k)) {
+                    for (size_t c = 0; c < k; ++c) oversize[tris[c]] = 1;
+                    oversizeCount = static_cast<uint32_t>(k);
+                    break;
+                }
+            }
+        }
+    }
+
     Builder b(prims);
     b.kLeafMax = std::min(std::max(leafMax, 1u), ptrk::kMaxLeafPrims);
     b.centers.resize(static_cast<size_t>(n) * 3);
     for (uint32_t i = 0; i < n; ++i) {
         for (int a = 0; a < 3; ++a) b.centers[static_cast<size_t>(i) * 3 + a] = 0.5f * (prims[i].lo[a] + prims[i].hi[a]);
     }
-    b.order.resize(n);
-    std::iota(b.order.begin(), b.order.end(), 0u);
-    b.nodes.resize(static_cast<size_t>(2) * n + 1);
+    b.order.reserve(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!oversize[i]) b.order.push_back(i);
+    }
+    const uint32_t inTree = static_cast<uint32_t>(b.order.size());
+    b.nodes.resize(static_cast<size_t>(2) * inTree + 1);
     if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
     b.freeThreads = static_cast<int>(std::min(threads, 32u)) - 1;
     const bool verbose = std::getenv("PTR_BUILD_VERBOSE") != nullptr;
@@ -305,7 +372,7 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
         tick = now;
     };
     lap("setup");
-    b.build(0, 0, n, 0);
+    b.build(0, 0, inTree, 0);
     lap("sah build");
 
     Flattener f{b, out, {}, {}};
@@ -324,6 +391,13 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
     f.run(std::max(static_cast<double>(b.nodes[0].box.halfArea()), 1e-30));
     out.nodes.resize(static_cast<size_t>(out.nodeCount) * 16);
     out.rootRef = 0u;
+    if (oversizeCount > 0) {
+        const uint32_t first = static_cast<uint32_t>(out.triOrder.size());
+        for (uint32_t i = 0; i < n; ++i) {
+            if (oversize[i]) out.triOrder.push_back(f.primToTri[i]);
+        }
+        out.oversizeRef = ptrk::kRefLeafBit | ((oversizeCount - 1u) << ptrk::kRefCountShift) | first;
+    }
     lap("flatten");
 
     // 16-bit grid version of the nodes.  lo is rounded down and hi up, plus one cell of padding on each
@@ -375,10 +449,11 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
         for (auto& th : pool) th.join();
     }
     double extentSum = 0.0;
-    for (const BuildPrim& p : prims) {
-        extentSum += std::max(std::max(p.hi[0] - p.lo[0], p.hi[1] - p.lo[1]), p.hi[2] - p.lo[2]);
+    for (uint32_t i = 0; i < n; ++i) {
+        const BuildPrim& p = prims[i];
+        if (!oversize[i]) extentSum += std::max(std::max(p.hi[0] - p.lo[0], p.hi[1] - p.lo[1]), p.hi[2] - p.lo[2]);
     }
-    out.meanPrimExtent = static_cast<float>(extentSum / n);
+    out.meanPrimExtent = static_cast<float>(extentSum / std::max(inTree, 1u));
     lap("quantise");
 }
 

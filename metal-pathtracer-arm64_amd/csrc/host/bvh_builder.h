@@ -26,10 +26,14 @@ struct FlatBvh {
     std::vector<uint32_t> qnodes;      // 8 words per node: 16-bit grid boxes + child refs (see device_types.h)
     float gridOrigin[3] = {0, 0, 0};
     float gridCell[3] = {1, 1, 1};
-    float meanPrimExtent = 0.0f;       // mean of the primitives' largest box edge (quantisation quality gate)
+    float meanPrimExtent = 0.0f;       // mean of the in-tree primitives' largest box edge (quantisation quality gate)
     std::vector<uint32_t> triOrder;    // leaf-order -> index into the triangle input
     std::vector<uint32_t> sphereOrder; // leaf-order -> index into the sphere input
     uint32_t rootRef = 0xFFFFFFFFu;
+    // Leaf reference of the triangles kept OUT of the tree (kRefEmpty: none): the few primitives so much larger than the rest
+    // that, inside the tree, they would stretch the 16-bit grid of the quantised nodes over mostly empty space (the floor of
+    // a room around a 28 M-triangle statue).  They are the last entries of triOrder and every ray tests them first.
+    uint32_t oversizeRef = 0xFFFFFFFFu;
     uint32_t nodeCount = 0, leafCount = 0, maxDepth = 0, maxLeafSize = 0;
     double sahCost = 0.0;
 };

@@ -140,6 +140,22 @@ int ptr_host_write_exr_multilayer(const char* path, const float* linear_rgb, uin
     });
 }
 
+int ptr_host_write_exr_aovs(const char* path, const float* linear_rgb, const float* albedo_rgba, const float* normal_rgba, uint32_t width,
+                            uint32_t height, char* err, size_t err_cap) {
+    return guarded(err, err_cap, [&]() -> int {
+        if (!path || !linear_rgb || !albedo_rgba || !normal_rgba || width == 0 || height == 0) {
+            setErr(err, err_cap, "ptr_host_write_exr_aovs: bad argument");
+            return 1;
+        }
+        std::string error;
+        if (!ptr::WriteExrAovs(path, linear_rgb, albedo_rgba, normal_rgba, width, height, &error)) {
+            setErr(err, err_cap, error);
+            return 1;
+        }
+        return 0;
+    });
+}
+
 int ptr_host_read_pfm(const char* path, float* out_rgb, uint32_t cap_floats, uint32_t* width, uint32_t* height) {
     FILE* f = std::fopen(path, "rb");
     if (!f) return 1;
@@ -208,7 +224,7 @@ int ptr_debug_scene_geometry(const PtrSceneDesc* scene, uint32_t leaf_max, uint6
                                    c.unreferenced, c.multiplyReferenced, c.boxViolations, c.quantViolations, c.badRefs,
                                    geo.triCount, geo.sphereCount, static_cast<uint64_t>(geo.bvh.sahCost * 1000.0),
                                    static_cast<uint64_t>((geo.gatherSeconds + geo.buildSeconds + geo.flattenSeconds) * 1000.0),
-                                   (geo.bvh.nodeCount > 0 && maxCell * 8.0f <= geo.bvh.meanPrimExtent) ? 1u : 0u};
+                                   ((geo.bvh.nodeCount > 0 && maxCell * 8.0f <= geo.bvh.meanPrimExtent) ? 1u : 0u) | (c.oversize << 8)};
         std::memcpy(out, vals, sizeof(vals));
         return 0;
     });

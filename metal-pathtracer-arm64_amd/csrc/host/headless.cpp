@@ -59,9 +59,44 @@ bool HipHeadlessRenderer::render(const HeadlessScene& scene, const HeadlessCamer
     out.linearRGB.assign(static_cast<size_t>(ps.width) * ps.height * 3u, 0.0f);
     char err[512] = {0};
     m_stats = PtrRenderStats{};
-    if (ptr_render(&desc, &ps, spp, verbose ? 1 : 0, out.linearRGB.data(), &m_stats, err, sizeof(err)) != 0) {
-        error = err[0] ? err : "HIP render failed";
-        return false;
+    m_aovAlbedo.clear();
+    m_aovNormal.clear();
+    if (m_devices != 1) {
+        // the frame in interleaved bands over several devices of the node, gathered on the first one
+        if (ptr_render_multi(&desc, &ps, spp, m_devices, verbose ? 1 : 0, out.linearRGB.data(), &m_stats, err, sizeof(err)) != 0) {
+            error = err[0] ? err : "HIP render failed";
+            return false;
+        }
+    } else if (!m_captureAovs) {
+        if (ptr_render(&desc, &ps, spp, verbose ? 1 : 0, out.linearRGB.data(), &m_stats, err, sizeof(err)) != 0) {
+            error = err[0] ? err : "HIP render failed";
+            return false;
+        }
+    }
+    if (m_captureAovs) {
+        // one upload serves the frame (single device) and the first-hit feature buffers
+        PtrDeviceScene* ds = nullptr;
+        if (ptr_scene_upload(&desc, 0, &ds, err, sizeof(err)) != 0) {
+            error = err[0] ? err : "HIP scene upload failed";
+            return false;
+        }
+        bool ok = true;
+        if (m_devices == 1) {
+            const uint32_t bands = ptr_part_band_count(ps.height, 0, 1);
+            std::vector<float> banded(static_cast<size_t>(bands) * PTR_BAND_ROWS * ps.width * 3u);
+            ok = ptr_render_bands(ds, &ps, spp, 0, 1, banded.data(), 0, &m_stats, err, sizeof(err)) == 0;
+            if (ok) std::copy(banded.begin(), banded.begin() + static_cast<std::ptrdiff_t>(out.linearRGB.size()), out.linearRGB.begin());
+        }
+        if (ok) {
+            m_aovAlbedo.assign(static_cast<size_t>(ps.width) * ps.height * 4u, 0.0f);
+            m_aovNormal.assign(static_cast<size_t>(ps.width) * ps.height * 4u, 0.0f);
+            ok = ptr_render_aovs(ds, &ps, 0u, m_aovAlbedo.data(), m_aovNormal.data(), err, sizeof(err)) == 0;
+        }
+        ptr_scene_release(ds);
+        if (!ok) {
+            error = err[0] ? err : "HIP render failed";
+            return false;
+        }
     }
     out.width = ps.width;
     out.height = ps.height;

@@ -51,9 +51,19 @@ public:
     bool render(const HeadlessScene& scene, const HeadlessCamera& camera, const RenderSettings& settings,
                 uint32_t sppTotal, bool verbose, HeadlessRenderOutput& out, std::string& error) override;
     const PtrRenderStats& lastStats() const { return m_stats; }
+    // devices of this node to spread the frame over (1 = the first device only, 0 = all visible): --devices of the CLI
+    void setDeviceCount(int n) { m_devices = n; }
+    // also keep the first-hit feature buffers of the frame (albedo rgb | hit, shading normal * 0.5 + 0.5 | distance; width*height*4
+    // floats each) - what the reference hands to its denoiser (shaders/pathtrace.metal:6424-6435, 9813-9815): --aovExr of the CLI
+    void setCaptureAovs(bool on) { m_captureAovs = on; }
+    const std::vector<float>& aovAlbedo() const { return m_aovAlbedo; }
+    const std::vector<float>& aovNormal() const { return m_aovNormal; }
 
 private:
     PtrRenderStats m_stats{};
+    int m_devices = 1;
+    bool m_captureAovs = false;
+    std::vector<float> m_aovAlbedo, m_aovNormal;
 };
 
 // RenderSettings -> POD settings of the C-ABI.

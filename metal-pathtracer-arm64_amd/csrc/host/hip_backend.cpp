@@ -16,6 +16,7 @@
 #include <exception>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../kernels/device_types.h"
@@ -124,14 +125,20 @@ struct PtrDeviceScene {
     DeviceBuffer<float4> ray0, ray1, thr, accum, recBuf, itemAccum;
     DeviceBuffer<float2> hit;
     DeviceBuffer<uint8_t> pending;
-    DeviceBuffer<uint32_t> flushItem, signature;
+    DeviceBuffer<uint32_t> flushItem, signature, tailList, tailWords;
+    // end of the frame: once the item queue is dry and at most this many slots are still alive, the remaining paths are finished by
+    // k_tail_run (one lane per path, no launches between bounces) instead of further extend / shade / connect rounds; 0 = never
+    uint64_t tailBelow = 512ull << 10;
     uint64_t poolSlots = 16ull << 20;
     uint32_t poolGroups = 4;   // the pool is split into this many independent groups, one HIP stream each
     uint32_t feederChunk = 256, feederChunkSparse = 0;   // slots per work-head claim: full pool / mostly dead pool (0: slots per resident wave)
     std::vector<hipStream_t> groupStreams;   // streams of groups 1.. (group 0 runs on the caller's stream)
     std::vector<hipEvent_t> groupEvents;
     int refillBelow = 40;
-    bool dualTraversal = true;   // two rays per lane in k_extend / k_connect (kernels/traverse_dual.h); PTR_TRAVERSAL=classic for the one-ray loop
+    // two rays per lane in k_extend / k_connect (kernels/traverse_dual.h).  Off: it fills the node steps better (0.71 of the lanes
+    // against 0.51) but needs 93 VGPRs (5 waves per SIMD instead of 8) and a vote + exchange every step, and measured 0.75x the
+    // frame rate of the one-ray loop (profiles/r2_dual_vs_classic.txt).  PTR_TRAVERSAL=dual selects it for A/B runs.
+    bool dualTraversal = false;
     uint32_t dualGrid = 0;
     int dualRefillAt = 32;
     DeviceBuffer<uint4> medium;
@@ -186,28 +193,34 @@ void compactMaterial(const PtrMaterial& m, std::vector<float>& out) {
     }
 }
 
-void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
-    const auto t0 = std::chrono::steady_clock::now();
+// Device-independent half of a scene upload: geometry bake + BVH, compact materials, light list, environment tables.  Built once
+// and uploaded to every device a frame is rendered on (ptr_render_multi).
+struct PreparedScene {
     ptr::SceneGeometry geo;
+    std::vector<float> mats, lights;
+    std::vector<int32_t> lightIndexByRect;
+    uint32_t lightCount = 0;
+    bool hasRandomWalkMaterial = false;
+    ptr::EnvImportanceDistribution envDist;
+    bool hasEnvDist = false;
+    double seconds = 0.0;
+};
+
+void prepareScene(const PtrSceneDesc& desc, PreparedScene& ps) {
+    const auto t0 = std::chrono::steady_clock::now();
     std::string geoError;
-    if (!ptr::BuildSceneGeometry(desc, 0, geo, geoError)) throw HipError{geoError};
-    const ptr::FlatBvh& bvh = geo.bvh;
-    const uint32_t triCount = geo.triCount;
+    if (!ptr::BuildSceneGeometry(desc, 0, ps.geo, geoError)) throw HipError{geoError};
 
     // compact materials
-    std::vector<float> mats;
-    mats.reserve(static_cast<size_t>(desc.materialCount) * kMaterialVec4 * 4);
-    for (uint32_t i = 0; i < desc.materialCount; ++i) compactMaterial(desc.materials[i], mats);
-    ds.hasRandomWalkMaterial = false;
+    ps.mats.reserve(static_cast<size_t>(desc.materialCount) * kMaterialVec4 * 4);
+    for (uint32_t i = 0; i < desc.materialCount; ++i) compactMaterial(desc.materials[i], ps.mats);
     for (uint32_t i = 0; i < desc.materialCount; ++i) {
         const PtrMaterial& m = desc.materials[i];
-        if (static_cast<uint32_t>(m.typeEta[0]) == PTR_MAT_SUBSURFACE && m.sssParams[1] >= 0.5f) ds.hasRandomWalkMaterial = true;
+        if (static_cast<uint32_t>(m.typeEta[0]) == PTR_MAT_SUBSURFACE && m.sssParams[1] >= 0.5f) ps.hasRandomWalkMaterial = true;
     }
 
     // rectangle lights: DiffuseLight rectangles with non-zero emission (:2484-2522)
-    std::vector<float> lights;
-    std::vector<int32_t> lightIndexByRect(desc.rectCount, -1);
-    uint32_t lightCount = 0;
+    ps.lightIndexByRect.assign(desc.rectCount, -1);
     if (desc.rectCount > 0 && desc.materialCount > 0) {
         for (uint32_t i = 0; i < desc.rectCount; ++i) {
             const PtrRect& r = desc.rects[i];
@@ -218,14 +231,27 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
             const float3 c{r.corner[0], r.corner[1], r.corner[2]}, eu{r.edgeU[0], r.edgeU[1], r.edgeU[2]},
                 ev{r.edgeV[0], r.edgeV[1], r.edgeV[2]};
             const float3 n = ptr::normalize(float3{r.normalAndPlane[0], r.normalAndPlane[1], r.normalAndPlane[2]});
-            put4(lights, c, ptr::length(ptr::cross(eu, ev)));
-            put4(lights, eu, r.materialTwoSided[1] != 0u ? 1.0f : 0.0f);
-            put4(lights, ev, bitsToFloat(i));
-            put4(lights, n, 0.0f);
-            put4(lights, e, 0.0f);
-            lightIndexByRect[i] = static_cast<int32_t>(lightCount++);
+            put4(ps.lights, c, ptr::length(ptr::cross(eu, ev)));
+            put4(ps.lights, eu, r.materialTwoSided[1] != 0u ? 1.0f : 0.0f);
+            put4(ps.lights, ev, bitsToFloat(i));
+            put4(ps.lights, n, 0.0f);
+            put4(ps.lights, e, 0.0f);
+            ps.lightIndexByRect[i] = static_cast<int32_t>(ps.lightCount++);
         }
     }
+    if (desc.envRgba && desc.envWidth > 0 && desc.envHeight > 0) {
+        ps.hasEnvDist = ptr::BuildEnvImportanceDistribution(desc.envRgba, desc.envWidth, desc.envHeight, &ps.envDist);
+    }
+    ps.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceScene& ds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const ptr::SceneGeometry& geo = ps.geo;
+    const ptr::FlatBvh& bvh = geo.bvh;
+    const uint32_t triCount = geo.triCount;
+    const uint32_t lightCount = ps.lightCount;
+    ds.hasRandomWalkMaterial = ps.hasRandomWalkMaterial;
 
     HIP_CHECK(hipSetDevice(ds.device));
     ds.nodes.upload(reinterpret_cast<const float4*>(bvh.nodes.data()), bvh.nodes.size() / 4);
@@ -234,10 +260,10 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     ds.triNormals.upload(reinterpret_cast<const float4*>(geo.triNormals.data()), geo.triNormals.size() / 4);
     ds.spheres.upload(reinterpret_cast<const float4*>(geo.sphereData.data()), geo.sphereData.size() / 4);
     ds.sphereInfo.upload(reinterpret_cast<const uint2*>(geo.sphereInfo.data()), geo.sphereInfo.size() / 2);
-    ds.materials.upload(reinterpret_cast<const float4*>(mats.data()), mats.size() / 4);
+    ds.materials.upload(reinterpret_cast<const float4*>(ps.mats.data()), ps.mats.size() / 4);
     ds.rects.upload(reinterpret_cast<const float4*>(desc.rects), static_cast<size_t>(desc.rectCount) * 5);
-    ds.rectLights.upload(reinterpret_cast<const float4*>(lights.data()), lights.size() / 4);
-    ds.lightIndexByRect.upload(lightIndexByRect.data(), lightIndexByRect.size());
+    ds.rectLights.upload(reinterpret_cast<const float4*>(ps.lights.data()), ps.lights.size() / 4);
+    ds.lightIndexByRect.upload(ps.lightIndexByRect.data(), ps.lightIndexByRect.size());
 
     SceneView& v = ds.view;
     std::memset(&v, 0, sizeof(v));
@@ -265,6 +291,7 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     v.nodeBytes = static_cast<uint32_t>(nodeBytes);
     v.triBytes = static_cast<uint32_t>(triBytes);
     v.rootRef = bvh.rootRef;
+    v.oversizeRef = bvh.oversizeRef;
     v.materialCount = desc.materialCount;
     v.rectCount = desc.rectCount;
     v.rectLightCount = lightCount;
@@ -275,8 +302,8 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
         v.envRgba = ds.envRgba.ptr;
         v.envWidth = desc.envWidth;
         v.envHeight = desc.envHeight;
-        ptr::EnvImportanceDistribution dist;
-        if (ptr::BuildEnvImportanceDistribution(desc.envRgba, desc.envWidth, desc.envHeight, &dist)) {
+        if (ps.hasEnvDist) {
+            const ptr::EnvImportanceDistribution& dist = ps.envDist;
             static_assert(sizeof(ptr::AliasEntry) == sizeof(float2), "alias entry layout");
             ds.envCond.upload(reinterpret_cast<const float2*>(dist.conditional.data()), dist.conditional.size());
             ds.envMarg.upload(reinterpret_cast<const float2*>(dist.marginal.data()), dist.marginal.size());
@@ -311,7 +338,7 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
         if (v >= 1 && v <= 16) ds.traceGrid = cus * static_cast<uint32_t>(v);
     }
     ds.dualGrid = cus * 5u;      // PTR_DUAL_WAVES blocks of 256 threads per CU (kernels/wavefront.hip)
-    if (const char* e = std::getenv("PTR_TRAVERSAL")) ds.dualTraversal = std::string(e) != "classic";   // A/B knob
+    if (const char* e = std::getenv("PTR_TRAVERSAL")) ds.dualTraversal = std::string(e) == "dual";   // A/B knob
     if (const char* e = std::getenv("PTR_DUAL_BLOCKS_PER_CU")) {   // tuning knob
         const int v = std::atoi(e);
         if (v >= 1 && v <= 16) ds.dualGrid = cus * static_cast<uint32_t>(v);
@@ -320,6 +347,7 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 128) ds.dualRefillAt = v;
     }
+    if (const char* e = std::getenv("PTR_TAIL_BELOW")) ds.tailBelow = std::strtoull(e, nullptr, 10);   // tuning knob (0 = off)
     if (const char* e = std::getenv("PTR_POOL_SLOTS")) {   // tuning knob: resident path slots
         const unsigned long long v = std::strtoull(e, nullptr, 10);
         if (v >= 1024) ds.poolSlots = v;
@@ -336,7 +364,13 @@ void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
     ds.zeros.ensure(16);
     HIP_CHECK(hipMemset(ds.zeros.ptr, 0, 16 * sizeof(uint32_t)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ds.pinnedAlive), sizeof(uint32_t) * (kPinnedHeadsOffset + kItemHeads), hipHostMallocDefault));
-    ds.uploadSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ds.uploadSeconds = ps.seconds + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
+    PreparedScene ps;
+    prepareScene(desc, ps);
+    uploadScene(desc, ps, ds);
 }
 
 // Camera basis on the host (BuildCamera, EmbreeHeadlessRenderer.mm:150-198).
@@ -405,7 +439,10 @@ void fillRenderParams(const PtrSettings& s, uint32_t spp, RenderParams& rp) {
     rp.minSpecularPdf = std::max(s.minSpecularPdf, 1.0e-8f);
     rp.clampEnabled = s.fireflyClampEnabled ? 1.0f : 0.0f;
     rp.emissionScale = (s.emissionScale > 0.0f && std::isfinite(s.emissionScale)) ? s.emissionScale : 1.0f;
-    rp.mediaMode = s.metalSemantics & (PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL | PTR_METAL_SPECULAR | PTR_METAL_SSS | PTR_METAL_PBR);
+    rp.mediaMode = s.metalSemantics & (PTR_METAL_MEDIA | PTR_METAL_THIN | PTR_METAL_FACE_NORMAL | PTR_METAL_SPECULAR | PTR_METAL_SSS | PTR_METAL_PBR |
+                                       PTR_METAL_CLAMPS);
+    rp.clampMaxContribution = std::max(s.fireflyClampMaxContribution, 0.0f);   // make_firefly_params, pathtrace.metal:3545
+    rp.minSpecularPdfRaw = s.minSpecularPdf;
     rp.sssMode = s.sssMode;
     rp.sssMaxSteps = std::max(s.sssMaxSteps, 1u);
 }
@@ -511,6 +548,10 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
     ds.pending.ensure(slots);
     ds.flushItem.ensure(slots);
     if (count) ds.signature.ensure(slots);
+    if (ds.tailBelow > 0) {
+        ds.tailList.ensure(slots);
+        ds.tailWords.ensure(4);
+    }
     ds.itemAccum.ensure(rp.itemCount);
     ds.recBuf.ensure(static_cast<size_t>(slots) * kRecSlots * 4u);
     ds.itemReserve.ensure((slots + 63u) / 64u);
@@ -657,9 +698,12 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
     // events without joining was tried: the host then runs up to a dozen empty iterations past the end - no gain.)
     uint64_t kPollEvery = 4;
     if (const char* e = std::getenv("PTR_POLL_EVERY")) kPollEvery = static_cast<uint64_t>(std::min(std::max(std::atoi(e), 1), 64));   // tuning knob
+    uint64_t kPollDry = 2;   // once the queue is dry: how often the live slots are counted (the hand-over to the tail kernels hangs on it)
+    if (const char* e = std::getenv("PTR_POLL_DRY")) kPollDry = static_cast<uint64_t>(std::min(std::max(std::atoi(e), 1), 64));   // tuning knob
     const bool tracePolls = std::getenv("PTR_TRACE_ITERATIONS") != nullptr;   // debugging aid: live slots per poll
     uint64_t nextCheck = kPollEvery;
     bool queueDry = false;
+    bool runTail = false;   // the last paths are handed to the tail kernels
     while (rp.maxDepth > 0) {
         const uint32_t ring = static_cast<uint32_t>(iterations % kAliveRing);
         for (Group& gr : groups) {
@@ -711,6 +755,16 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
                 }
                 allDone = allDone && gr.done;
             }
+            if (queueDry && !allDone && ds.tailBelow > 0) {
+                uint64_t live = 0;
+                for (uint32_t g = 0; g < groupCount; ++g) {
+                    if (!groups[g].done) live += ds.pinnedAlive[g];
+                }
+                if (live <= ds.tailBelow) {
+                    runTail = true;
+                    break;
+                }
+            }
             uint64_t head = slots;   // items claimed so far = pre-assigned + what every range head has handed out
             if (!queueDry) {
                 const uint32_t* heads = ds.pinnedAlive + kPinnedHeadsOffset;
@@ -721,7 +775,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
                 }
             }
             if (allDone) break;
-            nextCheck = iterations + kPollEvery;
+            nextCheck = iterations + (queueDry && ds.tailBelow > 0 ? kPollDry : kPollEvery);
             if (!queueDry) {
                 if (head >= rp.itemCount) {
                     queueDry = true;
@@ -737,6 +791,10 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
     for (uint32_t g = 1; g < groupCount; ++g) {
         HIP_CHECK(hipEventRecord(ds.groupEvents[g], groups[g].stream));
         HIP_CHECK(hipStreamWaitEvent(stream, ds.groupEvents[g], 0));
+    }
+    if (runTail) {
+        HIP_CHECK(hipMemsetAsync(ds.tailWords.ptr, 0, 4 * sizeof(uint32_t), stream));
+        timedLaunch(3, stream, [&] { launchTail(rp, ds.view, pool, groups[0].cfg, ds.tailList.ptr, ds.tailWords.ptr, ds.tailWords.ptr + 1, count, stream); });
     }
     launchResolve(rp, pool, parts, dOut, stream);
     HIP_CHECK(hipGetLastError());
@@ -765,8 +823,10 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
                 ++stats->traceLaunches;
             } else if (s.kind == 1) {
                 stats->shadeKernelMs += ms;
-            } else {
+            } else if (s.kind == 2) {
                 stats->shadowKernelMs += ms;
+            } else {
+                stats->tailKernelMs += ms;
             }
         }
         if (count) {
@@ -838,15 +898,18 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
             sum.traceKernelMs += one.traceKernelMs;
             sum.shadeKernelMs += one.shadeKernelMs;
             sum.shadowKernelMs += one.shadowKernelMs;
+            sum.tailKernelMs += one.tailKernelMs;
             sum.traceLaunches += one.traceLaunches;
             sum.samples += one.samples;
-            const double keepSeconds = sum.totalSeconds, keepTrace = sum.traceKernelMs, keepShade = sum.shadeKernelMs, keepShadow = sum.shadowKernelMs;
+            const double keepSeconds = sum.totalSeconds, keepTrace = sum.traceKernelMs, keepShade = sum.shadeKernelMs, keepShadow = sum.shadowKernelMs,
+                         keepTail = sum.tailKernelMs;
             const uint64_t keepLaunches = sum.traceLaunches, keepSamples = sum.samples;
             sum = one;   // counters are cumulative on the device: the last pass reports the totals
             sum.totalSeconds = keepSeconds;
             sum.traceKernelMs = keepTrace;
             sum.shadeKernelMs = keepShade;
             sum.shadowKernelMs = keepShadow;
+            sum.tailKernelMs = keepTail;
             sum.traceLaunches = keepLaunches;
             sum.samples = keepSamples;
         }
@@ -971,6 +1034,156 @@ int ptr_render(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t 
     }
     ptr_scene_release(ds);
     return rc;
+}
+
+// A frame on several devices: the scene is prepared once on the host, every device gets its own copy (uploads run in
+// parallel, one host thread per device), renders the bands b = rank (mod n) and hands them to the first device over the
+// fabric (hipMemcpyPeerAsync: xGMI between the GPUs of a node), which interleaves them into the image.
+// device_ids may name the same device more than once (how the single-GPU tests exercise the whole path).
+static int renderMulti(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t spp, const int* device_ids, int n, int verbose,
+                       float* out_rgb, PtrRenderStats* stats, char* err, size_t err_cap) {
+    try {
+        if (settings->width == 0 || settings->height == 0) throw HipError{"render size must be non-zero"};
+        const int available = ptr_device_count();
+        if (available < 1) throw HipError{"no HIP device (the HIP path has no CPU fallback)"};
+        for (int i = 0; i < n; ++i) {
+            if (device_ids[i] < 0 || device_ids[i] >= available) throw HipError{"ptr_render_multi: no such HIP device"};
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        PreparedScene prepared;
+        prepareScene(*scene, prepared);
+
+        const uint32_t parts = static_cast<uint32_t>(n);
+        const uint32_t width = settings->width, height = settings->height;
+        const size_t rowFloats = static_cast<size_t>(width) * 3u;
+        std::vector<uint64_t> partOffset(parts + 1u, 0u);
+        for (uint32_t p = 0; p < parts; ++p) {
+            partOffset[p + 1u] = partOffset[p] + static_cast<uint64_t>(ptr_part_band_count(height, p, parts)) * PTR_BAND_ROWS * rowFloats;
+        }
+        const int rootDevice = device_ids[0];
+        DeviceBuffer<float> gathered, image;
+        DeviceBuffer<uint64_t> dOffsets;
+        HIP_CHECK(hipSetDevice(rootDevice));
+        gathered.ensure(partOffset[parts]);
+        image.ensure(rowFloats * height);
+        dOffsets.upload(partOffset.data(), parts);
+
+        std::vector<std::unique_ptr<PtrDeviceScene>> scenes(parts);
+        std::vector<PtrRenderStats> partStats(parts);
+        std::vector<std::string> errors(parts);
+        std::vector<double> uploadSeconds(parts, 0.0), renderSeconds(parts, 0.0);
+        auto worker = [&](uint32_t p) {
+            try {
+                const auto w0 = std::chrono::steady_clock::now();
+                auto ds = std::make_unique<PtrDeviceScene>();
+                ds->device = device_ids[p];
+                uploadScene(*scene, prepared, *ds);
+                uploadSeconds[p] = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+                const size_t floats = static_cast<size_t>(partOffset[p + 1u] - partOffset[p]);
+                HIP_CHECK(hipSetDevice(ds->device));
+                ds->outBands.ensure(floats);
+                hipStream_t stream = nullptr;
+                HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+                const auto r0 = std::chrono::steady_clock::now();
+                renderBands(*ds, *settings, spp, p, parts, ds->outBands.ptr, stream, 0, &partStats[p]);
+                // the partition's bands travel to the first device (device-to-device over the fabric; a plain copy when it is local)
+                if (floats) {
+                    HIP_CHECK(hipMemcpyPeerAsync(gathered.ptr + partOffset[p], rootDevice, ds->outBands.ptr, ds->device, floats * sizeof(float), stream));
+                }
+                HIP_CHECK(hipStreamSynchronize(stream));
+                renderSeconds[p] = std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
+                HIP_CHECK(hipStreamDestroy(stream));
+                scenes[p] = std::move(ds);
+            } catch (const HipError& e) {
+                errors[p] = e.message;
+            } catch (const std::exception& e) {
+                errors[p] = std::string("exception: ") + e.what();
+            } catch (...) {
+                errors[p] = "unknown exception";
+            }
+        };
+        {
+            std::vector<std::thread> threads;
+            for (uint32_t p = 1; p < parts; ++p) threads.emplace_back(worker, p);
+            worker(0u);
+            for (std::thread& t : threads) t.join();
+        }
+        for (uint32_t p = 0; p < parts; ++p) {
+            if (!errors[p].empty()) throw HipError{"device " + std::to_string(device_ids[p]) + ": " + errors[p]};
+        }
+        HIP_CHECK(hipSetDevice(rootDevice));
+        launchInterleaveBands(gathered.ptr, dOffsets.ptr, parts, width, height, image.ptr, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(out_rgb, image.ptr, rowFloats * height * sizeof(float), hipMemcpyDeviceToHost));
+        const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        double slowestRender = 0.0, slowestUpload = 0.0;
+        for (uint32_t p = 0; p < parts; ++p) {
+            slowestRender = std::max(slowestRender, renderSeconds[p]);
+            slowestUpload = std::max(slowestUpload, uploadSeconds[p]);
+        }
+        if (stats) {
+            std::memset(stats, 0, sizeof(*stats));
+            // the integrate phase of the whole job: the slowest device's render + hand-over (devices run concurrently)
+            stats->totalSeconds = slowestRender;
+            stats->avgMsPerSample = slowestRender * 1000.0 / std::max(1u, spp);
+            stats->uploadSeconds = prepared.seconds + slowestUpload;
+            for (uint32_t p = 0; p < parts; ++p) {
+                stats->samples += partStats[p].samples;
+                stats->traceKernelMs += partStats[p].traceKernelMs;
+                stats->shadeKernelMs += partStats[p].shadeKernelMs;
+                stats->shadowKernelMs += partStats[p].shadowKernelMs;
+                stats->traceLaunches += partStats[p].traceLaunches;
+            }
+        }
+        if (verbose) {
+            std::fprintf(stderr, "[ptr] %d device(s): scene preparation %.3f s, slowest upload %.3f s, slowest render + hand-over %.3f s, whole call %.3f s\n", n,
+                         prepared.seconds, slowestUpload, slowestRender, wall);
+            for (uint32_t p = 0; p < parts; ++p) {
+                std::fprintf(stderr, "[ptr]   device %d: %u bands, render %.3f s\n", device_ids[p], ptr_part_band_count(height, p, parts), renderSeconds[p]);
+            }
+        }
+        for (uint32_t p = 0; p < parts; ++p) {
+            if (scenes[p]) {
+                (void)hipSetDevice(scenes[p]->device);
+                scenes[p].reset();
+            }
+        }
+        (void)hipSetDevice(rootDevice);
+        return 0;
+    }
+    PTR_CATCH_ALL(err, err_cap)
+}
+
+int ptr_render_multi(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t spp, int n_devices, int verbose, float* out_rgb,
+                     PtrRenderStats* stats, char* err, size_t err_cap) {
+    if (!scene || !settings || !out_rgb) {
+        setErr(err, err_cap, "ptr_render_multi: null argument");
+        return 1;
+    }
+    const int available = ptr_device_count();
+    if (available < 1) {
+        setErr(err, err_cap, "ptr_render_multi: no HIP device (the HIP path has no CPU fallback)");
+        return 2;
+    }
+    int n = n_devices <= 0 ? available : n_devices;
+    if (n > available) {
+        setErr(err, err_cap, "ptr_render_multi: " + std::to_string(n) + " devices requested, " + std::to_string(available) + " visible");
+        return 2;
+    }
+    // never more partitions than bands
+    n = static_cast<int>(std::min<uint32_t>(static_cast<uint32_t>(n), std::max(1u, (settings->height + PTR_BAND_ROWS - 1u) / PTR_BAND_ROWS)));
+    std::vector<int> ids(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i) ids[static_cast<size_t>(i)] = i;
+    return renderMulti(scene, settings, spp, ids.data(), n, verbose, out_rgb, stats, err, err_cap);
+}
+
+int ptr_debug_render_multi_on(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t spp, const int* device_ids, int n, float* out_rgb,
+                              PtrRenderStats* stats, char* err, size_t err_cap) {
+    if (!scene || !settings || !out_rgb || !device_ids || n < 1) {
+        setErr(err, err_cap, "ptr_debug_render_multi_on: bad argument");
+        return 1;
+    }
+    return renderMulti(scene, settings, spp, device_ids, n, 0, out_rgb, stats, err, err_cap);
 }
 
 int ptr_trace_rays(PtrDeviceScene* scene, const float* rays, uint64_t n, int any_hit, PtrHit* out, PtrRenderStats* stats,

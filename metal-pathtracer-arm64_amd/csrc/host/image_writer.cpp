@@ -429,4 +429,33 @@ bool WriteExrMultilayer(const std::string& path, const float* rgba, uint32_t wid
                             errorMessage);
 }
 
+
+bool WriteExrAovs(const std::string& path, const float* rgb, const float* albedoRgba, const float* normalRgba, uint32_t width, uint32_t height,
+                  std::string* errorMessage) {
+    if (!rgb || !albedoRgba || !normalRgba || width == 0 || height == 0) return fail(errorMessage, "Invalid EXR parameters");
+    const size_t n = static_cast<size_t>(width) * height;
+    // planes: beauty R G B, albedo R G B, normal X Y Z (decoded from the 0.5 + 0.5 n encoding), depth
+    std::vector<float> planes(n * 10u);
+    float* p[10];
+    for (int k = 0; k < 10; ++k) p[k] = planes.data() + static_cast<size_t>(k) * n;
+    for (size_t i = 0; i < n; ++i) {
+        p[0][i] = rgb[i * 3 + 0];
+        p[1][i] = rgb[i * 3 + 1];
+        p[2][i] = rgb[i * 3 + 2];
+        p[3][i] = albedoRgba[i * 4 + 0];
+        p[4][i] = albedoRgba[i * 4 + 1];
+        p[5][i] = albedoRgba[i * 4 + 2];
+        const bool hit = albedoRgba[i * 4 + 3] > 0.5f;
+        p[6][i] = hit ? normalRgba[i * 4 + 0] * 2.0f - 1.0f : 0.0f;
+        p[7][i] = hit ? normalRgba[i * 4 + 1] * 2.0f - 1.0f : 0.0f;
+        p[8][i] = hit ? normalRgba[i * 4 + 2] * 2.0f - 1.0f : 0.0f;
+        p[9][i] = normalRgba[i * 4 + 3];
+    }
+    // channel list in the alphabetical order the OpenEXR format asks for
+    return writeScanlineExr(path, rgb, 3, width, height,
+                            {{"B", 0, p[2]}, {"G", 0, p[1]}, {"R", 0, p[0]}, {"albedo.B", 0, p[5]}, {"albedo.G", 0, p[4]}, {"albedo.R", 0, p[3]},
+                             {"depth.Z", 0, p[9]}, {"normal.X", 0, p[6]}, {"normal.Y", 0, p[7]}, {"normal.Z", 0, p[8]}},
+                            "Linear sRGB", errorMessage);
+}
+
 }  // namespace ptr

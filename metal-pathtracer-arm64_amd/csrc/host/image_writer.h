@@ -32,6 +32,11 @@ bool WriteExrRgba(const std::string& path, const float* rgba, uint32_t width, ui
 bool WriteExrMultilayer(const std::string& path, const float* rgba, uint32_t width, uint32_t height, const float* sampleCount,
                         const char* colorspace, std::string* errorMessage = nullptr);
 
+// Beauty + denoiser feature layers in one scanline EXR: R G B, albedo.R/G/B, normal.X/Y/Z (unit vectors, 0 on a miss), depth.Z
+// (hit distance, 0 on a miss).  albedoRgba / normalRgba: the buffers of ptr_render_aovs (width*height*4 floats each).
+bool WriteExrAovs(const std::string& path, const float* rgb, const float* albedoRgba, const float* normalRgba, uint32_t width, uint32_t height,
+                  std::string* errorMessage = nullptr);
+
 // 8-bit tonemapped RGB (shared by PPM writer and tests).
 void TonemapToLdr(const float* linearRGB, uint32_t pixelCount, const TonemapSettings& tonemap, uint8_t* outRgb8);
 

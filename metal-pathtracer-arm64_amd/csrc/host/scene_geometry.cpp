@@ -350,6 +350,13 @@ void ValidateSceneGeometry(const SceneGeometry& g, GeometryCheck& out) {
             }
         }
     }
+    if (bvh.oversizeRef != ptrk::kRefEmpty) {
+        // the triangles kept out of the tree: one leaf reference, tested by every ray before the walk
+        Box b{{inf, inf, inf}, {-inf, -inf, -inf}};
+        if (!(bvh.oversizeRef & ptrk::kRefLeafBit) || (bvh.oversizeRef & ptrk::kRefSphereBit)) out.badRefs += 1;
+        leafBounds(bvh.oversizeRef, b);
+        out.oversize = ((bvh.oversizeRef >> ptrk::kRefCountShift) & 0xFu) + 1u;
+    }
     for (uint8_t s : triSeen) out.unreferenced += (s == 0);
     for (uint8_t s : sphSeen) out.unreferenced += (s == 0);
 }

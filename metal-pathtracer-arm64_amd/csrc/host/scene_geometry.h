@@ -37,6 +37,7 @@ struct GeometryCheck {
     uint64_t boxViolations = 0;       // primitives sticking out of an ancestor's child box (float nodes)
     uint64_t quantViolations = 0;     // float child boxes sticking out of their quantised twin
     uint64_t badRefs = 0;             // child references pointing outside the arrays / cycles
+    uint64_t oversize = 0;            // triangles kept out of the tree (FlatBvh::oversizeRef)
 };
 
 // Walks the flattened tree from the root and checks the invariants the device traversal relies on.

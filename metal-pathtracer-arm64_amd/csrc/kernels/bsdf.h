@@ -19,6 +19,9 @@ struct ClampCfg {
     bool metalSss;          // PTR_METAL_SSS: type 5 evaluates to zero (no NEE); separable diffusion sampling when sssMode == 1
     uint32_t sssMode;
     bool metalPbr;          // PTR_METAL_PBR: three-lobe metallic-roughness model of the Metal integrator (compiled with SSS = true)
+    bool metalClamps;       // PTR_METAL_CLAMPS: the Metal kernel's variants of the three clamps below (pathtrace.metal:3550-3633)
+    float maxContribution;  // fireflyClampMaxContribution (>= 0), read only with metalClamps
+    float minSpecPdfRaw;    // minSpecularPdf as given (the Embree variant floors it at 1e-8), read only with metalClamps
 };
 
 __device__ __forceinline__ uint32_t rngHash(uint32_t x) {  // lowbias32
@@ -56,7 +59,8 @@ __device__ __forceinline__ f3 clampFirefly(f3 throughput, f3 contribution, const
     f3 positive = vmax0(combined);
     if (!c.enabled) return positive;
     const float lum = luminance(positive);
-    const float maxLum = smax(luminance(vmax0(throughput)) * c.factor, c.floorLum);
+    float maxLum = smax(luminance(vmax0(throughput)) * c.factor, c.floorLum);
+    if (c.metalClamps && c.maxContribution > 0.0f) maxLum = smax(maxLum, c.maxContribution);   // pathtrace.metal:3563-3568
     if (lum > maxLum && lum > 0.0f) {
         combined *= maxLum / smax(lum, 1.0e-6f);
         positive = vmax0(combined);
@@ -65,6 +69,10 @@ __device__ __forceinline__ f3 clampFirefly(f3 throughput, f3 contribution, const
 }
 
 __device__ __forceinline__ float clampSpecPdf(float pdf, const ClampCfg& c) {
+    if (c.metalClamps) {   // pathtrace.metal:3579-3590
+        if (!isfinite(pdf) || pdf <= 0.0f) return 0.0f;
+        return c.minSpecPdfRaw <= 0.0f ? pdf : smax(pdf, c.minSpecPdfRaw);
+    }
     const float minPdf = smax(c.minSpecPdf, 1.0e-8f);
     return isfinite(pdf) ? smax(pdf, minPdf) : minPdf;
 }
@@ -81,6 +89,7 @@ __device__ __forceinline__ f3 clampSpecTail(f3 value, float roughness, f3 f0, co
     if (!finite3(value)) return mk3(0.0f);
     f3 positive = vmax0(value);
     if (!c.enabled) return positive;
+    if (c.metalClamps && c.tailBase <= 0.0f && c.tailRoughScale <= 0.0f) return positive;   // pathtrace.metal:3619-3621
     const float strength = smax(smax(f0.x, f0.y), smax(f0.z, 1.0e-3f));
     const float limit = smax((c.tailBase + c.tailRoughScale * roughness) * strength, c.floorLum);
     const float lum = luminance(positive);

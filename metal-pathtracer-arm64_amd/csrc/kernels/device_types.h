@@ -48,7 +48,7 @@ struct SceneView {
     uint32_t envSampling;          // distribution present
     uint32_t nodeBytes;            // size of the node array in use (qnodes or nodes): buffer-descriptor range
     uint32_t triBytes;             // size of the triangle array
-    uint32_t pad;
+    uint32_t oversizeRef;          // leaf reference of the triangles kept out of the tree (kRefEmpty: none): every ray tests them first
 };
 
 // Compact material record: the MaterialData fields the Embree-semantics integrator reads.
@@ -100,6 +100,7 @@ struct RenderParams {
     // FireflyClampParams
     float clampFactor, clampFloor, throughputClamp, tailClampBase, tailClampRoughnessScale, minSpecularPdf, clampEnabled;
     float emissionScale;
+    float clampMaxContribution, minSpecularPdfRaw;   // PTR_METAL_CLAMPS only
     float shadowSlack;             // test knob (PtrSettings.debugShadowSlack): 0 = the reference's shadow-ray length (quirk Q9)
 };
 

@@ -34,9 +34,17 @@ void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& po
                  hipStream_t stream);
 void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count,
                    hipStream_t stream);
+// End of the frame: every busy slot of `pool` (the WHOLE pool) is run to the end of its path by one lane (k_tail_collect + k_tail_run).
+// dList: pool.slots words; dListCount / dListHead: single words, zero on entry.
+void launchTail(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, uint32_t* dList, uint32_t* dListCount,
+                uint32_t* dListHead, bool count, hipStream_t stream);
 // Adds outstanding light connections, reduces the slots of each pixel in fixed order and writes
 // out[((localBand*PTR_BAND_ROWS + row) * width + x) * 3 + c] = sum / spp.
 void launchResolve(const RenderParams& rp, const PathPool& pool, uint32_t partCount, float* dOut, hipStream_t stream);
+
+// Multi-device gather: writes image[y][x][c] from the partitions' band buffers laid end to end (dPartOffset: float offsets).
+void launchInterleaveBands(const float* dGathered, const uint64_t* dPartOffset, uint32_t parts, uint32_t width, uint32_t height, float* dImage,
+                           hipStream_t stream);
 
 void launchTraceRays(const SceneView& sc, const float4* dRays, uint64_t n, bool anyHit, PtrHit* dOut, const LaunchConfig& cfg,
                      uint64_t* dCounters, hipStream_t stream);

@@ -206,6 +206,12 @@ __device__ __forceinline__ bool travBegin(const SceneView& sc, Trav& t, f3 org, 
     t.cur = sc.rootRef;
     t.leafPos = 0u;
     stack.sp = 0;
+    if (sc.oversizeRef != kRefEmpty) {
+        // the few triangles kept out of the tree (bvh_builder.cpp) come first: their hits shorten the ray before the walk
+        if (sc.rootRef != kRefEmpty) stack.push(sc.rootRef);
+        t.cur = sc.oversizeRef;
+        return true;
+    }
     return sc.rootRef != kRefEmpty;
 }
 

@@ -84,7 +84,7 @@ struct DualStack {
 
 // Start a ray in register set `r` (its stack column is kept).  Returns false when the scene is empty.
 template <bool QUANT>
-__device__ __forceinline__ bool rayBegin(const SceneView& sc, RayRegs& r, f3 org, f3 dir, float tfar, bool anyHit, uint32_t tag) {
+__device__ __forceinline__ bool rayBegin(const SceneView& sc, RayRegs& r, f3 org, f3 dir, float tfar, bool anyHit, uint32_t tag, const DualStack& stack) {
     r.org = org;
     r.dir = dir;
     constexpr float kInvMax = 1.0e28f;   // see travBegin (traverse.h): a finite reciprocal keeps the fma slab test free of NaNs
@@ -105,6 +105,12 @@ __device__ __forceinline__ bool rayBegin(const SceneView& sc, RayRegs& r, f3 org
     r.tag = tag;
     r.column = (r.column & 1u) | (anyHit ? 2u : 0u);
     r.cur = sc.rootRef;   // kRefEmpty == kRayIdle: an empty scene leaves the set idle
+    if (sc.oversizeRef != kRefEmpty) {
+        // triangles kept out of the tree first (see travBegin)
+        if (sc.rootRef != kRefEmpty) stack.push(r, sc.rootRef);
+        r.cur = sc.oversizeRef;
+        return true;
+    }
     return sc.rootRef != kRefEmpty;
 }
 

@@ -51,6 +51,9 @@ __device__ __forceinline__ ClampCfg clampCfg(const RenderParams& rp) {
     c.metalSss = (rp.mediaMode & PTR_METAL_SSS) != 0u;
     c.sssMode = rp.sssMode;
     c.metalPbr = (rp.mediaMode & PTR_METAL_PBR) != 0u;
+    c.metalClamps = (rp.mediaMode & PTR_METAL_CLAMPS) != 0u;
+    c.maxContribution = rp.clampMaxContribution;
+    c.minSpecPdfRaw = rp.minSpecularPdfRaw;
     return c;
 }
 
@@ -579,7 +582,7 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_DUAL_ATTR k_extend_dual(Scene
             aliveSeen += static_cast<uint32_t>(__popcll(__ballot(live)));   // wave-uniform: stays in an SGPR
             if (live) {
                 if (COUNT) ++rays;
-                if (!rayBegin<QUANT>(sc, B, mk3(r0), mk3(r0.w, r1.x, r1.y), INFINITY, false, idx)) {
+                if (!rayBegin<QUANT>(sc, B, mk3(r0), mk3(r0.w, r1.x, r1.y), INFINITY, false, idx, stack)) {
                     pool.hit[idx] = make_float2(INFINITY, __uint_as_float(kHitMiss));
                 }
             }
@@ -648,23 +651,22 @@ __device__ __forceinline__ uint4 mediumWithEntry(uint4 ms, uint32_t i, uint32_t 
 // (the instantiation with the Metal-only subsurface / PBR models needs more registers: 4 waves)
 #define PTR_SHADE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SSS ? 4 : PTR_SHADE_WAVES, SSS ? 4 : PTR_SHADE_WAVES)))
 // SSS: the instantiation with the Metal subsurface semantics (launched when PTR_METAL_SSS is set)
-template <bool COUNT, bool SSS>
-__global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(RenderParams rp, SceneView sc, PathPool pool, ShadeResets resets) {
-    const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x;
-    if (slot == 0u) {
-        // k_shade runs between this iteration's k_extend and k_connect: it clears the work heads they will claim from
-        // next (and the live-slot counter of the next k_extend), which saves two fill dispatches per iteration
-        if (resets.extendHead) *resets.extendHead = 0u;
-        if (resets.connectHead) *resets.connectHead = 0u;
-        if (resets.nextAlive) *resets.nextAlive = 0u;
-    }
-    const bool inRange = slot < pool.slots;
+struct ShadeCounts {
+    uint32_t shadedHit = 0u, triHit = 0u, primary = 0u;   // counting build
+};
+
+// One visit of a path slot: what k_shade does for its thread's slot.  TAIL: the caller is the end-of-frame kernel (k_tail_run),
+// whose lanes hold arbitrary slots and diverge - nothing in here may then rely on the wave (no ballots, no wave-level
+// reservations of work items).
+template <bool COUNT, bool SSS, bool TAIL>
+__device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const uint32_t slot, const bool inRange,
+                                          const bool drained, ShadeCounts& counts) {
     // Everything that depends only on the slot index is requested up front, and the record loads are pointed at a
     // zero word when the record is not pending, so the kernel has ~11 loads in flight per lane after ONE dependent
     // step (the state word) instead of walking a chain of ten load-wait pairs at 5 waves per SIMD.
     const uint32_t at = inRange ? slot : 0u;
     float4 ray1v = pool.ray1[at];
-    if (resets.drained) {
+    if (!TAIL && drained) {
         // end of the frame: most waves cover 64 dead slots, and the loads below would still stream 56 B per slot
         const uint32_t peek = __float_as_uint(ray1v.w);
         const bool busy = inRange && (peek & (kFlagAlive | kFlagFlush | (kFlagPendingMask << kFlagPendingShift))) != 0u;
@@ -1075,6 +1077,22 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
     }
 
     // ---- claim new work items ----
+    if (TAIL) {
+        // end of the frame: the range heads are dry; what can be left is the unused part of the last reservation of this slot's
+        // 64-slot group (csrc/host/hip_backend.cpp hands a group to the tail kernel only after the heads ran dry)
+        if (needItem) {
+            uint2* const res = pool.itemReserve + slot / 64u;
+            const uint32_t end = res->y;
+            if (res->x < end) {
+                const uint32_t got = atomicAdd(&res->x, 1u);
+                if (got < end && got < rp.itemCount) {
+                    item = got;
+                    beginSample(rp, pool.pixelOfLocal[got % rp.localPixels], got / rp.localPixels, rng, nextO, nextD);
+                    stillAlive = true;
+                }
+            }
+        }
+    } else {
     // Each wave holds a reservation of kItemReserve consecutive items in HBM and refills it with ONE atomic on one of
     // kItemHeads range heads (a per-lane or even per-wave-per-bounce atomic on one address caps at ~88 ops/us
     // chip-wide; so does one shared head once items are single samples).
@@ -1136,6 +1154,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
             }
         }
     }
+    }
 
     // light connections of this bounce: k_connect walks the slots and reads the pending mask
     uint32_t pendingMask = 0u;
@@ -1158,9 +1177,28 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
     }
 
     if (COUNT) {
-        addCounter(pool.counters, kCntShadedHits, shadedHit);
-        addCounter(pool.counters, kCntTriangleHits, triHit);
-        addCounter(pool.counters, kCntPrimaryRays, primary);
+        counts.shadedHit += shadedHit;
+        counts.triHit += triHit;
+        counts.primary += primary;
+    }
+}
+
+template <bool COUNT, bool SSS>
+__global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(RenderParams rp, SceneView sc, PathPool pool, ShadeResets resets) {
+    const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x;
+    if (slot == 0u) {
+        // k_shade runs between this iteration's k_extend and k_connect: it clears the work heads they will claim from
+        // next (and the live-slot counter of the next k_extend), which saves two fill dispatches per iteration
+        if (resets.extendHead) *resets.extendHead = 0u;
+        if (resets.connectHead) *resets.connectHead = 0u;
+        if (resets.nextAlive) *resets.nextAlive = 0u;
+    }
+    ShadeCounts counts;
+    shadeSlot<COUNT, SSS, false>(rp, sc, pool, slot, slot < pool.slots, resets.drained != 0u, counts);
+    if (COUNT) {
+        addCounter(pool.counters, kCntShadedHits, counts.shadedHit);
+        addCounter(pool.counters, kCntTriangleHits, counts.triHit);
+        addCounter(pool.counters, kCntPrimaryRays, counts.primary);
     }
 }
 
@@ -1407,7 +1445,7 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_DUAL_ATTR k_connect_dual(Rend
                 const uint32_t kind = __float_as_uint(d4.w);
                 if (kind != 2u) {   // kind 2 (MNEE chains) is resolved by k_connect_chain
                     if (COUNT) { if (kind == 0u) ++rays; else ++raysClosest; }
-                    if (!rayBegin<QUANT>(sc, B, mk3(o4), mk3(d4), kind == 0u ? o4.w : INFINITY, kind == 0u, recAt)) {
+                    if (!rayBegin<QUANT>(sc, B, mk3(o4), mk3(d4), kind == 0u ? o4.w : INFINITY, kind == 0u, recAt, stack)) {
                         if (kind != 0u) recBase[recAt + 2u * slots] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     }
                 }
@@ -1489,6 +1527,135 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect_chain(RenderParams rp, 
 }
 
 // =====================================================================================================
+// End of the frame.  Once the item queue is dry every slot still finishes its path, at falling occupancy: a dozen
+// extend / shade / connect rounds over a pool that is mostly dead, each paying its launches, its scan of dead slots and the
+// latency of its longest ray (about 10 ms per frame in round 1, whatever the frame size).  When few slots are left the host
+// hands them to these two kernels instead: k_tail_collect compacts the indices of the busy slots into a list (one atomic per
+// wave), and k_tail_run gives every lane ONE slot and runs it to the end of its path - closest hit, shade, light
+// connections, next bounce - through the same device functions as the three wavefront kernels, with no launch in between.
+// Lanes diverge completely; with a few hundred thousand paths left that costs less than the launches did.
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_tail_collect(PathPool pool, uint32_t* list, uint32_t* listCount) {
+    __shared__ uint32_t found[4][64];
+    const uint32_t wave = threadIdx.x >> 6, lane = laneId();
+    const uint32_t wavesTotal = gridDim.x * 4u;
+    const uint32_t waveId = blockIdx.x * 4u + wave;
+    // each wave scans a contiguous range of slots, 64 at a time, and appends the busy ones to the list in batches of up to 64
+    const uint32_t perWave = ((pool.slots + wavesTotal - 1u) / wavesTotal + 63u) & ~63u;
+    const uint32_t begin = waveId * perWave, end = min(begin + perWave, pool.slots);
+    uint32_t have = 0u;
+    auto flush = [&]() {
+        uint32_t base = 0u;
+        if (lane == 0u) base = atomicAdd(listCount, have);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane < have) list[base + lane] = found[wave][lane];
+        have = 0u;
+    };
+    for (uint32_t first = begin; first < end; first += 64u) {
+        const uint32_t slot = first + lane;
+        bool busy = false;
+        if (slot < end) {
+            const uint32_t flags = __float_as_uint(pool.ray1[slot].w);
+            busy = (flags & (kFlagAlive | kFlagFlush | (kFlagPendingMask << kFlagPendingShift))) != 0u;
+        }
+        const unsigned long long mask = __ballot(busy);
+        const uint32_t n = static_cast<uint32_t>(__popcll(mask));
+        if (n == 0u) continue;
+        if (have + n > 64u) flush();
+        const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+        if (busy) found[wave][have + rank] = slot;
+        have += n;
+    }
+    if (have) flush();
+}
+
+template <bool COUNT, bool SSS>
+__global__ void __launch_bounds__(kTraceBlock) k_tail_run(RenderParams rp, SceneView sc, PathPool pool, const uint32_t* list, const uint32_t* listCount,
+                                                          uint32_t* listHead, uint32_t* spill, uint32_t spillStride) {
+    __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
+    LaneStack stack;
+    stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
+    stack.spill = spill;
+    stack.spillStride = spillStride;
+    stack.sp = 0u;
+    const ClampCfg cc = clampCfg(rp);
+    TraceCounters cntExtend{0u, 0u}, cntAny{0u, 0u}, cntClosest{0u, 0u};
+    uint32_t raysExtend = 0u, raysAny = 0u, raysClosest = 0u, early = 0u;
+    ShadeCounts counts;
+    const uint32_t total = *listCount;
+    float4* const recBase = pool.rec[0].org;
+    const uint32_t slots = pool.recStride;
+    // a path never needs more visits than this (depth limit, plus the visit that publishes the item; random walks add their steps)
+    const uint32_t visitLimit = (rp.maxDepth + 2u) * (1u + (SSS ? rp.sssMaxSteps : 0u)) + 2u;
+    while (true) {
+        uint32_t base = 0u;
+        if (laneId() == 0u) base = atomicAdd(listHead, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= total) break;
+        const uint32_t index = base + laneId();
+        if (index < total) {
+            const uint32_t slot = list[index];
+            for (uint32_t visit = 0u; visit < visitLimit; ++visit) {
+                const float4 r1 = pool.ray1[slot];
+                const uint32_t flags = __float_as_uint(r1.w);
+                if ((flags & (kFlagAlive | kFlagFlush | (kFlagPendingMask << kFlagPendingShift))) == 0u) break;
+                if (flags & kFlagAlive) {
+                    // k_extend's part
+                    const float4 r0 = pool.ray0[slot];
+                    if (COUNT) ++raysExtend;
+                    const TraceHit h = traverse<false, COUNT>(sc, mk3(r0), mk3(r0.w, r1.x, r1.y), kEps, INFINITY, stack, cntExtend);
+                    pool.hit[slot] = make_float2(h.t, __uint_as_float(h.prim));
+                    __threadfence();
+                }
+                // k_shade's part
+                shadeSlot<COUNT, SSS, true>(rp, sc, pool, slot, true, false, counts);
+                __threadfence();
+                // k_connect's part: the records this visit queued
+                uint32_t bits = pool.pending[slot] & kFlagPendingMask;
+                while (bits != 0u) {
+                    const uint32_t rec = static_cast<uint32_t>(__ffs(static_cast<int>(bits))) - 1u;
+                    bits &= bits - 1u;
+                    const uint32_t recAt = rec * 4u * slots + slot;
+                    const float4 o4 = recBase[recAt], d4 = recBase[recAt + slots];
+                    float4* const a = recBase + recAt + 2u * slots;
+                    const uint32_t kind = __float_as_uint(d4.w);
+                    if (kind == 0u) {
+                        if (COUNT) ++raysAny;
+                        const TraceHit h = traverse<true, COUNT>(sc, mk3(o4), mk3(d4), kEps, o4.w, stack, cntAny);
+                        if (COUNT) early += (h.prim != kHitMiss) ? 1u : 0u;
+                        if (h.prim != kHitMiss) *a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    } else if (kind == 1u) {
+                        if (COUNT) ++raysClosest;
+                        const TraceHit h = traverse<false, COUNT>(sc, mk3(o4), mk3(d4), kEps, INFINITY, stack, cntClosest);
+                        const float4 a4 = *a;
+                        const f3 c = rectContribution(rp, sc, cc, mk3(o4), mk3(d4), h, mk3(a4), a4.w, mk3(recBase[recAt + 3u * slots]));
+                        *a = mk4(c, 0.0f);
+                    } else {
+                        const float4 a4 = *a;
+                        const f3 c = mneeChain<COUNT>(rp, sc, cc, mk3(o4), mk3(d4), __float_as_uint(o4.w), mk3(a4), a4.w, mk3(recBase[recAt + 3u * slots]),
+                                                      stack, cntAny, cntClosest, raysAny, raysClosest);
+                        *a = mk4(c, 0.0f);
+                    }
+                }
+                __threadfence();
+            }
+        }
+    }
+    if (COUNT) {
+        addCounter(pool.counters, kCntExtendRays, raysExtend + raysClosest);
+        addCounter(pool.counters, kCntExtendNodes, cntExtend.nodes + cntClosest.nodes);
+        addCounter(pool.counters, kCntExtendPrims, cntExtend.prims + cntClosest.prims);
+        addCounter(pool.counters, kCntShadowRays, raysAny);
+        addCounter(pool.counters, kCntShadowNodes, cntAny.nodes);
+        addCounter(pool.counters, kCntShadowPrims, cntAny.prims);
+        addCounter(pool.counters, kCntShadowEarlyExit, early);
+        addCounter(pool.counters, kCntShadedHits, counts.shadedHit);
+        addCounter(pool.counters, kCntTriangleHits, counts.triHit);
+        addCounter(pool.counters, kCntPrimaryRays, counts.primary);
+    }
+}
+
+// =====================================================================================================
 // k_resolve: fixed-order per-pixel reduction
 // =====================================================================================================
 __global__ void __launch_bounds__(256) k_flush(RenderParams rp, PathPool pool) {
@@ -1525,6 +1692,21 @@ __global__ void __launch_bounds__(256) k_resolve(RenderParams rp, PathPool pool,
     o[0] = total.x;
     o[1] = total.y;
     o[2] = total.z;
+}
+
+// =====================================================================================================
+// k_interleave_bands: the gather step of a multi-device frame.  `gathered` holds the band buffers of the P partitions one
+// after the other (partition p starts at float offset partOffset[p]); image band b = local band b / P of partition b % P.
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_interleave_bands(const float* gathered, const uint64_t* partOffset, uint32_t parts, uint32_t width,
+                                                          uint32_t height, float* image) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // one float of the image
+    const uint64_t rowFloats = static_cast<uint64_t>(width) * 3u;
+    if (i >= rowFloats * height) return;
+    const uint32_t y = static_cast<uint32_t>(i / rowFloats);
+    const uint64_t inRow = i - static_cast<uint64_t>(y) * rowFloats;
+    const uint32_t band = y / PTR_BAND_ROWS, part = band % parts, localBand = band / parts;
+    image[i] = gathered[partOffset[part] + (static_cast<uint64_t>(localBand) * PTR_BAND_ROWS + (y % PTR_BAND_ROWS)) * rowFloats + inRow];
 }
 
 // =====================================================================================================
@@ -1749,9 +1931,32 @@ void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& 
     }
 }
 
+void launchTail(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, uint32_t* dList, uint32_t* dListCount,
+                uint32_t* dListHead, bool count, hipStream_t stream) {
+    // dListCount and dListHead are zero on entry (the caller clears them on the same stream)
+    const uint32_t collectGrid = std::max(1u, std::min(cfg.traceGrid, ceilDiv(pool.slots, 256u * 16u)));
+    hipLaunchKernelGGL(k_tail_collect, dim3(collectGrid), dim3(256), 0, stream, pool, dList, dListCount);
+    const uint32_t stride = cfg.traceGrid * kTraceBlock;
+    const bool sss = (rp.mediaMode & (PTR_METAL_SSS | PTR_METAL_PBR)) != 0u;
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, dList, dListCount, dListHead, cfg.spill, stride);
+    };
+    if (count) {
+        if (sss) launch(k_tail_run<true, true>); else launch(k_tail_run<true, false>);
+    } else {
+        if (sss) launch(k_tail_run<false, true>); else launch(k_tail_run<false, false>);
+    }
+}
+
 void launchResolve(const RenderParams& rp, const PathPool& pool, uint32_t partCount, float* dOut, hipStream_t stream) {
     hipLaunchKernelGGL(k_flush, dim3(ceilDiv(pool.slots, 256)), dim3(256), 0, stream, rp, pool);
     hipLaunchKernelGGL(k_resolve, dim3(ceilDiv(rp.localPixels, 256)), dim3(256), 0, stream, rp, pool, partCount, dOut);
+}
+
+void launchInterleaveBands(const float* dGathered, const uint64_t* dPartOffset, uint32_t parts, uint32_t width, uint32_t height, float* dImage,
+                           hipStream_t stream) {
+    const uint64_t floats = static_cast<uint64_t>(width) * height * 3u;
+    hipLaunchKernelGGL(k_interleave_bands, dim3(ceilDiv(floats, 256)), dim3(256), 0, stream, dGathered, dPartOffset, parts, width, height, dImage);
 }
 
 void launchTraceRays(const SceneView& sc, const float4* dRays, uint64_t n, bool anyHit, PtrHit* dOut, const LaunchConfig& cfg,

@@ -103,7 +103,8 @@ V3 clampFireflyContribution(V3 throughput, V3 contribution, const ClampParams& p
     if (p.enabled < 0.5f) return positive;
     const float lum = luminance(positive);
     const float throughputLum = luminance(vmax(throughput, V3()));
-    const float maxLum = std::max(throughputLum * p.clampFactor, p.clampFloor);
+    float maxLum = std::max(throughputLum * p.clampFactor, p.clampFloor);
+    if (p.metalClamps && p.maxContribution > 0.0f) maxLum = std::max(maxLum, p.maxContribution);   // M:3563-3568
     if (lum > maxLum && lum > 0.0f) {
         const float scale = maxLum / std::max(lum, 1.0e-6f);
         combined *= scale;
@@ -113,6 +114,10 @@ V3 clampFireflyContribution(V3 throughput, V3 contribution, const ClampParams& p
 }
 
 float clampSpecularPdf(float pdf, const ClampParams& p) {
+    if (p.metalClamps) {   // M:3579-3590
+        if (!std::isfinite(pdf) || pdf <= 0.0f) return 0.0f;
+        return p.minSpecularPdfRaw <= 0.0f ? pdf : std::max(pdf, p.minSpecularPdfRaw);
+    }
     const float minPdf = std::max(p.minSpecularPdf, 1.0e-8f);
     if (!std::isfinite(pdf)) return minPdf;
     return std::max(pdf, minPdf);
@@ -132,6 +137,7 @@ V3 clampSpecularTail(V3 value, float roughness, V3 f0, const ClampParams& p) {
     if (!finite3(value)) return V3();
     V3 positive = vmax(value, V3());
     if (p.enabled < 0.5f) return positive;
+    if (p.metalClamps && p.specularTailClampBase <= 0.0f && p.specularTailClampRoughnessScale <= 0.0f) return positive;   // M:3619-3621
     const float strength = std::max(std::max(f0.x, f0.y), std::max(f0.z, 1.0e-3f));
     float limit = (p.specularTailClampBase + p.specularTailClampRoughnessScale * roughness) * strength;
     limit = std::max(limit, p.clampFloor);
@@ -727,6 +733,9 @@ ClampParams makeClampParams(const PtrSettings& s) {  // E:381-391
     p.sssMode = s.sssMode;
     p.sssMaxSteps = std::max(s.sssMaxSteps, 1u);
     p.metalPbr = (s.metalSemantics & PTR_METAL_PBR) != 0u;
+    p.metalClamps = (s.metalSemantics & PTR_METAL_CLAMPS) != 0u;
+    p.maxContribution = std::max(s.fireflyClampMaxContribution, 0.0f);
+    p.minSpecularPdfRaw = s.minSpecularPdf;
     return p;
 }
 

@@ -79,6 +79,9 @@ struct ClampParams {  // FireflyClampParams, :136-144
     uint32_t sssMode = 0;           // random walk when sssMode == 2 on materials that ask for it
     uint32_t sssMaxSteps = 32;
     bool metalPbr = false;          // PTR_METAL_PBR: three-lobe metallic-roughness model of the Metal integrator
+    bool metalClamps = false;       // PTR_METAL_CLAMPS: Metal variants of the clamps (shaders/pathtrace.metal:3550-3633, Appendix A rows 4-6)
+    float maxContribution = 0.0f;   // fireflyClampMaxContribution
+    float minSpecularPdfRaw = 0.0f;
 };
 
 struct BsdfEval {

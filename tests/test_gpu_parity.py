@@ -667,3 +667,164 @@ def test_ray_queries_against_the_reference_bvh_library():
     assert (rt_prim[mesh_hit] == g["primIndex"][mesh_hit]).mean() > 0.999
     other = ~mesh_hit
     assert not ((rt_t[other] >= 0) & ((g["t"][other] < 0) | (rt_t[other] < g["t"][other] * (1 - 1e-5)))).any()
+
+
+def test_multi_device_render_matches_single_device(cornell_small):
+    # ptr_render_multi: one preparation of the scene, one upload + one host thread per device, interleaved bands handed to the first
+    # device and interleaved there.  A one-GPU box runs the same path with the device named several times.
+    host, dev, _ = cornell_small
+    s = host.settings_for(width=88, height=72, max_depth=5, seed=1337)
+    single, _ = dev.render_image(s, 6)
+    for ids in ([0], [0, 0], [0, 0, 0], [0] * 9):             # 9 bands of 8 rows: the last case gives every partition one band
+        multi, st = pt.render_multi(host.desc, s, 6, device_ids=ids)
+        assert np.array_equal(multi, single), ids             # bit-identical, whatever the number of partitions
+        assert st.samples == 88 * 72 * 6 and st.totalSeconds > 0
+    whole, st = pt.render_multi(host.desc, s, 6, n_devices=1)
+    assert np.array_equal(whole, single)
+    with pytest.raises(pt.PtrError):
+        pt.render_multi(host.desc, s, 6, n_devices=pt.device_count() + 1)
+
+
+def test_cli_devices_and_aov_export(tmp_path):
+    import subprocess
+
+    out, aov = tmp_path / "frame.pfm", tmp_path / "features.exr"
+    r = subprocess.run([pt.CLI_PATH, "--scene=" + os.path.join(GOLDEN, "smoke.scene"), "--width=64", "--height=48", "--sppTotal=4", "--seed=1337",
+                        "--format=pfm", "--output=" + str(out), "--aovExr=" + str(aov), "--devices=1", "--backend=embree"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Feature layers written to" in r.stdout
+    data = aov.read_bytes()
+    assert b"albedo.R\x00" in data[:600] and b"normal.Z\x00" in data[:600] and b"depth.Z\x00" in data[:600]
+    assert len(data) > 64 * 48 * 10 * 4
+    body = np.frombuffer(data[-(48 * (8 + 10 * 64 * 4)):], np.uint8).reshape(48, 8 + 10 * 64 * 4)
+    planes = body[:, 8:].copy().view(np.float32).reshape(48, 10, 64)
+    host = pt.HostScene.load(os.path.join(GOLDEN, "smoke.scene"))
+    dev = pt.DeviceScene(host.desc, 0, keepalive=host)
+    s = host.settings_for(width=64, height=48, seed=1337)
+    img, _ = dev.render_image(s, 4)
+    albedo, normal = dev.render_aovs(s, 0)
+    assert np.array_equal(planes[:, 2], img[..., 0]) and np.array_equal(planes[:, 5], albedo[..., 0]) and np.array_equal(planes[:, 6], normal[..., 3])
+    # all visible devices through the CLI: the same image as one device
+    out2 = tmp_path / "frame_all.pfm"
+    r = subprocess.run([pt.CLI_PATH, "--scene=" + os.path.join(GOLDEN, "smoke.scene"), "--width=64", "--height=48", "--sppTotal=4", "--seed=1337",
+                        "--format=pfm", "--output=" + str(out2), "--devices=0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out2.read_bytes() == out.read_bytes()
+
+
+# --------------------------------------------------------------------------- deterministic-stream criterion
+_STREAM_CASES = [
+    ("golden/smoke.scene", 64, 64), ("golden/cornell_small_mesh.scene", 128, 128), ("golden/materials.scene", 192, 128),
+    ("golden/env_materials.scene", 192, 128), ("golden/lucy_small.scene", 160, 90), ("scenes/cornell.scene", 256, 256),
+    ("scenes/cornell_mesh.scene", 320, 180), ("scenes/helmet_env.scene", 320, 180), ("scenes/knot_glass.scene", 320, 180),
+]
+
+
+@pytest.mark.parametrize("case", _STREAM_CASES, ids=[c[0].split("/")[-1] for c in _STREAM_CASES])
+def test_deterministic_stream_criterion_and_what_the_rest_comes_from(case):
+    """>= 99 % of the pixels within 1e-3 (relative) of the oracle at 1 spp, depth 2, on every parity scene - the criterion as
+    SURVEY.md section 8(d) states it.  At the scenes' own depths the Cornell-box scenes fall below it; the path signatures
+    (which vertices received a rectangle-light sample that contributed + a hash of the primitives hit, computed by the HIP
+    counting build and by the oracle) say why, pixel by pixel: the paths hit the same primitives and differ in ONE thing, the
+    outcome of a rectangle-light shadow test - and the oracle flags exactly those tests as decided within +-2e-6 of the
+    shadow ray's length (quirk Q9: for a surface perpendicular to the light the ray ends 0.5e-4 before the light's own
+    plane, half an ulp of the distance).  Taking that one decision out of the rounding noise (debugShadowSlack, on both
+    sides) restores the criterion at every depth."""
+    from scenes.gen_assets import ensure_large_asset
+    rel_path, w, h = case
+    if "knot" in rel_path:
+        ensure_large_asset("torus_knot_871200.ply")
+    if "lucy_small" in rel_path:
+        ensure_large_asset("blob_125000.ply")
+    path = os.path.join(GOLDEN, rel_path.split("/", 1)[1]) if rel_path.startswith("golden/") else os.path.join(ROOT, rel_path)
+    host = pt.HostScene.load(path, SCENES)
+    dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
+    own_depth = int(host.settings_for(width=w, height=h).maxDepth)
+    for depth in sorted({2, own_depth}):
+        s = host.settings_for(width=w, height=h, max_depth=depth, seed=1337)
+        g, gsig = dev.render_signatures(s)
+        plain, _ = dev.render_image(s, 1)
+        assert np.array_equal(plain, g)                      # the counting build renders the same image as the timed build
+        o, osig, marginal = osc.render_signatures(s, threads=ORACLE_THREADS)
+        bad = _rel(g, o).max(axis=2) > 1e-3
+        frac = 1.0 - float(bad.mean())
+        nee = ((gsig ^ osig) & 0xFFFF) != 0
+        prim = ((gsig ^ osig) >> 16) != 0
+        if depth == 2:
+            assert frac >= 0.99, (rel_path, depth, frac)
+        if frac < 0.99:
+            shadow_flip = bad & nee & ~prim & marginal       # same primitives, another outcome of a marginal light-sample shadow test
+            assert shadow_flip.sum() >= 0.95 * bad.sum(), (rel_path, depth, int(bad.sum()), int(shadow_flip.sum()))
+        # signatures agree wherever the pixels agree (up to ties that change nothing visible)
+        assert (~bad & (nee | prim)).mean() < 1e-3
+        s2 = s.copy()
+        s2.debugShadowSlack = 1e-3
+        g2, _ = dev.render_image(s2, 1)
+        o2, _, _ = osc.render(s2, 1, threads=ORACLE_THREADS)
+        frac2 = float((_rel(g2, o2).max(axis=2) <= 1e-3).mean())
+        assert frac2 >= 0.99, (rel_path, depth, frac2)
+        if os.environ.get("PTR_TEST_VERBOSE"):
+            print("%s depth %d: %.4f within 1e-3 (%d differ, %d marginal shadow flips); with the shadow test out of the noise: %.4f"
+                  % (rel_path, depth, frac, int(bad.sum()), int((bad & nee & ~prim & marginal).sum()), frac2))
+    dev.close()
+    osc.close()
+
+
+def test_oversize_triangles_outside_the_tree(tmp_path):
+    # the floor of a room 600 times the size of a finely tessellated mesh is kept out of the BVH (so that the 16-bit grid of the
+    # 32 B nodes covers the mesh, not the room) and tested first by every ray: same hits as the oracle, same images
+    text = ("camera target=0,10,0 distance=40 yaw=1.0 pitch=0.3 vfov=40\nrenderer maxDepth=5 seed=1337\nbackground solid=0.1,0.1,0.12\n"
+            "material type=lambert albedo=0.6,0.6,0.6\nmaterial type=diffuse_light emit=14,14,14\nmaterial type=lambert albedo=0.8,0.5,0.3\n"
+            "rectangle x=-1500,1500 y=0 z=-1500,1500 normal=1 material=0\n"
+            "rectangle x=-40,40 y=90 z=-40,40 normal=-1 material=1\n"
+            "mesh path=assets/blob_70688.obj translate=0,10,0 scale=0.05 material=2\n")
+    p = tmp_path / "room.scene"
+    p.write_text(text)
+    host = pt.HostScene.load(str(p), SCENES)
+    g = pt.debug_scene_geometry(host.desc)
+    assert g["oversize"] == 2 and g["quantized_usable"] == 1
+    dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
+    rays = _random_rays(60_000, -30.0, 30.0, 4)
+    rays[:, 1] = np.abs(rays[:, 1]) + 0.5
+    for any_hit in (False, True):
+        gh, _ = dev.trace_rays(rays, any_hit=any_hit)
+        oh = osc.trace_rays(rays, any_hit=any_hit)
+        assert np.array_equal(gh["t"] >= 0, oh["t"] >= 0)
+        if not any_hit:
+            assert np.array_equal(gh["t"], oh["t"])
+            hit = oh["t"] >= 0
+            assert ((gh["primType"][hit] == oh["primType"][hit]) & (gh["primIndex"][hit] == oh["primIndex"][hit])).mean() > 0.999
+            assert (oh["primType"][hit] == 2).any() and (oh["primType"][hit] == 0).any()     # floor halves and mesh triangles
+    _image_parity(host, dev, osc, 96, 64, 5, 1, 16, 0.95)
+
+
+def test_metal_clamp_variants(materials_scene):
+    # PTR_METAL_CLAMPS (shaders/pathtrace.metal:3550-3633, SURVEY.md Appendix A rows 4-6): firefly limit raised to
+    # fireflyClampMaxContribution, clamp_specular_tail skipped while base = scale = 0, clamp_specular_pdf passing the pdf through.
+    # Parity against the oracle's restatement; and the variant really differs from the Embree-parity clamps.
+    host, dev, osc = materials_scene
+    assert host.settings.fireflyClampMaxContribution == 1000.0 and host.settings.specularTailClampBase == 0.0
+    _image_parity(host, dev, osc, 96, 64, 6, 1, 32, 0.90, metalSemantics=64)
+    _image_parity(host, dev, osc, 96, 64, 6, 1, 16, 0.90, metalSemantics=64 | 8, minSpecularPdf=1e-3, specularTailClampBase=2.0)
+    s0 = host.settings_for(width=96, height=64, max_depth=6, seed=1337)
+    s1 = s0.copy()
+    s1.metalSemantics = 64
+    a, b = dev.render_image(s0, 64)[0], dev.render_image(s1, 64)[0]
+    assert _rmse(a, b) > 1e-3 and b.mean() > a.mean()        # looser clamps keep more energy
+    # device functions: the BSDF values of a smooth metal are no longer capped at the clamp floor
+    d = host.desc
+    metals = [i for i in range(d.materialCount) if int(d.materials[i].typeEta[0]) == 1]
+    assert metals
+    rng = np.random.default_rng(2)
+    n = 2000
+    wo = rng.normal(size=(n, 3))
+    wo[:, 2] = np.abs(wo[:, 2]) + 0.2
+    wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    wi = wo * np.array([-1, -1, 1]) + rng.normal(scale=0.02, size=(n, 3))
+    wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    inputs = np.concatenate([np.zeros((n, 3)), np.tile([0, 0, 1.0], (n, 1)), wo, wi], axis=1).astype(np.float32)
+    for mi in metals[:2]:
+        g = pt.debug_eval_bsdf(d.materials[mi], s1, inputs)
+        o = ol.eval_bsdf(d.materials[mi], s1, inputs)
+        both = np.isfinite(g).all(axis=1) & np.isfinite(o).all(axis=1)
+        assert np.isclose(g[both], o[both], rtol=5e-3, atol=1e-4).all(axis=1).mean() > 0.99

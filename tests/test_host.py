@@ -391,6 +391,29 @@ def test_bvh_invariants_mixed_and_degenerate_scenes(tmp_path):
     assert g["max_leaf_size"] <= 4
 
 
+def test_bvh_keeps_oversize_triangles_out_of_the_tree(tmp_path):
+    # a finely tessellated mesh in a room 600 times its size: inside the tree the floor would stretch the 16-bit grid of the
+    # quantised nodes until a cell is coarser than the mesh triangles (-> 64 B float nodes); kept out of the tree (and tested
+    # first by every ray) the grid covers the mesh and the light only
+    text = ("material type=lambert\nrectangle x=-1500,1500 y=0 z=-1500,1500 normal=1 material=0\n"
+            "rectangle x=-40,40 y=90 z=-40,40 normal=-1 material=0\n"
+            "mesh path=assets/blob_70688.obj translate=0,10,0 scale=0.05 material=0\n")
+    host = pt.HostScene.load(_write(tmp_path, text), os.path.join(ROOT, "scenes"))
+    g = pt.debug_scene_geometry(host.desc)
+    _geometry_ok(g, 70688 + 4, 0)                       # every triangle referenced exactly once, the two floor halves included
+    assert g["oversize"] == 2 and g["quantized_usable"] == 1
+    os.environ["PTR_NO_OVERSIZE"] = "1"
+    try:
+        g0 = pt.debug_scene_geometry(host.desc)
+    finally:
+        del os.environ["PTR_NO_OVERSIZE"]
+    _geometry_ok(g0, 70688 + 4, 0)
+    assert g0["oversize"] == 0 and g0["quantized_usable"] == 0
+    # the scenes whose grid is fine anyway are left alone
+    cfg2 = pt.HostScene.load(os.path.join(ROOT, "scenes", "cornell_mesh.scene"), os.path.join(ROOT, "scenes"))
+    assert pt.debug_scene_geometry(cfg2.desc)["oversize"] == 0
+
+
 def test_bvh_rejects_bad_mesh_indices(tmp_path):
     host = pt.HostScene.load(_write(tmp_path, "material type=lambert\nmesh type=plane material=0\n"))
     d = host.desc
@@ -483,6 +506,38 @@ def test_ppm_tonemap_and_exr_layout(tmp_path):
     assert np.array_equal(planes[:, 4], counts) and np.array_equal(planes[:, 2], img[..., 0]) and (planes[:, 3] == 1.0).all()
 
 
+def test_aov_exr_layers(tmp_path):
+    # beauty + first-hit feature layers (ptr_host_write_exr_aovs): channel list in alphabetical order, normals decoded to unit vectors
+    h, w = 3, 4
+    rng = np.random.default_rng(5)
+    rgb = rng.random((h, w, 3), dtype=np.float32)
+    albedo = np.concatenate([rng.random((h, w, 3), dtype=np.float32), np.ones((h, w, 1), np.float32)], axis=2)
+    n = rng.normal(size=(h, w, 3)).astype(np.float32)
+    n /= np.linalg.norm(n, axis=2, keepdims=True)
+    normal = np.concatenate([n * 0.5 + 0.5, rng.uniform(1, 9, size=(h, w, 1)).astype(np.float32)], axis=2).astype(np.float32)
+    albedo[0, 0] = 0.0                      # a miss: no hit flag
+    normal[0, 0] = (0.5, 0.5, 0.5, 0.0)
+    path = tmp_path / "aov.exr"
+    pt.write_exr_aovs(str(path), rgb, albedo, normal)
+    data = path.read_bytes()
+    assert struct.unpack("<II", data[:8]) == (20000630, 2)
+    names = [b"B", b"G", b"R", b"albedo.B", b"albedo.G", b"albedo.R", b"depth.Z", b"normal.X", b"normal.Y", b"normal.Z"]
+    at = data.index(b"chlist\x00") + 7 + 4
+    found = []
+    while data[at] != 0:
+        end = data.index(b"\x00", at)
+        found.append(data[at:end])
+        at = end + 1 + 16
+    assert found == names
+    body = np.frombuffer(data[-(h * (8 + 10 * w * 4)):], np.uint8).reshape(h, 8 + 10 * w * 4)
+    planes = body[:, 8:].copy().view(np.float32).reshape(h, 10, w)
+    assert np.array_equal(planes[:, 2], rgb[..., 0]) and np.array_equal(planes[:, 0], rgb[..., 2])
+    assert np.array_equal(planes[:, 5], albedo[..., 0]) and np.array_equal(planes[:, 6], normal[..., 3])
+    dec = np.stack([planes[:, 7], planes[:, 8], planes[:, 9]], axis=2)
+    assert np.allclose(dec[1:], n[1:], atol=1e-6) and np.allclose(np.linalg.norm(dec[1:], axis=2), 1.0, atol=1e-5)
+    assert (dec[0, 0] == 0).all() and planes[0, 6, 0] == 0.0
+
+
 # --------------------------------------------------------------------------- CLI surface
 def test_cli_flag_surface():
     exe = pt.CLI_PATH
@@ -496,6 +551,13 @@ def test_cli_flag_surface():
     assert r.returncode == 1 and "--width must be >= 8" in r.stderr
     r = subprocess.run([exe, "--scene=/nonexistent.scene"], capture_output=True, text=True)
     assert r.returncode == 1 and "Failed to load scene" in r.stderr
+    # backend selection of the reference (main_headless.mm:344-371) is accepted: the names pick the integrator semantics
+    for flags in (["--backend=embree"], ["--backend", "metal"], ["--enableEmbree"], ["--enableEmbree=0"], ["--backend=hip", "--semantics=metal"],
+                  ["--devices=2"], ["--aovExr=/tmp/unused.exr"]):
+        r = subprocess.run([exe, "--scene=/nonexistent.scene"] + flags, capture_output=True, text=True)
+        assert r.returncode == 1 and "Failed to load scene" in r.stderr and "Unknown option" not in r.stderr, flags
+    r = subprocess.run([exe, "--scene=x.scene", "--backend=optix"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Invalid value for --backend" in r.stderr
     if pt.device_count() == 0:
         r = subprocess.run([exe, "--scene", os.path.join(GOLDEN, "smoke.scene"), "--sppTotal=1"], capture_output=True, text=True)
         assert r.returncode == 1 and "Render failed" in r.stderr

@@ -531,3 +531,28 @@ def test_metal_pbr_model_sample_and_eval_agree():
     sin_o = np.linalg.norm(wo[dn, :2], axis=1)
     sin_t = np.linalg.norm(outd[dn, :2], axis=1)
     assert np.allclose(sin_t * 1.45, sin_o, atol=1e-4)                                                               # Snell
+
+
+def test_metal_clamp_variants_restated():
+    """PTR_METAL_CLAMPS (shaders/pathtrace.metal:3550-3633) on the oracle side: with the default
+    settings (tail base = scale = 0, minSpecularPdf = 0, maxContribution = 1000) the Embree variants cap a smooth metal lobe's
+    luminance at the clamp floor (4) while the Metal variants leave it alone."""
+    host = pt.HostScene.load(os.path.join(GOLDEN, "materials.scene"))
+    d = host.desc
+    metal = next(i for i in range(d.materialCount) if int(d.materials[i].typeEta[0]) == 1 and d.materials[i].baseColorRoughness[3] < 0.3)
+    s0 = host.settings_for(width=32, height=32)
+    s1 = s0.copy()
+    s1.metalSemantics = 64
+    wo = np.array([0.3, 0.1, 0.95])
+    wo /= np.linalg.norm(wo)
+    wi = wo * np.array([-1, -1, 1])          # the mirror direction: the peak of the lobe
+    inputs = np.concatenate([np.zeros(3), [0, 0, 1.0], wo, wi]).astype(np.float32)[None]
+    capped = ol.eval_bsdf(d.materials[metal], s0, inputs)[0]
+    free = ol.eval_bsdf(d.materials[metal], s1, inputs)[0]
+    lum = lambda v: 0.2126 * v[0] + 0.7152 * v[1] + 0.0722 * v[2]
+    assert lum(capped[:3]) <= 4.0 + 1e-4 < lum(free[:3])
+    assert free[3] >= capped[3] > 0                 # pdf: passed through / floored at 1e-8
+    # the firefly limit: a 500-luminance contribution survives under the Metal variant only
+    img0, _, _ = ol.OracleScene(host).render(s0, 8, threads=2)
+    img1, _, _ = ol.OracleScene(host).render(s1, 8, threads=2)
+    assert img1.mean() >= img0.mean()

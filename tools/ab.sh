@@ -11,5 +11,5 @@ for n in "$@"; do
   timeout -k 10 300 python bench.py $ARGS --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(d['value'], d['kernel_ms_per_step'], 'extend launch ms', d['roofline']['avg_launch_ms'], 'B/sample', d['roofline']['bytes_per_sample'])"
+print(d['value'], 'Msamples/s', d['ms_per_step'], 'ms/step', d['kernel_ms_per_step'])"
 done

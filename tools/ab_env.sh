@@ -12,5 +12,5 @@ for kv in "$@"; do
 import json,sys
 lines=sys.stdin.read().strip().splitlines()
 d=json.loads(lines[-1])
-print(d['value'], d['kernel_ms_per_step'], 'extend launch ms', d['roofline'].get('avg_launch_ms'), 'B/sample', d['roofline'].get('bytes_per_sample'))" || tail -5 gpurun_out/ab_env.err
+print(d['value'], 'Msamples/s', d['ms_per_step'], 'ms/step', d['kernel_ms_per_step'])" || tail -5 gpurun_out/ab_env.err
 done
