@@ -105,7 +105,23 @@ typedef struct PtrMeshDesc {
     float localToWorld[16];         /* column-major 4x4 */
     uint32_t materialIndex;
     uint32_t pad;
+    /* texture coordinates and tangents (SceneVertex, include/MetalShaderTypes.h:351-356); each may be NULL.  Read only by the
+     * textured metallic-roughness model (PTR_METAL_PBR), as in the reference, whose Embree backend never samples textures. */
+    const float* uv0;               /* vertexCount * 2 */
+    const float* uv1;               /* vertexCount * 2 */
+    const float* tangents;          /* vertexCount * 4: object-space tangent, w = handedness (0: no tangent) */
 } PtrMeshDesc;
+
+/* A material texture: level 0 as linear RGBA floats (sRGB-encoded images are decoded to linear when loaded), row 0 = top.
+ * The renderer builds the mip chain itself (2x2 box filter).  wrap: 0 repeat, 1 clamp to edge, 2 mirrored repeat (glTF sampler
+ * wrapS / wrapT 10497 / 33071 / 33648); filter: 0 nearest, 1 linear (glTF magFilter 9728 / 9729). */
+typedef struct PtrTexture {
+    const float* rgba;
+    uint32_t width, height;
+    uint32_t wrapS, wrapT;
+    uint32_t filter;
+    uint32_t pad;
+} PtrTexture;
 
 typedef struct PtrSceneDesc {
     const PtrSphere* spheres;
@@ -119,6 +135,9 @@ typedef struct PtrSceneDesc {
     uint32_t meshCount;
     uint32_t envWidth;
     uint32_t envHeight;
+    const PtrTexture* textures;     /* what PtrMaterial.textureIndices0/1 index (0xFFFFFFFF = no texture); NULL if none */
+    uint32_t textureCount;
+    uint32_t pad;
 } PtrSceneDesc;
 
 enum PtrBackgroundMode { PTR_BG_GRADIENT = 0, PTR_BG_SOLID = 1, PTR_BG_ENVIRONMENT = 2 };
@@ -321,6 +340,11 @@ int ptr_host_write_exr_multilayer(const char* path, const float* linear_rgb, uin
  * shaders/pathtrace.metal:9813-9815), written with the layer convention of ImageWriter::WriteEXR_Multilayer (ImageWriter.mm:657-684). */
 int ptr_host_write_exr_aovs(const char* path, const float* linear_rgb, const float* albedo_rgba, const float* normal_rgba,
                             uint32_t width, uint32_t height, char* err, size_t err_cap);
+/* PNG / baseline JPEG bytes -> 8-bit RGBA (row 0 = top), the decoders the glTF loader uses for material textures
+ * (csrc/host/image_decoders.h; the reference leaves this to MTKTextureLoader, src/renderer/SceneResources.mm:213-420).
+ * out_rgba may be NULL to query the size. */
+int ptr_host_decode_image(const uint8_t* data, uint64_t size, uint8_t* out_rgba, uint64_t cap_bytes, uint32_t* width, uint32_t* height,
+                          char* err, size_t err_cap);
 int ptr_host_read_pfm(const char* path, float* out_rgb, uint32_t cap_floats, uint32_t* width, uint32_t* height);
 
 const char* ptr_version(void);

@@ -31,6 +31,10 @@ int ptr_debug_camera_rays(const PtrSettings* settings, const uint32_t* xys, uint
 int ptr_debug_render_signatures(PtrDeviceScene* scene, const PtrSettings* settings, float* out_rgb, uint32_t* out_signature,
                                 char* err, size_t err_cap);
 
+/* The texture filtering rule of the textured metallic-roughness model (csrc/kernels/texture.h) on a batch: in n * 3 floats
+ * {u, v, lod}, out n * 4 floats RGBA (-1 in every channel when the scene has no such texture). */
+int ptr_debug_texture_sample(PtrDeviceScene* scene, uint32_t texture, const float* in, uint64_t n, float* out, char* err, size_t err_cap);
+
 /* ptr_render_multi on an explicit list of devices; an id may appear more than once, which lets a one-GPU box run the whole
  * multi-device path (threads, partitions, hand-over, interleave). */
 int ptr_debug_render_multi_on(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t spp, const int* device_ids, int n,

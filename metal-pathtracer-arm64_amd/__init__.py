@@ -80,6 +80,21 @@ class PtrMeshDesc(C.Structure):
         ("localToWorld", C.c_float * 16),
         ("materialIndex", C.c_uint32),
         ("pad", C.c_uint32),
+        ("uv0", C.POINTER(C.c_float)),
+        ("uv1", C.POINTER(C.c_float)),
+        ("tangents", C.POINTER(C.c_float)),
+    ]
+
+
+class PtrTexture(C.Structure):
+    _fields_ = [
+        ("rgba", C.POINTER(C.c_float)),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("wrapS", C.c_uint32),
+        ("wrapT", C.c_uint32),
+        ("filter", C.c_uint32),
+        ("pad", C.c_uint32),
     ]
 
 
@@ -96,6 +111,9 @@ class PtrSceneDesc(C.Structure):
         ("meshCount", C.c_uint32),
         ("envWidth", C.c_uint32),
         ("envHeight", C.c_uint32),
+        ("textures", C.POINTER(PtrTexture)),
+        ("textureCount", C.c_uint32),
+        ("pad", C.c_uint32),
     ]
 
 
@@ -194,11 +212,11 @@ ABI_SYMBOLS = (
     "ptr_device_count", "ptr_scene_upload", "ptr_scene_release", "ptr_scene_info", "ptr_render",
     "ptr_render_bands_device", "ptr_part_band_count", "ptr_render_bands", "ptr_trace_rays", "ptr_render_aovs",
     "ptr_host_scene_load", "ptr_host_scene_free", "ptr_host_scene_desc", "ptr_host_write_image", "ptr_host_write_exr_multilayer",
-    "ptr_host_read_pfm", "ptr_version", "ptr_render_multi", "ptr_host_write_exr_aovs",
+    "ptr_host_read_pfm", "ptr_version", "ptr_render_multi", "ptr_host_write_exr_aovs", "ptr_host_decode_image",
 )
 # include/ptr_debug.h (test-only device-function probes)
 DEBUG_SYMBOLS = ("ptr_debug_eval_bsdf", "ptr_debug_sample_bsdf", "ptr_debug_camera_rays", "ptr_debug_env_distribution",
-                 "ptr_debug_scene_geometry", "ptr_debug_render_signatures", "ptr_debug_render_multi_on")
+                 "ptr_debug_scene_geometry", "ptr_debug_render_signatures", "ptr_debug_render_multi_on", "ptr_debug_texture_sample")
 
 _lib: Optional[C.CDLL] = None
 
@@ -248,10 +266,12 @@ def load_library() -> C.CDLL:
     lib.ptr_debug_env_distribution.argtypes = [fp, u32, u32, fp, up, fp, up, fp, fp]
     lib.ptr_debug_scene_geometry.argtypes = [C.POINTER(PtrSceneDesc), u32, C.POINTER(u64), cp, sz]
     lib.ptr_debug_render_signatures.argtypes = [vp, C.POINTER(PtrSettings), fp, up, cp, sz]
+    lib.ptr_debug_texture_sample.argtypes = [vp, u32, fp, u64, fp, cp, sz]
     lib.ptr_render_multi.argtypes = [C.POINTER(PtrSceneDesc), C.POINTER(PtrSettings), u32, C.c_int, C.c_int, fp, C.POINTER(PtrRenderStats), cp, sz]
     lib.ptr_debug_render_multi_on.argtypes = [C.POINTER(PtrSceneDesc), C.POINTER(PtrSettings), u32, C.POINTER(C.c_int), C.c_int, fp,
                                               C.POINTER(PtrRenderStats), cp, sz]
     lib.ptr_host_write_exr_aovs.argtypes = [cp, fp, fp, fp, u32, u32, cp, sz]
+    lib.ptr_host_decode_image.argtypes = [cp, u64, C.POINTER(C.c_uint8), u64, up, up, cp, sz]
     _lib = lib
     return lib
 
@@ -401,6 +421,14 @@ class DeviceScene:
                                                           err, len(err)), err)
         return img, sig
 
+    def texture_sample(self, texture: int, uv_lod: np.ndarray) -> np.ndarray:
+        """Filtered texture lookups on the device (include/ptr_debug.h): uv_lod [n, 3] -> [n, 4] RGBA."""
+        uv_lod = np.ascontiguousarray(uv_lod, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((uv_lod.shape[0], 4), dtype=np.float32)
+        err = _err_buf()
+        _check(load_library().ptr_debug_texture_sample(self._h, texture, _fptr(uv_lod), uv_lod.shape[0], _fptr(out), err, len(err)), err)
+        return out
+
     def trace_rays(self, rays: np.ndarray, any_hit: bool = False) -> Tuple[np.ndarray, PtrRenderStats]:
         """rays: [n, 8] float32 {ox,oy,oz,tmin,dx,dy,dz,tmax}; returns a structured array of PtrHit."""
         lib = load_library()
@@ -438,6 +466,17 @@ def render_multi(desc: PtrSceneDesc, settings: PtrSettings, spp: int, n_devices:
     else:
         _check(lib.ptr_render_multi(C.byref(desc), C.byref(settings), spp, n_devices, int(verbose), _fptr(img), C.byref(stats), err, len(err)), err)
     return img, stats
+
+
+def decode_image(data: bytes) -> np.ndarray:
+    """PNG / baseline JPEG bytes -> [H, W, 4] uint8 through the library's own decoders (ptr_host_decode_image)."""
+    lib = load_library()
+    w, h = C.c_uint32(), C.c_uint32()
+    err = _err_buf()
+    _check(lib.ptr_host_decode_image(data, len(data), None, 0, C.byref(w), C.byref(h), err, len(err)), err)
+    out = np.zeros((h.value, w.value, 4), dtype=np.uint8)
+    _check(lib.ptr_host_decode_image(data, len(data), out.ctypes.data_as(C.POINTER(C.c_uint8)), out.nbytes, C.byref(w), C.byref(h), err, len(err)), err)
+    return out
 
 
 def write_exr_aovs(path: str, rgb: np.ndarray, albedo: np.ndarray, normal: np.ndarray) -> None:

@@ -46,6 +46,9 @@ struct TempNode {
     uint32_t left = 0, right = 0;   // children (internal)
     uint32_t first = 0, count = 0;  // range in `order` (leaf when count > 0)
     uint32_t sphereLeaf = 0;
+    // subtree totals, filled on the way back up: what the flattener needs to give every subtree its own slice of the node /
+    // triangle / sphere arrays, so that subtrees can be laid out in parallel
+    uint32_t internalNodes = 0, triPrims = 0, spherePrims = 0;
 };
 
 struct Builder {
@@ -71,6 +74,28 @@ struct Builder {
         nodes[node].first = begin;
         nodes[node].count = end - begin;
         nodes[node].sphereLeaf = prims[order[begin]].isSphere;
+        nodes[node].internalNodes = 0;
+        nodes[node].triPrims = nodes[node].sphereLeaf ? 0u : end - begin;
+        nodes[node].spherePrims = nodes[node].sphereLeaf ? end - begin : 0u;
+    }
+
+    // Nodes above this size split their own loops over the host threads: the top five levels of a 29 M-triangle tree touch every
+    // primitive once per level, and before the subtrees fan out over the threads that was most of the build (6.9 s of it serial).
+    static constexpr uint32_t kWideNode = 1u << 20;
+    uint32_t wideThreads = 1;
+    std::vector<uint32_t> scratch;   // parallel partition of wide nodes
+
+    template <typename Fn>
+    void forChunks(uint32_t begin, uint32_t end, Fn&& fn) const {   // fn(chunkIndex, chunkBegin, chunkEnd)
+        const uint32_t t = std::max(1u, std::min(wideThreads, (end - begin) >> 16));
+        const uint32_t chunk = (end - begin + t - 1) / t;
+        std::vector<std::thread> pool;
+        for (uint32_t k = 1; k < t; ++k) {
+            const uint32_t b = std::min(end, begin + chunk * k), e = std::min(end, begin + chunk * (k + 1));
+            if (b < e) pool.emplace_back([&fn, k, b, e]() { fn(k, b, e); });
+        }
+        fn(0u, begin, std::min(end, begin + chunk));
+        for (auto& th : pool) th.join();
     }
 
     void build(uint32_t node, uint32_t begin, uint32_t end, uint32_t depth) {
@@ -78,11 +103,41 @@ struct Builder {
         box.reset();
         cbox.reset();
         uint32_t sphereCount = 0;
-        for (uint32_t i = begin; i < end; ++i) {
-            const BuildPrim& p = prims[order[i]];
-            box.grow(p.lo, p.hi);
-            cbox.growPoint(&centers[static_cast<size_t>(order[i]) * 3]);
-            sphereCount += p.isSphere;
+        const bool wide = (end - begin) >= kWideNode && wideThreads > 1;
+        if (wide) {
+            struct Part {
+                Aabb box, cbox;
+                uint32_t spheres;
+            };
+            std::vector<Part> parts(wideThreads);
+            for (Part& p : parts) {
+                p.box.reset();
+                p.cbox.reset();
+                p.spheres = 0;
+            }
+            forChunks(begin, end, [&](uint32_t k, uint32_t b, uint32_t e) {
+                Part& part = parts[k];
+                for (uint32_t i = b; i < e; ++i) {
+                    const BuildPrim& p = prims[order[i]];
+                    part.box.grow(p.lo, p.hi);
+                    part.cbox.growPoint(&centers[static_cast<size_t>(order[i]) * 3]);
+                    part.spheres += p.isSphere;
+                }
+            });
+            for (const Part& p : parts) {
+                if (p.box.lo[0] <= p.box.hi[0]) {
+                    box.grow(p.box.lo, p.box.hi);
+                    cbox.grow(p.cbox.lo, p.cbox.hi);
+                }
+                sphereCount += p.spheres;
+            }
+        } else {
+            for (uint32_t i = begin; i < end; ++i) {
+                const BuildPrim& p = prims[order[i]];
+                box.grow(p.lo, p.hi);
+                cbox.growPoint(&centers[static_cast<size_t>(order[i]) * 3]);
+                sphereCount += p.isSphere;
+            }
         }
         nodes[node].box = box;
         const uint32_t count = end - begin;
@@ -111,11 +166,42 @@ struct Builder {
                     binCount[b] = 0;
                 }
                 const float scale = static_cast<float>(kBins) / (hi - lo);
-                for (uint32_t i = begin; i < end; ++i) {
-                    const uint32_t id = order[i];
-                    const int b = std::min(kBins - 1, static_cast<int>((centers[static_cast<size_t>(id) * 3 + axis] - lo) * scale));
-                    binBox[b].grow(prims[id].lo, prims[id].hi);
-                    ++binCount[b];
+                if (wide) {
+                    struct Bins {
+                        Aabb box[kBins];
+                        uint32_t count[kBins];
+                    };
+                    std::vector<Bins> parts(wideThreads);
+                    for (Bins& p : parts) {
+                        for (int b = 0; b < kBins; ++b) {
+                            p.box[b].reset();
+                            p.count[b] = 0;
+                        }
+                    }
+                    forChunks(begin, end, [&](uint32_t k, uint32_t cb, uint32_t ce) {
+                        Bins& part = parts[k];
+                        for (uint32_t i = cb; i < ce; ++i) {
+                            const uint32_t id = order[i];
+                            const int b = std::min(kBins - 1, static_cast<int>((centers[static_cast<size_t>(id) * 3 + axis] - lo) * scale));
+                            part.box[b].grow(prims[id].lo, prims[id].hi);
+                            ++part.count[b];
+                        }
+                    });
+                    for (const Bins& p : parts) {
+                        for (int b = 0; b < kBins; ++b) {
+                            if (p.count[b]) {
+                                binBox[b].grow(p.box[b].lo, p.box[b].hi);
+                                binCount[b] += p.count[b];
+                            }
+                        }
+                    }
+                } else {
+                    for (uint32_t i = begin; i < end; ++i) {
+                        const uint32_t id = order[i];
+                        const int b = std::min(kBins - 1, static_cast<int>((centers[static_cast<size_t>(id) * 3 + axis] - lo) * scale));
+                        binBox[b].grow(prims[id].lo, prims[id].hi);
+                        ++binCount[b];
+                    }
                 }
                 float rightArea[kBins];
                 uint32_t rightCount[kBins];
@@ -151,10 +237,39 @@ struct Builder {
                 }
                 const float lo = cbox.lo[bestAxis];
                 const float scale = static_cast<float>(kBins) / (cbox.hi[bestAxis] - lo);
-                auto it = std::partition(order.begin() + begin, order.begin() + end, [&](uint32_t id) {
+                auto goesLeft = [&](uint32_t id) {
                     return std::min(kBins - 1, static_cast<int>((centers[static_cast<size_t>(id) * 3 + bestAxis] - lo) * scale)) <= bestBin;
-                });
-                mid = static_cast<uint32_t>(it - order.begin());
+                };
+                if (wide) {
+                    // chunk-wise counts, prefix sums, stable scatter through the scratch array (which side a primitive lands on is all
+                    // that matters: the subtrees re-partition their ranges anyway)
+                    std::vector<uint32_t> lefts(wideThreads + 1u, 0u), sizes(wideThreads + 1u, 0u);
+                    forChunks(begin, end, [&](uint32_t k, uint32_t cb, uint32_t ce) {
+                        uint32_t n = 0;
+                        for (uint32_t i = cb; i < ce; ++i) n += goesLeft(order[i]) ? 1u : 0u;
+                        lefts[k + 1u] = n;
+                        sizes[k + 1u] = ce - cb;
+                    });
+                    uint32_t totalLeft = 0;
+                    for (uint32_t k = 1; k <= wideThreads; ++k) totalLeft += lefts[k];
+                    std::vector<uint32_t> leftAt(wideThreads + 1u, 0u), rightAt(wideThreads + 1u, 0u);
+                    for (uint32_t k = 0; k < wideThreads; ++k) {
+                        leftAt[k + 1u] = leftAt[k] + lefts[k + 1u];
+                        rightAt[k + 1u] = rightAt[k] + (sizes[k + 1u] - lefts[k + 1u]);
+                    }
+                    forChunks(begin, end, [&](uint32_t k, uint32_t cb, uint32_t ce) {
+                        uint32_t l = begin + leftAt[k], r = begin + totalLeft + rightAt[k];
+                        for (uint32_t i = cb; i < ce; ++i) {
+                            const uint32_t id = order[i];
+                            if (goesLeft(id)) scratch[l++] = id; else scratch[r++] = id;
+                        }
+                    });
+                    forChunks(begin, end, [&](uint32_t, uint32_t cb, uint32_t ce) { std::memcpy(&order[cb], &scratch[cb], static_cast<size_t>(ce - cb) * 4u); });
+                    mid = begin + totalLeft;
+                } else {
+                    auto it = std::partition(order.begin() + begin, order.begin() + end, goesLeft);
+                    mid = static_cast<uint32_t>(it - order.begin());
+                }
                 haveSplit = mid != begin && mid != end;
             }
         }
@@ -199,6 +314,9 @@ struct Builder {
             build(left, begin, mid, depth + 1);
             build(left + 1, mid, end, depth + 1);
         }
+        nodes[node].internalNodes = 1u + nodes[left].internalNodes + nodes[left + 1].internalNodes;
+        nodes[node].triPrims = nodes[left].triPrims + nodes[left + 1].triPrims;
+        nodes[node].spherePrims = nodes[left].spherePrims + nodes[left + 1].spherePrims;
     }
 };
 
@@ -207,16 +325,25 @@ struct Flattener {
     FlatBvh& out;
     std::vector<uint32_t> primToTri, primToSphere;  // input index -> n-th triangle / sphere
 
-    uint32_t leafRef(const TempNode& n) {
+    struct Stats {
+        double sahCost = 0.0;
+        uint32_t leafCount = 0, maxDepth = 0, maxLeafSize = 0;
+    };
+    struct Item {
+        uint32_t temp, device, depth, triBase, sphereBase;
+    };
+
+    // the leaf's primitives land at their precomputed place in the leaf-order arrays
+    uint32_t leafRef(const TempNode& n, uint32_t triBase, uint32_t sphereBase, Stats& st) {
         const bool sphere = n.sphereLeaf != 0;
         std::vector<uint32_t>& dst = sphere ? out.sphereOrder : out.triOrder;
-        const uint32_t first = static_cast<uint32_t>(dst.size());
+        const uint32_t first = sphere ? sphereBase : triBase;
         for (uint32_t i = 0; i < n.count; ++i) {
             const uint32_t id = b.order[n.first + i];
-            dst.push_back(sphere ? primToSphere[id] : primToTri[id]);
+            dst[first + i] = sphere ? primToSphere[id] : primToTri[id];
         }
-        ++out.leafCount;
-        out.maxLeafSize = std::max(out.maxLeafSize, n.count);
+        ++st.leafCount;
+        st.maxLeafSize = std::max(st.maxLeafSize, n.count);
         return ptrk::kRefLeafBit | (sphere ? ptrk::kRefSphereBit : 0u) | ((n.count - 1u) << ptrk::kRefCountShift) | first;
     }
 
@@ -233,49 +360,98 @@ struct Flattener {
         }
     }
 
-    // iterative DFS: device node indices are assigned in preorder, left subtree first
-    void run(double rootArea) {
-        struct Item {
-            uint32_t temp, device, depth;
-        };
+    // One internal node: its two child slots.  Device indices are preorder - the left subtree follows its parent, the right one
+    // follows the left subtree - and every subtree owns a contiguous slice of the node and leaf-order arrays (sizes known from the
+    // build), so disjoint subtrees can be written by different threads.
+    void emit(const Item& it, double rootArea, Stats& st, std::vector<Item>& pending) {
+        const TempNode& n = b.nodes[it.temp];
+        st.sahCost += n.box.halfArea() / rootArea;
+        const TempNode& l = b.nodes[n.left];
+        const uint32_t kids[2] = {n.left, n.right};
+        const uint32_t triBase[2] = {it.triBase, it.triBase + l.triPrims}, sphereBase[2] = {it.sphereBase, it.sphereBase + l.spherePrims};
+        const uint32_t device[2] = {it.device + 1u, it.device + 1u + l.internalNodes};
+        Item next[2];
+        bool internal[2] = {false, false};
+        for (int s = 0; s < 2; ++s) {
+            const TempNode& c = b.nodes[kids[s]];
+            if (c.count > 0) {
+                setChild(it.device, s, c.box, leafRef(c, triBase[s], sphereBase[s], st));
+                st.sahCost += (c.box.halfArea() / rootArea) * c.count;
+                st.maxDepth = std::max(st.maxDepth, it.depth + 2);
+            } else {
+                setChild(it.device, s, c.box, device[s]);
+                next[s] = {kids[s], device[s], it.depth + 1, triBase[s], sphereBase[s]};
+                internal[s] = true;
+            }
+        }
+        if (internal[1]) pending.push_back(next[1]);
+        if (internal[0]) pending.push_back(next[0]);
+    }
+
+    void run(double rootArea, uint32_t threads) {
         const TempNode& root = b.nodes[0];
-        // one flat node per internal temp node: size the array once (upper bound: every allocated temp node)
-        out.nodes.assign(static_cast<size_t>(std::max(b.nextNode.load(), 1u)) * 16, 0.0f);
-        out.nodeCount = 1;
-        const uint32_t empty = ptrk::kRefEmpty;
-        std::memcpy(out.nodes.data() + 3, &empty, 4);
-        std::memcpy(out.nodes.data() + 7, &empty, 4);
+        out.triOrder.assign(root.triPrims, 0u);
+        out.sphereOrder.assign(root.spherePrims, 0u);
+        Stats total;
         if (root.count > 0) {  // whole scene fits one leaf: wrap it in a single-child root
-            setChild(0, 0, root.box, leafRef(root));
+            out.nodes.assign(16, 0.0f);
+            out.nodeCount = 1;
+            const uint32_t empty = ptrk::kRefEmpty;
+            std::memcpy(out.nodes.data() + 3, &empty, 4);
+            std::memcpy(out.nodes.data() + 7, &empty, 4);
+            setChild(0, 0, root.box, leafRef(root, 0u, 0u, total));
+            out.leafCount = total.leafCount;
+            out.maxLeafSize = total.maxLeafSize;
             out.maxDepth = 1;
             out.sahCost = root.count;
             return;
         }
-        std::vector<Item> stack{{0u, 0u, 0u}};
-        while (!stack.empty()) {
-            const Item it = stack.back();
-            stack.pop_back();
-            const TempNode& n = b.nodes[it.temp];
-            out.sahCost += n.box.halfArea() / rootArea;
-            const uint32_t kids[2] = {n.left, n.right};
-            uint32_t pendingDevice[2] = {0, 0};
-            bool internal[2] = {false, false};
-            for (int s = 0; s < 2; ++s) {
-                const TempNode& c = b.nodes[kids[s]];
-                if (c.count > 0) {
-                    setChild(it.device, s, c.box, leafRef(c));
-                    out.sahCost += (c.box.halfArea() / rootArea) * c.count;
-                    out.maxDepth = std::max(out.maxDepth, it.depth + 2);
-                } else {
-                    const uint32_t dev = out.nodeCount++;
-                    setChild(it.device, s, c.box, dev);
-                    pendingDevice[s] = dev;
-                    internal[s] = true;
+        out.nodeCount = root.internalNodes;
+        out.nodes.assign(static_cast<size_t>(out.nodeCount) * 16, 0.0f);
+        // the top of the tree serially (breadth first, until there are a few subtrees per thread), the subtrees in parallel
+        std::vector<Item> tasks{{0u, 0u, 0u, 0u, 0u}};
+        const size_t wanted = out.nodeCount >= (1u << 16) ? static_cast<size_t>(std::max(threads, 1u)) * 4u : 1u;
+        while (tasks.size() < wanted) {
+            // expand the largest subtree
+            size_t pick = 0;
+            for (size_t i = 1; i < tasks.size(); ++i) {
+                if (b.nodes[tasks[i].temp].internalNodes > b.nodes[tasks[pick].temp].internalNodes) pick = i;
+            }
+            if (b.nodes[tasks[pick].temp].internalNodes < 1024u) break;
+            const Item it = tasks[pick];
+            tasks.erase(tasks.begin() + static_cast<std::ptrdiff_t>(pick));
+            emit(it, rootArea, total, tasks);
+        }
+        std::vector<Stats> partial(tasks.size());
+        std::atomic<size_t> nextTask{0};
+        auto worker = [&]() {
+            std::vector<Item> stack;
+            while (true) {
+                const size_t t = nextTask.fetch_add(1);
+                if (t >= tasks.size()) break;
+                stack.assign(1, tasks[t]);
+                while (!stack.empty()) {
+                    const Item it = stack.back();
+                    stack.pop_back();
+                    emit(it, rootArea, partial[t], stack);
                 }
             }
-            if (internal[1]) stack.push_back({kids[1], pendingDevice[1], it.depth + 1});
-            if (internal[0]) stack.push_back({kids[0], pendingDevice[0], it.depth + 1});
+        };
+        const uint32_t workers = tasks.size() > 1 ? std::min<uint32_t>(std::max(threads, 1u), static_cast<uint32_t>(tasks.size())) : 1u;
+        std::vector<std::thread> pool;
+        for (uint32_t w = 1; w < workers; ++w) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
+        for (const Stats& p : partial) {   // in task order: the floating-point sum does not depend on the thread schedule
+            total.sahCost += p.sahCost;
+            total.leafCount += p.leafCount;
+            total.maxDepth = std::max(total.maxDepth, p.maxDepth);
+            total.maxLeafSize = std::max(total.maxLeafSize, p.maxLeafSize);
         }
+        out.sahCost = total.sahCost;
+        out.leafCount = total.leafCount;
+        out.maxDepth = total.maxDepth;
+        out.maxLeafSize = total.maxLeafSize;
     }
 };
 
@@ -364,6 +540,8 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
     b.nodes.resize(static_cast<size_t>(2) * inTree + 1);
     if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
     b.freeThreads = static_cast<int>(std::min(threads, 32u)) - 1;
+    b.wideThreads = std::min(threads, 32u);
+    if (inTree >= Builder::kWideNode) b.scratch.resize(n);
     const bool verbose = std::getenv("PTR_BUILD_VERBOSE") != nullptr;
     auto tick = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -386,10 +564,7 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
             f.primToTri[i] = tri++;
         }
     }
-    out.triOrder.reserve(tri);
-    out.sphereOrder.reserve(sph);
-    f.run(std::max(static_cast<double>(b.nodes[0].box.halfArea()), 1e-30));
-    out.nodes.resize(static_cast<size_t>(out.nodeCount) * 16);
+    f.run(std::max(static_cast<double>(b.nodes[0].box.halfArea()), 1e-30), std::min(threads, 32u));
     out.rootRef = 0u;
     if (oversizeCount > 0) {
         const uint32_t first = static_cast<uint32_t>(out.triOrder.size());

@@ -9,6 +9,7 @@
 
 #include "env_importance_sampler.h"
 #include "headless.h"
+#include "image_decoders.h"
 #include "image_writer.h"
 #include "ptr_abi.h"
 #include "ptr_debug.h"
@@ -151,6 +152,32 @@ int ptr_host_write_exr_aovs(const char* path, const float* linear_rgb, const flo
         if (!ptr::WriteExrAovs(path, linear_rgb, albedo_rgba, normal_rgba, width, height, &error)) {
             setErr(err, err_cap, error);
             return 1;
+        }
+        return 0;
+    });
+}
+
+int ptr_host_decode_image(const uint8_t* data, uint64_t size, uint8_t* out_rgba, uint64_t cap_bytes, uint32_t* width, uint32_t* height, char* err,
+                          size_t err_cap) {
+    return guarded(err, err_cap, [&]() -> int {
+        if (!data || !width || !height) {
+            setErr(err, err_cap, "ptr_host_decode_image: null argument");
+            return 1;
+        }
+        ptr::DecodedImage img;
+        std::string error;
+        if (!ptr::DecodeImage(data, static_cast<size_t>(size), img, &error)) {
+            setErr(err, err_cap, error);
+            return 1;
+        }
+        *width = img.width;
+        *height = img.height;
+        if (out_rgba) {
+            if (cap_bytes < img.rgba.size()) {
+                setErr(err, err_cap, "ptr_host_decode_image: output buffer too small");
+                return 1;
+            }
+            std::memcpy(out_rgba, img.rgba.data(), img.rgba.size());
         }
         return 0;
     });

@@ -4,11 +4,15 @@
 // (792-1237), how a material becomes a 576 B MaterialData of type PbrMetallicRoughness (650-788), how a
 // triangle primitive becomes a SceneResources mesh incl. area-weighted normals when NORMAL is absent
 // (1239-1466) and the depth-first node walk with column-major TRS composition (1468-1534).  Image decoding is
+// (textures: decoded by csrc/host/image_decoders.cpp and handed to SceneResources::addTexture; they are sampled only by the
+// Metal-semantics PBR model, PtrSettings.metalSemantics bit PTR_METAL_PBR - see below)
 // not done here: the parity oracle (the Embree backend) never samples material textures, so every texture slot
 // is recorded as "invalid" exactly as the reference leaves it when no Metal device exists
 // (SceneResources.mm:1279-1284); texture coordinate sets and KHR_texture_transform rows are still stored.
 // The JSON reader below replaces NSJSONSerialization.
 #include "gltf_loader.h"
+
+#include "image_decoders.h"
 
 #include <algorithm>
 #include <cctype>
@@ -397,7 +401,7 @@ struct SourceMaterial {
 };
 
 struct Primitive {
-    int material = -1, position = -1, normal = -1, texcoord = -1, indices = -1, mode = 4;
+    int material = -1, position = -1, normal = -1, texcoord = -1, texcoord1 = -1, tangent = -1, indices = -1, mode = 4;
 };
 
 struct MeshDef {
@@ -788,6 +792,87 @@ bool LoadGltfScene(const std::string& path, SceneResources& resources, std::stri
         }
     }
 
+    // ---- textures (GltfLoader.mm ResolveTextureIndex, 560-648): image bytes from a buffer view, a data URI or a file next to the
+    // document; decoded here (PNG / baseline JPEG), converted to linear floats (base colour and emissive are sRGB-encoded) and
+    // registered once per (image, sampler, encoding).  A texture that cannot be read is reported and left unbound.
+    struct SamplerDef {
+        uint32_t wrapS = 0, wrapT = 0, filter = 1;
+    };
+    struct TextureDef {
+        int source = -1, sampler = -1;
+    };
+    struct ImageDef {
+        int view = -1;
+        std::string uri;
+    };
+    std::vector<SamplerDef> samplers;
+    std::vector<TextureDef> textureDefs;
+    std::vector<ImageDef> images;
+    auto wrapOf = [](int gl) -> uint32_t { return gl == 33071 ? 1u : (gl == 33648 ? 2u : 0u); };
+    if (const Json* arr = root.array("samplers")) {
+        samplers.resize(arr->items.size());
+        for (size_t i = 0; i < arr->items.size(); ++i) {
+            samplers[i].wrapS = wrapOf(arr->items[i].intOr("wrapS", 10497));
+            samplers[i].wrapT = wrapOf(arr->items[i].intOr("wrapT", 10497));
+            samplers[i].filter = arr->items[i].intOr("magFilter", 9729) == 9728 ? 0u : 1u;
+        }
+    }
+    if (const Json* arr = root.array("textures")) {
+        textureDefs.resize(arr->items.size());
+        for (size_t i = 0; i < arr->items.size(); ++i) {
+            textureDefs[i].source = arr->items[i].intOr("source", -1);
+            textureDefs[i].sampler = arr->items[i].intOr("sampler", -1);
+        }
+    }
+    if (const Json* arr = root.array("images")) {
+        images.resize(arr->items.size());
+        for (size_t i = 0; i < arr->items.size(); ++i) {
+            images[i].view = arr->items[i].intOr("bufferView", -1);
+            images[i].uri = arr->items[i].stringOr("uri");
+        }
+    }
+    std::vector<std::pair<uint64_t, uint32_t>> textureCache;   // (texture index << 1 | srgb) -> registered texture
+    std::vector<DecodedImage> decodedImages(images.size());
+    std::vector<int> decodeState(images.size(), 0);            // 0 not tried, 1 ok, -1 failed
+    auto resolveTexture = [&](int textureIndex, bool srgb) -> uint32_t {
+        if (!options.loadTextures || textureIndex < 0 || textureIndex >= static_cast<int>(textureDefs.size())) return kNoTexture;
+        const uint64_t key = (static_cast<uint64_t>(textureIndex) << 1) | (srgb ? 1u : 0u);
+        for (const auto& e : textureCache) {
+            if (e.first == key) return e.second;
+        }
+        const TextureDef& t = textureDefs[static_cast<size_t>(textureIndex)];
+        if (t.source < 0 || t.source >= static_cast<int>(images.size())) return kNoTexture;
+        const size_t im = static_cast<size_t>(t.source);
+        if (decodeState[im] == 0) {
+            std::vector<uint8_t> bytes;
+            const uint8_t* data = nullptr;
+            size_t size = 0;
+            if (images[im].view >= 0 && images[im].view < static_cast<int>(doc.views.size())) {
+                const BufferView& v = doc.views[static_cast<size_t>(images[im].view)];
+                if (v.buffer >= 0 && v.buffer < static_cast<int>(doc.buffers.size()) && v.offset + v.length <= doc.buffers[static_cast<size_t>(v.buffer)].size()) {
+                    data = doc.buffers[static_cast<size_t>(v.buffer)].data() + v.offset;
+                    size = v.length;
+                }
+            } else if (!images[im].uri.empty()) {
+                std::string readError;
+                if (decodeDataUri(images[im].uri, bytes) || readFileBytes(gltfPath.parent_path() / images[im].uri, bytes, readError)) {
+                    data = bytes.data();
+                    size = bytes.size();
+                }
+            }
+            std::string decodeError = "no image data";
+            decodeState[im] = (data && DecodeImage(data, size, decodedImages[im], &decodeError)) ? 1 : -1;
+            if (decodeState[im] < 0) std::fprintf(stderr, "[glTF] image %zu not loaded: %s\n", im, decodeError.c_str());
+        }
+        if (decodeState[im] < 0) return kNoTexture;
+        SamplerDef sampler;
+        if (t.sampler >= 0 && t.sampler < static_cast<int>(samplers.size())) sampler = samplers[static_cast<size_t>(t.sampler)];
+        const DecodedImage& img = decodedImages[im];
+        const uint32_t index = resources.addTexture(img.rgba.data(), img.width, img.height, srgb, sampler.wrapS, sampler.wrapT, sampler.filter);
+        textureCache.push_back({key, index});
+        return index;
+    };
+
     // materials: a document without any still gets one default material (all factors 1, GltfLoader.mm:1061-1063)
     std::vector<SourceMaterial> materials;
     if (const Json* arr = root.array("materials")) {
@@ -800,7 +885,15 @@ bool LoadGltfScene(const std::string& path, SceneResources& resources, std::stri
     std::vector<uint32_t> materialMap(materials.size(), 0u);
     for (size_t i = 0; i < materials.size(); ++i) {
         materials[i].disableOrm = containsNoCase(materials[i].name, "visor");   // quirk Q7
-        materialMap[i] = resources.addMaterialData(buildMaterial(materials[i], options), materials[i].name);
+        PtrMaterial built = buildMaterial(materials[i], options);
+        // texture slots (GltfLoader.mm:700-747): base colour and emissive are sRGB-encoded, the rest is linear data
+        built.textureIndices0[0] = resolveTexture(materials[i].baseColorTex.index, !options.forceLinearBaseColor);
+        built.textureIndices0[1] = resolveTexture(materials[i].metalRoughTex.index, false);
+        built.textureIndices0[2] = resolveTexture(materials[i].normalTex.index, false);
+        built.textureIndices0[3] = resolveTexture(materials[i].occlusionTex.index, false);
+        built.textureIndices1[0] = resolveTexture(materials[i].emissiveTex.index, !options.forceLinearEmissive);
+        built.textureIndices1[1] = resolveTexture(materials[i].transmissionTex.index, false);
+        materialMap[i] = resources.addMaterialData(built, materials[i].name);
     }
 
     std::vector<MeshDef> meshes;
@@ -820,6 +913,8 @@ bool LoadGltfScene(const std::string& path, SceneResources& resources, std::stri
                     p.position = attrs->intOr("POSITION", -1);
                     p.normal = attrs->intOr("NORMAL", -1);
                     p.texcoord = attrs->intOr("TEXCOORD_0", -1);
+                    p.texcoord1 = attrs->intOr("TEXCOORD_1", -1);
+                    p.tangent = attrs->intOr("TANGENT", -1);
                 }
                 meshes[i].primitives.push_back(p);
             }
@@ -921,8 +1016,14 @@ bool LoadGltfScene(const std::string& path, SceneResources& resources, std::stri
             growSceneBounds(lo, hi);
         }
 
-        std::vector<float> normals, uvs;
-        bool hasNormals = false, hasUvs = false;
+        std::vector<float> normals, uvs, uvs1, tangents;
+        bool hasNormals = false, hasUvs = false, hasUvs1 = false, hasTangents = false;
+        if (prim.texcoord1 >= 0 && prim.texcoord1 < static_cast<int>(doc.accessors.size())) {
+            hasUvs1 = doc.readFloats(doc.accessors[static_cast<size_t>(prim.texcoord1)], 2, uvs1) && uvs1.size() >= vertexCount * 2;
+        }
+        if (prim.tangent >= 0 && prim.tangent < static_cast<int>(doc.accessors.size())) {
+            hasTangents = doc.readFloats(doc.accessors[static_cast<size_t>(prim.tangent)], 4, tangents) && tangents.size() >= vertexCount * 4;
+        }
         if (prim.normal >= 0 && prim.normal < static_cast<int>(doc.accessors.size())) {
             hasNormals = doc.readFloats(doc.accessors[static_cast<size_t>(prim.normal)], 3, normals) && normals.size() >= vertexCount * 3;
         }
@@ -946,6 +1047,8 @@ bool LoadGltfScene(const std::string& path, SceneResources& resources, std::stri
             v.position = {positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]};
             if (hasNormals) v.normal = {normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]};
             if (hasUvs) v.uv = {uvs[2 * i], uvs[2 * i + 1]};
+            if (hasUvs1) v.uv1 = {uvs1[2 * i], uvs1[2 * i + 1]};
+            if (hasTangents) v.tangent = {tangents[4 * i], tangents[4 * i + 1], tangents[4 * i + 2], tangents[4 * i + 3] < 0.0f ? -1.0f : 1.0f};
         }
         if (!hasNormals) {
             // area-weighted vertex normals; vertices no valid triangle touches keep the default (0,1,0)
@@ -966,8 +1069,14 @@ bool LoadGltfScene(const std::string& path, SceneResources& resources, std::stri
         }
         uint32_t materialIndex = 0u;
         if (prim.material >= 0 && prim.material < static_cast<int>(materialMap.size())) materialIndex = materialMap[static_cast<size_t>(prim.material)];
-        resources.addMesh(vertices.data(), static_cast<uint32_t>(vertices.size()), indices.data(), static_cast<uint32_t>(indices.size()),
-                          localToWorld, materialIndex, name);
+        const uint32_t meshIndex = resources.addMesh(vertices.data(), static_cast<uint32_t>(vertices.size()), indices.data(),
+                                                     static_cast<uint32_t>(indices.size()), localToWorld, materialIndex, name);
+        // texture coordinates / tangents travel with the mesh (a mesh without tangents gets its tangent frame per triangle from the
+        // UV derivatives, like the reference kernel when SceneVertex::tangent.w is 0 - shaders/pathtrace.metal:843-911)
+        SceneResources::Mesh& stored = resources.meshAt(meshIndex);
+        stored.hasUv0 = hasUvs;
+        stored.hasUv1 = hasUvs1;
+        stored.hasTangents = hasTangents;
         return true;
     };
 

@@ -1,5 +1,6 @@
-// glTF 2.0 / GLB loader: geometry + factor-only PBR materials (what the Embree oracle sees; textures are
-// never sampled on that path).  Interface follows the reference's
+// glTF 2.0 / GLB loader: geometry, metallic-roughness materials and their textures.  The Embree-parity integrator reads the
+// factors only (textures are never sampled on that path); the Metal-semantics PBR model
+// (PTR_METAL_PBR) samples the textures the loader decodes (PNG / baseline JPEG, csrc/host/image_decoders.h).  Interface follows the reference's
 // include/assets/GltfLoader.h; behaviour follows src/assets/GltfLoader.mm:650-788, 792-1535.
 #pragma once
 
@@ -22,6 +23,9 @@ struct GltfCameraInfo {
 
 struct GltfLoadOptions {
     float emissiveScale = 1.0f;
+    bool loadTextures = true;           // decode and register material textures
+    bool forceLinearBaseColor = false;  // GltfLoadOptions of the reference: treat the base colour / emissive images as linear data
+    bool forceLinearEmissive = false;
 };
 
 bool LoadGltfScene(const std::string& path, SceneResources& resources, std::string& error,

@@ -113,7 +113,9 @@ struct PtrDeviceScene {
     DeviceBuffer<float4> nodes, tris, triNormals, spheres, materials, rects, rectLights, envRgba;
     DeviceBuffer<uint2> sphereInfo;
     DeviceBuffer<int32_t> lightIndexByRect;
-    DeviceBuffer<float2> envCond, envMarg;
+    DeviceBuffer<float2> envCond, envMarg, cone;
+    DeviceBuffer<float4> triUv, triTangent, texels, materialTex;
+    DeviceBuffer<uint4> texInfo;
     DeviceBuffer<float> envPdf;
     SceneView view{};
     uint64_t info[8] = {0};
@@ -169,7 +171,8 @@ constexpr uint32_t kAliveRing = 16;
 constexpr uint32_t kAliveBase = 4;
 constexpr uint32_t kScalarCount = kAliveBase + kAliveRing;
 constexpr uint32_t kMaxPoolGroups = 8;        // one block of scalars / one spill area per group
-constexpr uint32_t kPinnedHeadsOffset = 16;   // pinned staging: [0..15] per-group live-slot counts, then kItemHeads range heads
+constexpr uint32_t kPinnedHeadsOffset = 16;
+constexpr uint32_t kTexInfoWords = 20;   // kernels/texture.h kTexInfoVec4 uint4 per texture   // pinned staging: [0..15] per-group live-slot counts, then kItemHeads range heads
 
 // Stack spill area of one pool group: the larger of the one-ray layout (levels beyond kLdsStackLevels, one column per thread of
 // the persistent grid) and the two-ray layout (levels beyond kDualLdsLevels, two columns per thread).
@@ -203,8 +206,51 @@ struct PreparedScene {
     bool hasRandomWalkMaterial = false;
     ptr::EnvImportanceDistribution envDist;
     bool hasEnvDist = false;
+    // material textures (kernels/texture.h): every level of every texture in one array, the per-texture records, and the
+    // per-material texture records; empty when the scene has no textures
+    std::vector<float> texels;
+    std::vector<uint32_t> texInfo;
+    std::vector<float> materialTex;
     double seconds = 0.0;
 };
+
+// Mip chain of one texture appended to `texels`: level l + 1 halves both sizes (at least 1) and averages the 2x2 block of level
+// l under each of its texels, the second tap clamped at the edge of odd-sized levels; sums in the order ((a + b) + (c + d)) * 0.25.
+void appendTextureWithMips(const PtrTexture& t, std::vector<float>& texels, std::vector<uint32_t>& info) {
+    uint32_t w = t.width, h = t.height, levels = 1;
+    for (uint32_t a = w, b = h; a > 1u || b > 1u; a = std::max(a / 2u, 1u), b = std::max(b / 2u, 1u)) ++levels;
+    levels = std::min(levels, 16u);
+    const size_t head = info.size();
+    info.resize(head + kTexInfoWords, 0u);
+    info[head + 0] = t.width;
+    info[head + 1] = t.height;
+    info[head + 2] = levels;
+    info[head + 3] = (t.wrapS & 3u) | ((t.wrapT & 3u) << 2) | ((t.filter ? 1u : 0u) << 4);
+    size_t prev = texels.size() / 4u;
+    info[head + 4] = static_cast<uint32_t>(prev);
+    texels.insert(texels.end(), t.rgba, t.rgba + static_cast<size_t>(w) * h * 4u);
+    for (uint32_t l = 1; l < levels; ++l) {
+        const uint32_t nw = std::max(w / 2u, 1u), nh = std::max(h / 2u, 1u);
+        const size_t at = texels.size() / 4u;
+        info[head + 4 + l] = static_cast<uint32_t>(at);
+        texels.resize(texels.size() + static_cast<size_t>(nw) * nh * 4u);
+        for (uint32_t y = 0; y < nh; ++y) {
+            const uint32_t y0 = std::min(2u * y, h - 1u), y1 = std::min(2u * y + 1u, h - 1u);
+            for (uint32_t x = 0; x < nw; ++x) {
+                const uint32_t x0 = std::min(2u * x, w - 1u), x1 = std::min(2u * x + 1u, w - 1u);
+                const float* a = &texels[(prev + static_cast<size_t>(y0) * w + x0) * 4u];
+                const float* b = &texels[(prev + static_cast<size_t>(y0) * w + x1) * 4u];
+                const float* c = &texels[(prev + static_cast<size_t>(y1) * w + x0) * 4u];
+                const float* d = &texels[(prev + static_cast<size_t>(y1) * w + x1) * 4u];
+                float* o = &texels[(at + static_cast<size_t>(y) * nw + x) * 4u];
+                for (int ch = 0; ch < 4; ++ch) o[ch] = ((a[ch] + b[ch]) + (c[ch] + d[ch])) * 0.25f;
+            }
+        }
+        prev = at;
+        w = nw;
+        h = nh;
+    }
+}
 
 void prepareScene(const PtrSceneDesc& desc, PreparedScene& ps) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -241,6 +287,28 @@ void prepareScene(const PtrSceneDesc& desc, PreparedScene& ps) {
     }
     if (desc.envRgba && desc.envWidth > 0 && desc.envHeight > 0) {
         ps.hasEnvDist = ptr::BuildEnvImportanceDistribution(desc.envRgba, desc.envWidth, desc.envHeight, &ps.envDist);
+    }
+    if (desc.textures && desc.textureCount > 0 && !ps.geo.triUv.empty()) {
+        for (uint32_t i = 0; i < desc.textureCount; ++i) {
+            if (!desc.textures[i].rgba || desc.textures[i].width == 0 || desc.textures[i].height == 0) throw HipError{"texture without pixels"};
+            appendTextureWithMips(desc.textures[i], ps.texels, ps.texInfo);
+            if (ps.texels.size() / 4u > 0xFFFFFFF0ull) throw HipError{"textures exceed the 4 G texel limit"};
+        }
+        ps.materialTex.assign(static_cast<size_t>(desc.materialCount) * kMaterialTexVec4 * 4u, 0.0f);
+        for (uint32_t i = 0; i < desc.materialCount; ++i) {
+            const PtrMaterial& m = desc.materials[i];
+            float* o = &ps.materialTex[static_cast<size_t>(i) * kMaterialTexVec4 * 4u];
+            for (int r = 0; r < 12; ++r) std::memcpy(o + r * 4, m.textureTransform[r], 16);
+            for (int k = 0; k < 4; ++k) o[48 + k] = bitsToFloat(m.textureIndices0[k]);
+            o[52] = bitsToFloat(m.textureIndices1[0]);
+            o[53] = bitsToFloat(m.textureIndices1[1]);
+            const uint32_t uvSets = (std::min(m.textureUvSet0[0], 1u) << 0) | (std::min(m.textureUvSet0[1], 1u) << 1) | (std::min(m.textureUvSet0[2], 1u) << 2) |
+                                    (std::min(m.textureUvSet0[3], 1u) << 3) | (std::min(m.textureUvSet1[0], 1u) << 4) | (std::min(m.textureUvSet1[1], 1u) << 5);
+            o[54] = bitsToFloat(uvSets);
+            o[55] = bitsToFloat(m.materialFlags);
+            std::memcpy(o + 56, m.pbrParams, 16);
+            std::memcpy(o + 60, m.pbrExtras, 16);
+        }
     }
     ps.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -313,6 +381,20 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
             v.envPdf = ds.envPdf.ptr;
             v.envSampling = 1u;
         }
+    }
+
+    if (!ps.texels.empty()) {
+        ds.triUv.upload(reinterpret_cast<const float4*>(geo.triUv.data()), geo.triUv.size() / 4);
+        ds.triTangent.upload(reinterpret_cast<const float4*>(geo.triTangent.data()), geo.triTangent.size() / 4);
+        ds.texels.upload(reinterpret_cast<const float4*>(ps.texels.data()), ps.texels.size() / 4);
+        ds.texInfo.upload(reinterpret_cast<const uint4*>(ps.texInfo.data()), ps.texInfo.size() / 4);
+        ds.materialTex.upload(reinterpret_cast<const float4*>(ps.materialTex.data()), ps.materialTex.size() / 4);
+        v.triUv = ds.triUv.ptr;
+        v.triTangent = ds.triTangent.ptr;
+        v.texels = ds.texels.ptr;
+        v.texInfo = ds.texInfo.ptr;
+        v.materialTex = ds.materialTex.ptr;
+        v.textureCount = desc.textureCount;
     }
 
     ds.info[0] = bvh.nodeCount;
@@ -556,6 +638,8 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
     ds.recBuf.ensure(static_cast<size_t>(slots) * kRecSlots * 4u);
     ds.itemReserve.ensure((slots + 63u) / 64u);
     if (rp.mediaMode & PTR_METAL_MEDIA) ds.medium.ensure(slots);
+    const bool texturedPaths = (rp.mediaMode & PTR_METAL_PBR) && ds.view.textureCount > 0u;   // the paths carry a ray cone
+    if (texturedPaths) ds.cone.ensure(slots);
 
     PathPool pool;
     std::memset(&pool, 0, sizeof(pool));
@@ -568,6 +652,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
     pool.flushItem = ds.flushItem.ptr;
     pool.signature = count ? ds.signature.ptr : nullptr;
     pool.medium = (rp.mediaMode & PTR_METAL_MEDIA) ? ds.medium.ptr : nullptr;
+    pool.cone = texturedPaths ? ds.cone.ptr : nullptr;
     pool.itemAccum = ds.itemAccum.ptr;
     ds.itemHeads.ensure(kItemHeadWords);
     pool.nextItem = ds.itemHeads.ptr;
@@ -626,6 +711,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         gr.pool.flushItem += first;
         if (gr.pool.signature) gr.pool.signature += first;
         if (gr.pool.medium) gr.pool.medium += first;
+        if (gr.pool.cone) gr.pool.cone += first;
         for (uint32_t k = 0; k < kRecSlots; ++k) {
             gr.pool.rec[k].org += first;
             gr.pool.rec[k].dir += first;
@@ -1268,6 +1354,26 @@ int ptr_debug_render_signatures(PtrDeviceScene* scene, const PtrSettings* settin
             std::memcpy(&bits, &items[lp].w, sizeof(bits));
             out_signature[pixelOfLocal[lp]] = bits;
         }
+        return 0;
+    }
+    PTR_CATCH_ALL(err, err_cap)
+}
+
+int ptr_debug_texture_sample(PtrDeviceScene* scene, uint32_t texture, const float* in, uint64_t n, float* out, char* err, size_t err_cap) {
+    if (!scene || (!in && n) || (!out && n)) {
+        setErr(err, err_cap, "ptr_debug_texture_sample: null argument");
+        return 1;
+    }
+    try {
+        HIP_CHECK(hipSetDevice(scene->device));
+        if (n == 0) return 0;
+        DeviceBuffer<float> din;
+        DeviceBuffer<float4> dout;
+        din.upload(in, n * 3);
+        dout.ensure(n);
+        launchDebugTexSample(scene->view, texture, din.ptr, n, dout.ptr, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(out, dout.ptr, n * sizeof(float4), hipMemcpyDeviceToHost));
         return 0;
     }
     PTR_CATCH_ALL(err, err_cap)

@@ -138,6 +138,16 @@ bool BuildSceneGeometry(const PtrSceneDesc& desc, uint32_t leafMax, SceneGeometr
     const uint32_t triCount = static_cast<uint32_t>(triTotal);
     std::vector<float> triIn(static_cast<size_t>(triCount) * 12), nrmIn(static_cast<size_t>(triCount) * 12);
     std::vector<BuildPrim> prims(static_cast<size_t>(triCount) + desc.sphereCount);
+    // texture attributes, input order (textured scenes only): see SceneGeometry::triUv / triTangent
+    bool textured = false;
+    if (desc.textures && desc.textureCount > 0) {
+        for (uint32_t mi = 0; mi < desc.meshCount; ++mi) textured = textured || desc.meshes[mi].uv0 != nullptr || desc.meshes[mi].uv1 != nullptr;
+    }
+    std::vector<float> uvIn, tanIn;
+    if (textured) {
+        uvIn.assign(static_cast<size_t>(triCount) * 16, 0.0f);
+        tanIn.assign(static_cast<size_t>(triCount) * 12, 0.0f);
+    }
 
     // meshes: baked to world space, normals through the inverse-transpose (EmbreeHeadlessRenderer.mm:2100-2166)
     size_t cursor = 0;
@@ -147,6 +157,10 @@ bool BuildSceneGeometry(const PtrSceneDesc& desc, uint32_t leafMax, SceneGeometr
         if (mesh.vertexCount == 0 || mesh.indexCount == 0) continue;
         const M4 l2w = loadM4(mesh.localToWorld);
         const M4 w2l = inverse(l2w);
+        const float det3 = l2w.m[0][0] * (l2w.m[1][1] * l2w.m[2][2] - l2w.m[2][1] * l2w.m[1][2]) -
+                           l2w.m[1][0] * (l2w.m[0][1] * l2w.m[2][2] - l2w.m[2][1] * l2w.m[0][2]) +
+                           l2w.m[2][0] * (l2w.m[0][1] * l2w.m[1][2] - l2w.m[1][1] * l2w.m[0][2]);
+        const float detSign = det3 < 0.0f ? -1.0f : 1.0f;
         const float3 nc0{w2l.m[0][0], w2l.m[1][0], w2l.m[2][0]};
         const float3 nc1{w2l.m[0][1], w2l.m[1][1], w2l.m[2][1]};
         const float3 nc2{w2l.m[0][2], w2l.m[1][2], w2l.m[2][2]};
@@ -171,6 +185,54 @@ bool BuildSceneGeometry(const PtrSceneDesc& desc, uint32_t leafMax, SceneGeometr
                 const size_t k = base + t;
                 storeTri(&triIn[k * 12], &nrmIn[k * 12], prims[k], pos[i0], pos[i1], pos[i2], nrm[i0], nrm[i1], nrm[i2],
                          mesh.materialIndex, 0u, mi, static_cast<uint32_t>(t));
+                if (textured) {
+                    const uint32_t vi[3] = {i0, i1, i2};
+                    float* uv = &uvIn[k * 16];
+                    float* tg = &tanIn[k * 12];
+                    for (int c = 0; c < 3; ++c) {
+                        if (mesh.uv0) {
+                            uv[c * 4 + 0] = mesh.uv0[2 * vi[c]];
+                            uv[c * 4 + 1] = mesh.uv0[2 * vi[c] + 1];
+                        }
+                        if (mesh.uv1) {
+                            uv[c * 4 + 2] = mesh.uv1[2 * vi[c]];
+                            uv[c * 4 + 3] = mesh.uv1[2 * vi[c] + 1];
+                        }
+                        if (mesh.tangents) {
+                            // world-space tangent: the linear part of localToWorld (interpolate_tangent, shaders/pathtrace.metal:693-739)
+                            const float* tl = mesh.tangents + 4 * vi[c];
+                            tg[c * 4 + 0] = (l2w.m[0][0] * tl[0] + l2w.m[1][0] * tl[1]) + l2w.m[2][0] * tl[2];
+                            tg[c * 4 + 1] = (l2w.m[0][1] * tl[0] + l2w.m[1][1] * tl[1]) + l2w.m[2][1] * tl[2];
+                            tg[c * 4 + 2] = (l2w.m[0][2] * tl[0] + l2w.m[1][2] * tl[1]) + l2w.m[2][2] * tl[2];
+                            tg[c * 4 + 3] = tl[3] == 0.0f ? 0.0f : (tl[3] < 0.0f ? -1.0f : 1.0f) * detSign;
+                        }
+                    }
+                    // uv-per-world of both sets (triangle_surface_partials, shaders/pathtrace.metal:741-820) in world space
+                    const float3 edge1 = pos[i1] - pos[i0], edge2 = pos[i2] - pos[i0];
+                    for (int set = 0; set < 2; ++set) {
+                        const float du1 = uv[4 + set * 2] - uv[set * 2], dv1 = uv[4 + set * 2 + 1] - uv[set * 2 + 1];
+                        const float du2 = uv[8 + set * 2] - uv[set * 2], dv2 = uv[8 + set * 2 + 1] - uv[set * 2 + 1];
+                        const float det = du1 * dv2 - dv1 * du2;
+                        float perWorld = 0.0f;
+                        bool done = false;
+                        if (std::fabs(det) > 1.0e-9f) {
+                            const float inv = 1.0f / det;
+                            const float3 dPdu = (edge1 * dv2 - edge2 * dv1) * inv, dPdv = (edge2 * du1 - edge1 * du2) * inv;
+                            const float lenU = length(dPdu), lenV = length(dPdv);
+                            if (lenU > 1.0e-8f && lenV > 1.0e-8f) {
+                                perWorld = std::max(1.0f / lenU, 1.0f / lenV);
+                                done = std::isfinite(perWorld) && perWorld > 0.0f;
+                            }
+                        }
+                        if (!done) {
+                            const float worldArea = length(cross(edge1, edge2)), uvArea = std::fabs(det);
+                            perWorld = (worldArea > 1.0e-12f && uvArea > 1.0e-12f) ? std::sqrt(uvArea / worldArea) : 0.0f;
+                            if (!std::isfinite(perWorld)) perWorld = 0.0f;
+                        }
+                        uv[12 + set] = perWorld;
+                    }
+                    uv[14] = detSign;
+                }
             }
         });
         cursor += meshTris;
@@ -229,6 +291,16 @@ bool BuildSceneGeometry(const PtrSceneDesc& desc, uint32_t leafMax, SceneGeometr
             std::memcpy(&out.triNormals[k * 12], &nrmIn[static_cast<size_t>(order[k]) * 12], 48);
         }
     });
+    if (textured) {
+        out.triUv.resize(static_cast<size_t>(triCount) * 16);
+        out.triTangent.resize(static_cast<size_t>(triCount) * 12);
+        parallelFor(order.size(), [&](size_t b, size_t e) {
+            for (size_t k = b; k < e; ++k) {
+                std::memcpy(&out.triUv[k * 16], &uvIn[static_cast<size_t>(order[k]) * 16], 64);
+                std::memcpy(&out.triTangent[k * 12], &tanIn[static_cast<size_t>(order[k]) * 12], 48);
+            }
+        });
+    }
     for (uint32_t idx : out.bvh.sphereOrder) {
         const PtrSphere& s = desc.spheres[idx];
         out.sphereData.insert(out.sphereData.end(), s.centerRadius, s.centerRadius + 4);

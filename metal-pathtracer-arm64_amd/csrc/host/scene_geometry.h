@@ -22,6 +22,9 @@ struct SceneGeometry {
     std::vector<float> triNormals;   // 12 floats per triangle in leaf order: world-space vertex normals
     std::vector<float> sphereData;   // 4 floats per sphere in leaf order: centre, radius
     std::vector<uint32_t> sphereInfo;  // 2 words per sphere in leaf order: original index, material
+    // textured scenes only (desc.textureCount > 0 and some mesh carries texture coordinates); leaf order:
+    std::vector<float> triUv;        // 16 floats per triangle: (uv0, uv1) of the three vertices, then (uvPerWorld0, uvPerWorld1, sign of det(localToWorld), 0)
+    std::vector<float> triTangent;   // 12 floats per triangle: world-space vertex tangents, w = handedness x sign of det (0: no tangent)
     uint32_t triCount = 0, sphereCount = 0;
     double gatherSeconds = 0.0, buildSeconds = 0.0, flattenSeconds = 0.0;
 };

@@ -80,6 +80,7 @@ void SceneResources::clear() {
     m_materials.clear();
     m_materialNames.clear();
     m_meshes.clear();
+    m_textures.clear();
     m_envRgba.clear();
     m_envWidth = 0;
     m_envHeight = 0;
@@ -354,6 +355,31 @@ void SceneResources::setEnvironmentPixels(std::vector<float> rgba, uint32_t widt
     m_envHeight = height;
 }
 
+uint32_t SceneResources::addTexture(const uint8_t* rgba8, uint32_t width, uint32_t height, bool srgb, uint32_t wrapS, uint32_t wrapT,
+                                    uint32_t filter) {
+    Texture t;
+    t.width = width;
+    t.height = height;
+    t.wrapS = std::min(wrapS, 2u);
+    t.wrapT = std::min(wrapT, 2u);
+    t.filter = filter ? 1u : 0u;
+    // 8-bit -> float through a 256-entry table; the sRGB transfer function is the piecewise IEC 61966-2-1 one
+    float linear[256], plain[256];
+    for (int i = 0; i < 256; ++i) {
+        const float c = static_cast<float>(i) / 255.0f;
+        plain[i] = c;
+        linear[i] = c <= 0.04045f ? c / 12.92f : std::pow((c + 0.055f) / 1.055f, 2.4f);
+    }
+    const size_t n = static_cast<size_t>(width) * height;
+    t.rgba.resize(n * 4u);
+    for (size_t i = 0; i < n; ++i) {
+        for (int c = 0; c < 3; ++c) t.rgba[i * 4 + c] = (srgb ? linear : plain)[rgba8[i * 4 + c]];
+        t.rgba[i * 4 + 3] = plain[rgba8[i * 4 + 3]];
+    }
+    m_textures.push_back(std::move(t));
+    return static_cast<uint32_t>(m_textures.size() - 1u);
+}
+
 void SceneResources::fillSceneDesc(PtrSceneDesc& desc) const {
     std::memset(&desc, 0, sizeof(desc));
     desc.spheres = m_spheres.empty() ? nullptr : m_spheres.data();
@@ -366,6 +392,9 @@ void SceneResources::fillSceneDesc(PtrSceneDesc& desc) const {
     m_meshDescs.clear();
     m_meshPositions.assign(m_meshes.size(), {});
     m_meshNormals.assign(m_meshes.size(), {});
+    m_meshUv0.assign(m_meshes.size(), {});
+    m_meshUv1.assign(m_meshes.size(), {});
+    m_meshTangents.assign(m_meshes.size(), {});
     for (size_t i = 0; i < m_meshes.size(); ++i) {
         const Mesh& mesh = m_meshes[i];
         auto& pos = m_meshPositions[i];
@@ -394,10 +423,49 @@ void SceneResources::fillSceneDesc(PtrSceneDesc& desc) const {
             d.localToWorld[c * 4 + 3] = mesh.localToWorld.columns[c].w;
         }
         d.materialIndex = mesh.materialIndex;
+        if (mesh.hasUv0 || mesh.hasUv1) {
+            auto& a = m_meshUv0[i];
+            auto& b = m_meshUv1[i];
+            a.resize(mesh.vertices.size() * 2);
+            b.resize(mesh.vertices.size() * 2);
+            for (size_t v = 0; v < mesh.vertices.size(); ++v) {
+                a[v * 2] = mesh.vertices[v].uv.x;
+                a[v * 2 + 1] = mesh.vertices[v].uv.y;
+                b[v * 2] = mesh.vertices[v].uv1.x;
+                b[v * 2 + 1] = mesh.vertices[v].uv1.y;
+            }
+            if (mesh.hasUv0) d.uv0 = a.data();
+            if (mesh.hasUv1) d.uv1 = b.data();
+        }
+        if (mesh.hasTangents) {
+            auto& t = m_meshTangents[i];
+            t.resize(mesh.vertices.size() * 4);
+            for (size_t v = 0; v < mesh.vertices.size(); ++v) {
+                t[v * 4] = mesh.vertices[v].tangent.x;
+                t[v * 4 + 1] = mesh.vertices[v].tangent.y;
+                t[v * 4 + 2] = mesh.vertices[v].tangent.z;
+                t[v * 4 + 3] = mesh.vertices[v].tangent.w;
+            }
+            d.tangents = t.data();
+        }
         m_meshDescs.push_back(d);
     }
     desc.meshes = m_meshDescs.empty() ? nullptr : m_meshDescs.data();
     desc.meshCount = static_cast<uint32_t>(m_meshDescs.size());
+    m_textureDescs.clear();
+    for (const Texture& t : m_textures) {
+        PtrTexture d;
+        std::memset(&d, 0, sizeof(d));
+        d.rgba = t.rgba.data();
+        d.width = t.width;
+        d.height = t.height;
+        d.wrapS = t.wrapS;
+        d.wrapT = t.wrapT;
+        d.filter = t.filter;
+        m_textureDescs.push_back(d);
+    }
+    desc.textures = m_textureDescs.empty() ? nullptr : m_textureDescs.data();
+    desc.textureCount = static_cast<uint32_t>(m_textureDescs.size());
     if (!m_envRgba.empty() && m_envWidth > 0 && m_envHeight > 0) {
         desc.envRgba = m_envRgba.data();
         desc.envWidth = m_envWidth;

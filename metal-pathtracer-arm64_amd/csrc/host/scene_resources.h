@@ -76,6 +76,17 @@ public:
         float3 position{0.0f, 0.0f, 0.0f};
         float3 normal{0.0f, 1.0f, 0.0f};
         float2 uv{};
+        float2 uv1{};
+        float4 tangent{0.0f, 0.0f, 0.0f, 0.0f};   // object space, w = handedness; w = 0: the mesh has no tangents
+    };
+
+    // A material texture as the device and the oracle consume it: level 0, linear RGBA floats, with its sampler state
+    // (the CPU half of SceneResources::materialTextures / MaterialTextureInfo, src/renderer/SceneResources.mm:213-420).
+    struct Texture {
+        std::vector<float> rgba;
+        uint32_t width = 0, height = 0;
+        uint32_t wrapS = 0, wrapT = 0;   // 0 repeat, 1 clamp to edge, 2 mirrored repeat
+        uint32_t filter = 1;             // 0 nearest, 1 linear
     };
 
     struct Mesh {
@@ -84,9 +95,15 @@ public:
         float4x4 localToWorld = float4x4::identity();
         uint32_t materialIndex = 0;
         std::string name;
+        bool hasUv0 = false, hasUv1 = false, hasTangents = false;
     };
 
     void clear();
+
+    // 8-bit RGBA pixels (row 0 = top) -> linear float texture; srgb: the colour channels are sRGB-encoded (base colour, emissive)
+    uint32_t addTexture(const uint8_t* rgba8, uint32_t width, uint32_t height, bool srgb, uint32_t wrapS, uint32_t wrapT, uint32_t filter);
+    const std::vector<Texture>& textures() const { return m_textures; }
+    Mesh& meshAt(uint32_t index) { return m_meshes[index]; }
 
     uint32_t addMaterial(const MaterialParams& params);
     // Raw MaterialData (glTF path: BuildGltfMaterial -> addMaterialData, SceneResources.mm:1088-1102)
@@ -134,6 +151,7 @@ private:
     std::vector<PtrMaterial> m_materials;
     std::vector<std::string> m_materialNames;
     std::vector<Mesh> m_meshes;
+    std::vector<Texture> m_textures;
     std::vector<float> m_envRgba;
     uint32_t m_envWidth = 0;
     uint32_t m_envHeight = 0;
@@ -142,6 +160,8 @@ private:
     mutable std::vector<PtrMeshDesc> m_meshDescs;
     mutable std::vector<std::vector<float>> m_meshPositions;
     mutable std::vector<std::vector<float>> m_meshNormals;
+    mutable std::vector<std::vector<float>> m_meshUv0, m_meshUv1, m_meshTangents;
+    mutable std::vector<PtrTexture> m_textureDescs;
 };
 
 }  // namespace ptr

@@ -43,10 +43,31 @@ __device__ __forceinline__ float luminance(f3 c) { return (0.2126f * c.x + 0.715
 // Material record view: 16 float4, fetched on demand (most branches need 2-4 of them).
 struct Mat {
     const float4* p;
-    __device__ __forceinline__ float4 v(uint32_t slot) const { return p[slot]; }
+    // per-hit values of the textured metallic-roughness model (shaders/pathtrace.metal:6391-6394 writes them back into its copy
+    // of the material): [0] base colour | roughness, [1] emission, [2] = (metallic, transmission, diffuse occlusion, 0).
+    // Null everywhere else - and always in the kernels compiled without the Metal-only models.
+    const float4* o = nullptr;
+    __device__ __forceinline__ float4 v(uint32_t slot) const {
+        if (o) {
+            if (slot == kMatBaseColorRoughness) return o[0];
+            if (slot == kMatEmission) return o[1];
+            if (slot == kMatCoatTint) {
+                float4 r = p[slot];
+                r.w = o[2].x;
+                return r;
+            }
+            if (slot == kMatDielectricSigmaA) {
+                float4 r = p[slot];
+                r.w = o[2].y;
+                return r;
+            }
+        }
+        return p[slot];
+    }
+    __device__ __forceinline__ float occlusion() const { return o ? o[2].z : 1.0f; }
     __device__ __forceinline__ uint32_t type() const { return static_cast<uint32_t>(p[kMatTypeEta].x); }
-    __device__ __forceinline__ f3 baseColor() const { return vclamp(mk3(p[kMatBaseColorRoughness]), 0.0f, 1.0f); }
-    __device__ __forceinline__ float roughness01() const { return clampf(p[kMatBaseColorRoughness].w, 0.0f, 1.0f); }
+    __device__ __forceinline__ f3 baseColor() const { return vclamp(mk3(v(kMatBaseColorRoughness)), 0.0f, 1.0f); }
+    __device__ __forceinline__ float roughness01() const { return clampf(v(kMatBaseColorRoughness).w, 0.0f, 1.0f); }
     __device__ __forceinline__ float ior() const { return p[kMatTypeEta].y; }
     __device__ __forceinline__ bool thinFlag() const { return p[kMatTypeEta].w > 0.5f; }   // material_is_thin_dielectric
     __device__ __forceinline__ f3 sigmaA() const { return vmax0(mk3(p[kMatDielectricSigmaA])); }
@@ -567,6 +588,7 @@ __device__ __forceinline__ PbrMetal loadPbrMetal(const Mat& m) {   // :4656-4678
     const f3 d0 = mk3(dielectricF0Clamped(m.ior()));
     p.f0 = d0 + (base - d0) * metallic;   // mix(dielectricF0, baseColor, metallic)
     p.diffuseColor = base * (1.0f - metallic);
+    p.diffuseColor = p.diffuseColor * clampf(m.occlusion(), 0.0f, 1.0f);   // diffuseOcclusion (:4661; 1 without an occlusion texture)
     p.transmission = clampf(m.v(kMatDielectricSigmaA).w, 0.0f, 1.0f) * (1.0f - metallic);   // pbrExtras.z rides in this lane
     p.reflectScale = 1.0f - p.transmission;
     const float specWeightBase = clampf(smax(p.f0.x, smax(p.f0.y, p.f0.z)), 0.05f, 0.95f);
@@ -754,6 +776,10 @@ struct BsdfSampleResult {
     int mediumEvent;   // +1: refracted into a dielectric through its front face, -1: out through a back face, else 0
     bool hasExit;      // separable subsurface sample: the path leaves the surface at exitPoint (normal = the shading normal)
     f3 exitPoint;
+    // which lobe the textured metallic-roughness model sampled (0 diffuse, 1 specular, 2 transmission) and its roughness: what the
+    // ray cone of the path widens by (bsdf_cone_spread_increment, shaders/pathtrace.metal:5703-5715); read only in textured scenes
+    int lobe = 0;
+    float lobeRoughness = 0.0f;
 };
 
 // ---- separable subsurface scattering of the Metal integrator (shaders/pathtrace.metal:3916-3994) ----
@@ -1029,6 +1055,8 @@ __device__ BsdfSampleResult samplePbrMetal(const Mat& m, f3 n, f3 wo, f3 inciden
     f3 wi = mk3(0.0f), f = mk3(0.0f);
     float pdfSpec = 0.0f, pdfDiffuse = 0.0f, pdfTrans = 0.0f;
     bool isDelta = false;
+    r.lobe = choose < p.pSpec ? 1 : (choose < p.pSpec + p.pDiff ? 0 : 2);
+    r.lobeRoughness = p.roughness;
     if (choose < p.pSpec) {
         if (p.roughness <= 1.0e-3f) {
             wi = reflectDir(incident, n);

@@ -49,7 +49,21 @@ struct SceneView {
     uint32_t nodeBytes;            // size of the node array in use (qnodes or nodes): buffer-descriptor range
     uint32_t triBytes;             // size of the triangle array
     uint32_t oversizeRef;          // leaf reference of the triangles kept out of the tree (kRefEmpty: none): every ray tests them first
+    // ---- material textures (PTR_METAL_PBR only; all null / 0 when the scene has none) - kernels/texture.h
+    const float4* triUv;           // 4 float4 per triangle, leaf order: (uv0, uv1) of the three vertices, then (uvPerWorld0, uvPerWorld1, 0, 0)
+    const float4* triTangent;      // 3 float4 per triangle, leaf order: world-space vertex tangents, w = handedness (0: none)
+    const float4* texels;          // every level of every texture, linear RGBA
+    const uint4* texInfo;          // kTexInfoVec4 uint4 per texture
+    const float4* materialTex;     // kMaterialTexVec4 float4 per material: texture transforms, indices, uv sets, pbr params
+    uint32_t textureCount;
+    uint32_t pad2;
 };
+
+// per-material texture record (materialTex): [0..11] KHR_texture_transform rows of the six slots (base colour, metallic-roughness,
+// normal, occlusion, emissive, transmission), [12] bits(texture index) of slots 0..3, [13] = bits(index slot 4, index slot 5,
+// uv-set bits (bit k = slot k reads TEXCOORD_1), materialFlags), [14] pbrParams (metallic, roughness, occlusion strength, normal
+// scale), [15] pbrExtras (alpha factor, alpha cutoff, transmission factor, alpha mode)
+constexpr uint32_t kMaterialTexVec4 = 16u;
 
 // Compact material record: the MaterialData fields the Embree-semantics integrator reads.
 constexpr uint32_t kMaterialVec4 = 16u;
@@ -140,6 +154,7 @@ struct PathPool {
     uint8_t* pending;      // light-connection records of this bounce (bits 0..4): what k_connect walks
     uint32_t* flushItem;   // valid while kFlagFlush: the finished item whose sum is published once its last records have landed
     uint4* medium;         // media mode only: stack of up to 8 dielectric material ids (16 bit each), depth in the flags
+    float2* cone;          // textured scenes only: ray cone of the slot's path (width at the ray origin, spread), shaders/pathtrace.metal:129-160
     uint32_t* signature;   // counting build only: per-slot path signature (see kSig* below); null otherwise
     float4* itemAccum;     // [itemCount] finished work items (summed per pixel, in sample order, by k_resolve); w = signature
     uint32_t* nextItem;    // [kItemHeadWords] head k at [k * kItemHeadStride]: next unclaimed item of range k (k_shade)

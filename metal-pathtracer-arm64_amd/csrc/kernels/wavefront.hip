@@ -21,6 +21,7 @@
 #include "device_types.h"
 #include "launch.h"
 #include "traverse.h"
+#include "texture.h"
 #include "traverse_dual.h"
 #include "vec.h"
 
@@ -37,6 +38,9 @@ constexpr uint32_t kShadeBlock = 128u;
 
 __device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
+// METAL: the instantiation that carries the Metal-only material models (k_shade<.., SSS = true>, the debug kernels).  The default
+// kernel is compiled without them: as run-time flags they cost it 70 more spilled registers (k_shade is held at 96 VGPRs).
+template <bool METAL = true>
 __device__ __forceinline__ ClampCfg clampCfg(const RenderParams& rp) {
     ClampCfg c;
     c.factor = rp.clampFactor;
@@ -51,9 +55,9 @@ __device__ __forceinline__ ClampCfg clampCfg(const RenderParams& rp) {
     c.metalSss = (rp.mediaMode & PTR_METAL_SSS) != 0u;
     c.sssMode = rp.sssMode;
     c.metalPbr = (rp.mediaMode & PTR_METAL_PBR) != 0u;
-    c.metalClamps = (rp.mediaMode & PTR_METAL_CLAMPS) != 0u;
-    c.maxContribution = rp.clampMaxContribution;
-    c.minSpecPdfRaw = rp.minSpecularPdfRaw;
+    c.metalClamps = METAL && (rp.mediaMode & PTR_METAL_CLAMPS) != 0u;
+    c.maxContribution = METAL ? rp.clampMaxContribution : 0.0f;
+    c.minSpecPdfRaw = METAL ? rp.minSpecularPdfRaw : 0.0f;
     return c;
 }
 
@@ -174,6 +178,17 @@ __device__ __forceinline__ void beginSample(const RenderParams& rp, uint32_t pix
     cameraRay(rp, pixel % rp.width, pixel / rp.width, rng, org, dir);
 }
 
+// make_primary_ray_cone (shaders/pathtrace.metal:141-152): the cone a textured scene's paths start with
+__device__ __forceinline__ float2 primaryCone(const RenderParams& rp) {
+    const CameraParams& cam = rp.cam;
+    const float pixelX = length(ld3(cam.horizontal)) / smax(static_cast<float>(rp.width), 1.0f);
+    const float pixelY = length(ld3(cam.vertical)) / smax(static_cast<float>(rp.height), 1.0f);
+    const float pixelFootprint = smax(smax(pixelX, pixelY), 1.0e-6f);
+    const f3 centre = (ld3(cam.lowerLeft) + 0.5f * ld3(cam.horizontal)) + 0.5f * ld3(cam.vertical);
+    const float focus = length(centre - ld3(cam.origin));
+    return make_float2(smax(2.0f * cam.lensRadius, 0.0f), pixelFootprint / smax(focus, 1.0e-6f));
+}
+
 // ---------------------------------------------------------------- environment
 __device__ __forceinline__ f3 skyColor(f3 direction) {
     const f3 unit = normalize(direction);
@@ -260,12 +275,17 @@ struct Surface {
     uint32_t primType;    // 0 mesh, 1 sphere, 2 rectangle
     uint32_t primIndex;   // rectangle index for primType 2
     uint32_t geomIndex;   // mesh index for primType 0
+    uint32_t prim;        // leaf-order triangle index (primType 0 / 2)
+    float bu, bv;         // barycentrics of a mesh-triangle hit
     bool frontFace, twoSided;
 };
 
 __device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 dir, float t, uint32_t prim) {
     Surface s;
     s.t = t;
+    s.prim = prim;
+    s.bu = 0.0f;
+    s.bv = 0.0f;
     s.position = org + t * dir;
     s.normal = mk3(0.0f, 1.0f, 0.0f);
     s.twoSided = false;
@@ -303,6 +323,8 @@ __device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 d
         s.geomIndex = meta & 0x3FFFFFFFu;
         float u, v;   // the traversal kernels store distance and primitive only
         triangleUv(mk3(a), mk3(b), mk3(c), org, dir, u, v);
+        s.bu = u;
+        s.bv = v;
         const float w = 1.0f - u - v;
         const f3 interp = (w * mk3(n0) + u * mk3(n1)) + v * mk3(n2);
         if (dot(interp, interp) > 0.0f) {
@@ -423,6 +445,7 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams rp, PathPool pool
     pool.accum[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(slot));
     pool.pending[slot] = 0u;
     if (pool.signature) pool.signature[slot] = 0u;
+    if (pool.cone) pool.cone[slot] = primaryCone(rp);
 }
 
 // =====================================================================================================
@@ -431,7 +454,7 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams rp, PathPool pool
 // 8 waves/SIMD: the step loop with its repeated steps wants 66-68 VGPRs; holding it at 64 costs no spill in the loop
 // and is 4 % faster than 7 waves
 #define PTR_EXTEND_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
-template <bool COUNT, bool ALIVE>
+template <bool COUNT, bool ALIVE, int NODES>
 __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride, uint32_t* workCounter,
                                                          int kRefillBelow, uint32_t feederChunk, uint32_t* aliveOut) {
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
@@ -468,7 +491,7 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
             if (live) {
                 mySlot = idx;
                 if (COUNT) ++rays;
-                active = travBegin(sc, t, mk3(r0), mk3(r0.w, r1.x, r1.y), kEps, INFINITY, false, stack);
+                active = travBegin<NODES>(sc, t, mk3(r0), mk3(r0.w, r1.x, r1.y), kEps, INFINITY, false, stack);
                 if (!active) pool.hit[idx] = make_float2(INFINITY, __uint_as_float(kHitMiss));
             }
             if (COUNT) {
@@ -484,7 +507,7 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
             leafLanes += static_cast<uint32_t>(__popcll(__ballot(active && travAtLeaf(t))));
             ++voteIterations;
         }
-        if (!travVote<COUNT>(sc, mem, t, active, stack, cnt)) {
+        if (!travVote<COUNT, NODES>(sc, mem, t, active, stack, cnt)) {
             active = false;
             pool.hit[mySlot] = make_float2(t.hit.t, __uint_as_float(t.hit.prim));
         }
@@ -640,15 +663,162 @@ __device__ __forceinline__ uint4 mediumWithEntry(uint4 ms, uint32_t i, uint32_t 
     return ms;
 }
 
+// ---- textured metallic-roughness material at a mesh-triangle hit (PTR_METAL_PBR; shaders/pathtrace.metal:5919-6400) ----
+// Builds the per-hit material the Metal kernel writes back into its copy of MaterialData: base colour x texture, metallic /
+// roughness x the G / B channels of the metallic-roughness texture, transmission, occlusion, emissive, the normal-mapped shading
+// normal with the roughness widening of shortened normals, and the alpha test.  Level of detail from the path's ray cone;
+// filtering rule in kernels/texture.h.  Returns true when the alpha test discards the hit (the ray passes through).
+struct PbrHit {
+    float4 ov[3];      // Mat overrides: base colour | roughness, emission, (metallic, transmission, occlusion, 0)
+    f3 shadingNormal;
+    bool twoSided;
+};
+
+__device__ __forceinline__ bool applyPbrTextures(const SceneView& sc, const Surface& sf, uint32_t materialIndex, const Mat& mat, f3 wo, float2 cone,
+                                                 float hitDistance, uint32_t& rng, PbrHit& out) {
+    const float4* mt = sc.materialTex + static_cast<size_t>(materialIndex) * kMaterialTexVec4;
+    const float4 idx0 = mt[12], idx1 = mt[13], pbrParams = mt[14], pbrExtras = mt[15];
+    const uint32_t texBase = __float_as_uint(idx0.x), texOrm = __float_as_uint(idx0.y), texNormal = __float_as_uint(idx0.z),
+                   texOcc = __float_as_uint(idx0.w), texEmissive = __float_as_uint(idx1.x), texTrans = __float_as_uint(idx1.y);
+    const uint32_t uvSets = __float_as_uint(idx1.z), materialFlags = __float_as_uint(idx1.w);
+    // interpolate_uv / interpolate_tangent with saturated barycentric weights (:583-591, 640-739)
+    f3 w = vmax0(mk3(1.0f - sf.bu - sf.bv, sf.bu, sf.bv));
+    const float wsum = (w.x + w.y) + w.z;
+    w = (wsum > 1.0e-8f) ? w / wsum : mk3(1.0f, 0.0f, 0.0f);
+    const float4* tu = sc.triUv + static_cast<size_t>(sf.prim) * 4u;
+    const float4 a = tu[0], b = tu[1], c = tu[2], per = tu[3];
+    const float2 uv0 = make_float2((a.x * w.x + b.x * w.y) + c.x * w.z, (a.y * w.x + b.y * w.y) + c.y * w.z);
+    const float2 uv1 = make_float2((a.z * w.x + b.z * w.y) + c.z * w.z, (a.w * w.x + b.w * w.y) + c.w * w.z);
+    // footprint of the ray cone on the surface (:158-160, 178-185, 5947-5949)
+    const float coneFootprint = smax(cone.x + cone.y * smax(hitDistance, 0.0f), 1.0e-7f);
+    const float surfaceFootprint = coneFootprint / smax(fabsf(dot(normalize(sf.normal), normalize(wo))), 1.0e-3f);
+    auto slot = [&](uint32_t k) { return texSlot(mt, k, (uvSets >> k) & 1u, uv0, uv1, per.x, per.y); };
+    auto lodOf = [&](uint32_t tex, const TexSlot& t) { return texLod(sc, tex, t.uvPerWorld, surfaceFootprint); };
+    const float4 one = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+
+    const TexSlot sBase = slot(0u);
+    const float4 baseSample = texSample(sc, texBase, sBase.u, sBase.v, lodOf(texBase, sBase), one);
+    const float4 bcr = mat.p[kMatBaseColorRoughness];
+    const f3 baseColor = mk3(bcr) * mk3(baseSample);
+    float metallic = clampf(pbrParams.x, 0.0f, 1.0f), roughness = clampf(pbrParams.y, 0.0f, 1.0f);
+    const bool disableOrm = (materialFlags & 1u) != 0u;   // kMaterialFlagDisableOrm
+    if (!disableOrm && texOrm != kNoTexture && texOrm < sc.textureCount) {
+        const TexSlot sOrm = slot(1u);
+        const float4 mr = texSample(sc, texOrm, sOrm.u, sOrm.v, lodOf(texOrm, sOrm), one);
+        metallic = clampf(mr.z * metallic, 0.0f, 1.0f);
+        roughness = clampf(mr.y * roughness, 0.0f, 1.0f);
+    }
+    float transmission = clampf(pbrExtras.z, 0.0f, 1.0f);
+    if (texTrans != kNoTexture && texTrans < sc.textureCount) {
+        const TexSlot sT = slot(5u);
+        transmission = clampf(transmission * texSample(sc, texTrans, sT.u, sT.v, lodOf(texTrans, sT), one).x, 0.0f, 1.0f);
+    }
+    transmission *= (1.0f - metallic);   // (the model applies this factor once more, as the reference does: :6194, 4666)
+    // alpha test (:6196-6217): MASK compares with the cutoff, BLEND keeps the hit with probability alpha
+    const float alpha = clampf(clampf(pbrExtras.x, 0.0f, 1.0f) * baseSample.w, 0.0f, 1.0f);
+    if (pbrExtras.w > 0.5f) {
+        const bool discard = pbrExtras.w < 1.5f ? (alpha < clampf(pbrExtras.y, 0.0f, 1.0f)) : (rngNext(rng) > alpha);
+        if (discard) return true;
+    }
+    float occlusion = 1.0f;
+    if (!disableOrm && texOcc != kNoTexture && texOcc < sc.textureCount) {
+        const TexSlot sO = slot(3u);
+        const float occ = texSample(sc, texOcc, sO.u, sO.v, lodOf(texOcc, sO), one).x;
+        const float strength = clampf(pbrParams.z, 0.0f, 1.0f);
+        occlusion = 1.0f + (occ - 1.0f) * strength;   // mix(1, occ, strength)
+    }
+    f3 emissive = mk3(mat.p[kMatEmission]);
+    if (texEmissive != kNoTexture && texEmissive < sc.textureCount) {
+        const TexSlot sE = slot(4u);
+        emissive *= mk3(texSample(sc, texEmissive, sE.u, sE.v, lodOf(texEmissive, sE), one));
+    }
+    // normal map (:6281-6346): vertex tangent (Gram-Schmidt against the shading normal), else the triangle's UV derivatives, else an
+    // arbitrary frame; the mapped normal is kept on the geometric normal's side
+    f3 shadingNormal = sf.hitShadingNormal;
+    if (dot(shadingNormal, shadingNormal) <= 0.0f) shadingNormal = sf.normal;
+    shadingNormal = normalize(shadingNormal);
+    const float normalScale = pbrParams.w;
+    const bool useNormalMap = texNormal != kNoTexture && texNormal < sc.textureCount && normalScale > 1.0e-4f;
+    if (useNormalMap) {
+        const TexSlot sN = slot(2u);
+        const float4 ns = texSample(sc, texNormal, sN.u, sN.v, lodOf(texNormal, sN), make_float4(0.5f, 0.5f, 1.0f, 1.0f));
+        float normalLength = 1.0f;
+        const f3 nts = decodeNormalMap(mk3(ns), normalScale, normalLength);
+        f3 t = mk3(1.0f, 0.0f, 0.0f), bt = mk3(0.0f);
+        bool hasBasis = false;
+        if (sc.triTangent) {
+            const float4* tt = sc.triTangent + static_cast<size_t>(sf.prim) * 3u;
+            const float4 t0 = tt[0], t1 = tt[1], t2 = tt[2];
+            f3 tw = (mk3(t0) * w.x + mk3(t1) * w.y) + mk3(t2) * w.z;
+            const float tsign = (t0.w * w.x + t1.w * w.y) + t2.w * w.z;
+            const float len2 = dot(tw, tw);
+            tw = (finite3(tw) && len2 > 1.0e-12f) ? tw * (1.0f / sqrtf(len2)) : mk3(1.0f, 0.0f, 0.0f);
+            if (fabsf(tsign) > 0.5f) {
+                t = tw - shadingNormal * dot(shadingNormal, tw);
+                if (finite3(t) && dot(t, t) > 1.0e-6f) {
+                    t = normalize(t);
+                    bt = normalize(cross(shadingNormal, t)) * (tsign < 0.0f ? -1.0f : 1.0f);
+                    hasBasis = finite3(bt) && dot(bt, bt) > 1.0e-6f;
+                }
+            }
+        }
+        if (!hasBasis) {
+            // compute_tangent_basis_from_uv (:843-911) in world space: the triangle's edges and the UV deltas of the normal map's set
+            const float4* tp = sc.tris + static_cast<size_t>(sf.prim) * 3u;
+            const f3 edge1 = -mk3(tp[1]), edge2 = mk3(tp[2]);   // stored as v0 - v1, v2 - v0
+            const bool set1 = ((uvSets >> 2) & 1u) != 0u;
+            const float2 q0 = set1 ? make_float2(a.z, a.w) : make_float2(a.x, a.y), q1 = set1 ? make_float2(b.z, b.w) : make_float2(b.x, b.y),
+                         q2 = set1 ? make_float2(c.z, c.w) : make_float2(c.x, c.y);
+            const float du1 = q1.x - q0.x, dv1 = q1.y - q0.y, du2 = q2.x - q0.x, dv2 = q2.y - q0.y;
+            const float denom = du1 * dv2 - dv1 * du2;
+            if (fabsf(denom) >= 1.0e-8f) {
+                const float r = 1.0f / denom;
+                f3 tangentW = (edge1 * dv2 - edge2 * dv1) * r;
+                f3 bitangentW = (edge2 * du1 - edge1 * du2) * r;
+                const float tl = dot(tangentW, tangentW), bl = dot(bitangentW, bitangentW);
+                if (finite3(tangentW) && tl > 1.0e-12f && finite3(bitangentW) && bl > 1.0e-12f) {
+                    tangentW = tangentW * (1.0f / sqrtf(tl));
+                    bitangentW = bitangentW * (1.0f / sqrtf(bl));
+                    t = tangentW - shadingNormal * dot(shadingNormal, tangentW);
+                    if (finite3(t) && dot(t, t) > 1.0e-6f) {
+                        t = normalize(t);
+                        const float handed = dot(cross(shadingNormal, t), bitangentW) < 0.0f ? -1.0f : 1.0f;
+                        bt = normalize(cross(shadingNormal, t)) * (handed * (per.z < 0.0f ? -1.0f : 1.0f));   // x sign of det(localToWorld), as the reference has it
+                        hasBasis = true;
+                    }
+                }
+            }
+        }
+        if (!hasBasis) {   // build_onb (:934-940)
+            const f3 up = fabsf(shadingNormal.z) < 0.999f ? mk3(0.0f, 0.0f, 1.0f) : mk3(1.0f, 0.0f, 0.0f);
+            t = normalize(cross(up, shadingNormal));
+            bt = cross(shadingNormal, t);
+        }
+        f3 mapped = normalize((t * nts.x + bt * nts.y) + shadingNormal * nts.z);
+        if (dot(mapped, sf.normal) < 0.0f) mapped = -mapped;
+        shadingNormal = mapped;
+        // shortened (filtered) normals widen the lobe (:6348-6388, without the first-hit gradient term)
+        const float tok = smax((1.0f - normalLength) / smax(normalLength, 1.0e-6f), 0.0f);
+        roughness = clampf(sqrtf(roughness * roughness + tok), 0.0f, 1.0f);
+    }
+    out.ov[0] = mk4(baseColor, roughness);
+    out.ov[1] = mk4(emissive, 0.0f);
+    out.ov[2] = make_float4(metallic, transmission, occlusion, 0.0f);
+    out.shadingNormal = shadingNormal;
+    out.twoSided = sf.twoSided || mat.p[kMatTypeEta].z > 0.5f;
+    return false;
+}
+
 // =====================================================================================================
 // k_shade
 // =====================================================================================================
-// 5 waves/SIMD (<= 96 VGPRs, a handful of spills in the cold material branches) measured best: the compiler's own
-// choice of 121 VGPRs / 4 waves was 10 % slower, 6 and 8 waves spill into the hot path (132 / 167 ms vs 105 ms).
+// 4 waves/SIMD (<= 128 VGPRs, no spills).  Round 1 ran it at 5 waves / 96 VGPRs with ~230 spilled registers in cold branches; with
+// the slot body shared with the end-of-frame kernel the allocation at 96 spilled into the hot path (k_shade 372 -> 468 ms per
+// frame), and measured on one box: 4 waves 1664, 5 waves 1570, 6 waves 1374 Msamples/s (profiles/r2_ab_shade_waves.txt).
 #ifndef PTR_SHADE_WAVES
-#define PTR_SHADE_WAVES 5
+#define PTR_SHADE_WAVES 4
 #endif
-// (the instantiation with the Metal-only subsurface / PBR models needs more registers: 4 waves)
+// (the instantiation with the Metal-only subsurface / PBR models runs at 4 waves too)
 #define PTR_SHADE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SSS ? 4 : PTR_SHADE_WAVES, SSS ? 4 : PTR_SHADE_WAVES)))
 // SSS: the instantiation with the Metal subsurface semantics (launched when PTR_METAL_SSS is set)
 struct ShadeCounts {
@@ -699,9 +869,11 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
     f3 acc = mk3(0.0f), thr = mk3(1.0f), nextO = mk3(0.0f), nextD = mk3(0.0f);
     float lastPdf = 1.0f;
     uint32_t sig = 0u;   // counting build: path signature of the slot's current item
+    float2 cone = make_float2(0.0f, 0.0f);   // textured scenes: ray cone of the path (width at the ray origin, spread)
+    bool haveCone = false, newSample = false;
 
     if (touched) {
-        const ClampCfg cc = clampCfg(rp);
+        const ClampCfg cc = clampCfg<SSS>(rp);
         acc = mk3(acc4);
         // light connections queued last bounce have been resolved by k_connect: add them in slot order
 #pragma unroll
@@ -838,7 +1010,8 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                         thr *= mk3(expf(-sigma.x * segment), expf(-sigma.y * segment), expf(-sigma.z * segment));
                     }
                 }
-                const Mat mat{sc.materials + static_cast<size_t>(min(sf.material, sc.materialCount - 1u)) * kMaterialVec4};
+                const uint32_t materialIndex = min(sf.material, sc.materialCount - 1u);
+                Mat mat{sc.materials + static_cast<size_t>(materialIndex) * kMaterialVec4};
                 const uint32_t type = mat.type();
                 const f3 incident = normalize(rayD);
                 const f3 wo = -incident;
@@ -849,8 +1022,37 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                     if ((rp.mediaMode & PTR_METAL_FACE_NORMAL) && !sf.frontFace) n = -n;   // set_face_normal, pathtrace.metal:1187-1191
                 }
                 n = normalize(n);
+                bool hitTwoSided = sf.twoSided;
+                bool passThrough = false;   // the alpha test of a textured material discarded the hit
+                PbrHit pbrHit;
+                if (SSS && cc.metalPbr && type == 7u) {
+                    if (sf.primType == 0u && sc.textureCount > 0u && sc.triUv != nullptr) {
+                        cone = pool.cone ? pool.cone[slot] : make_float2(0.0f, 0.0f);
+                        haveCone = pool.cone != nullptr;
+                        passThrough = applyPbrTextures(sc, sf, materialIndex, mat, wo, cone, hitv.x, rng, pbrHit);
+                        if (!passThrough) {
+                            mat.o = pbrHit.ov;
+                            n = pbrHit.shadingNormal;
+                            hitTwoSided = pbrHit.twoSided;
+                        }
+                    }
+                    if (!passThrough) {
+                        // an emissive metallic-roughness surface adds its emission and the path goes on (pathtrace.metal:6437-6442)
+                        const f3 emission = mk3(mat.v(kMatEmission));
+                        if ((emission.x != 0.0f || emission.y != 0.0f || emission.z != 0.0f) && (sf.frontFace || hitTwoSided)) {
+                            acc += clampFirefly(thr, emission, cc);
+                        }
+                    }
+                }
 
-                if (type == 3u) {
+                if (SSS && passThrough) {
+                    // pathtrace.metal:6206-6216: the ray carries on through the surface; counts as a specular bounce
+                    nextO = offsetOrigin(sf, rayD);
+                    nextD = rayD;
+                    lastPdf = 1.0f;
+                    lastDelta = true;
+                    specDepth += 1u;
+                } else if (type == 3u) {
                     // ---- emitter reached by a BSDF-sampled ray ----
                     const float4 em = mat.v(kMatEmission);
                     f3 emission = mk3(em) * rp.emissionScale;
@@ -1034,6 +1236,20 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                             lastDelta = bs.isDelta;
                             nextO = (SSS && bs.hasExit) ? sssExitOrigin(bs.exitPoint, n, bs.dir) : offsetOrigin(sf, bs.dir);
                             nextD = bs.dir;
+                            if (SSS && pool.cone) {
+                                // the path's ray cone: width at this hit, spread widened by the sampled lobe (pathtrace.metal:7262-7267, 5703-5715)
+                                if (!haveCone) cone = pool.cone[slot];
+                                haveCone = true;
+                                cone.x = smax(cone.x + cone.y * smax(hitv.x, 0.0f), 1.0e-7f);
+                                float inc = 0.0f;
+                                if (!bs.isDelta) {
+                                    const bool pbr = cc.metalPbr && type == 7u;
+                                    const int lobe = pbr ? bs.lobe : ((type == 0u || type == 5u) ? 0 : 1);
+                                    const float r = clampf(pbr ? bs.lobeRoughness : mat.roughness01(), 0.0f, 1.0f);
+                                    inc = lobe == 0 ? 0.55f : (lobe == 1 ? 0.03f + (0.45f - 0.03f) * r : 0.10f + (0.60f - 0.10f) * r);
+                                }
+                                cone.y = smin(cone.y + inc, 1.5f);
+                            }
                             if (rp.enableRussianRoulette && depth >= 5u) {
                                 const float p = clampf(maxComp, 0.05f, 0.95f);
                                 if (rngNext(rng) > p) {
@@ -1089,6 +1305,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                     item = got;
                     beginSample(rp, pool.pixelOfLocal[got % rp.localPixels], got / rp.localPixels, rng, nextO, nextD);
                     stillAlive = true;
+                    newSample = true;
                 }
             }
         }
@@ -1151,6 +1368,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                 item = claimed;
                 beginSample(rp, pool.pixelOfLocal[claimed % rp.localPixels], claimed / rp.localPixels, rng, nextO, nextD);
                 stillAlive = true;
+                newSample = true;
             }
         }
     }
@@ -1174,6 +1392,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
             pool.thr[slot] = mk4(thr, __uint_as_float(rng));
         }
         if (COUNT && pool.signature) pool.signature[slot] = sig;
+        if (SSS && pool.cone && stillAlive && (haveCone || newSample)) pool.cone[slot] = newSample ? primaryCone(rp) : cone;
     }
 
     if (COUNT) {
@@ -1301,7 +1520,7 @@ __device__ f3 mneeChain(const RenderParams& rp, const SceneView& sc, const Clamp
 
 }  // namespace
 
-template <bool COUNT>
+template <bool COUNT, int NODES>
 __global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) k_connect(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride,
                                                           uint32_t* workCounter, int kRefillBelow, uint32_t feederChunk) {
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
@@ -1348,7 +1567,7 @@ __global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_e
                 const uint32_t kind = __float_as_uint(d4.w);
                 if (kind != 2u) {   // kind 2 (MNEE chains) is resolved by k_connect_chain
                     if (COUNT) { if (kind == 0u) ++rays; else ++raysClosest; }
-                    active = travBegin(sc, t, mk3(o4), mk3(d4), kEps, kind == 0u ? o4.w : INFINITY, kind == 0u, stack);
+                    active = travBegin<NODES>(sc, t, mk3(o4), mk3(d4), kEps, kind == 0u ? o4.w : INFINITY, kind == 0u, stack);
                     if (!active && kind != 0u) recBase[myRecAt + 2u * slots] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 }
             }
@@ -1358,7 +1577,7 @@ __global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_e
         {
             // counting build: nodes/prims of closest-hit (kind 1) rays are booked with the extend counters
             TraceCounters step{0u, 0u};
-            const bool more = travVote<COUNT>(sc, mem, t, active, stack, step);
+            const bool more = travVote<COUNT, NODES>(sc, mem, t, active, stack, step);
             if (COUNT) {
                 TraceCounters& dst = t.anyHit ? cnt : cntClosest;
                 dst.nodes += step.nodes;
@@ -1578,7 +1797,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_tail_run(RenderParams rp, Scene
     stack.spill = spill;
     stack.spillStride = spillStride;
     stack.sp = 0u;
-    const ClampCfg cc = clampCfg(rp);
+    const ClampCfg cc = clampCfg<SSS>(rp);
     TraceCounters cntExtend{0u, 0u}, cntAny{0u, 0u}, cntClosest{0u, 0u};
     uint32_t raysExtend = 0u, raysAny = 0u, raysClosest = 0u, early = 0u;
     ShadeCounts counts;
@@ -1838,6 +2057,12 @@ __global__ void k_debug_sample(const float4* material, RenderParams rp, const fl
     rngOut[i] = rng;
 }
 
+__global__ void k_debug_tex_sample(SceneView sc, uint32_t texture, const float* in, uint64_t n, float4* out) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = texSample(sc, texture, in[i * 3u], in[i * 3u + 1u], in[i * 3u + 2u], make_float4(-1.0f, -1.0f, -1.0f, -1.0f));
+}
+
 __global__ void k_debug_camera(RenderParams rp, const uint32_t* xys, uint64_t n, float* out, uint32_t* rngOut) {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1882,17 +2107,21 @@ void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig&
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters, cfg.refillBelow,
                            cfg.feederChunk, aliveOut);
     };
+    // the node format is a compile-time choice of the persistent kernels (no dead float / quantised path in the step loop); the
+    // counting build keeps the run-time flag
     if (count) {
-        if (aliveOut) launch(k_extend<true, true>); else launch(k_extend<true, false>);
+        if (aliveOut) launch(k_extend<true, true, -1>); else launch(k_extend<true, false, -1>);
+    } else if (sc.useQuantized) {
+        if (aliveOut) launch(k_extend<false, true, 1>); else launch(k_extend<false, false, 1>);
     } else {
-        if (aliveOut) launch(k_extend<false, true>); else launch(k_extend<false, false>);
+        if (aliveOut) launch(k_extend<false, true, 0>); else launch(k_extend<false, false, 0>);
     }
 }
 
 void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, bool count,
                  hipStream_t stream) {
     const uint32_t grid = ceilDiv(pool.slots, kShadeBlock);
-    const bool sss = (rp.mediaMode & (PTR_METAL_SSS | PTR_METAL_PBR)) != 0u;   // the instantiation that carries those Metal-only models
+    const bool sss = (rp.mediaMode & (PTR_METAL_SSS | PTR_METAL_PBR | PTR_METAL_CLAMPS)) != 0u;   // the instantiation that carries those Metal-only models
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, resets); };
     if (count) {
         if (sss) launch(k_shade<true, true>); else launch(k_shade<true, false>);
@@ -1915,10 +2144,16 @@ void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& 
         }
     } else {
         const uint32_t stride = cfg.traceGrid * kTraceBlock;
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1,
+                               cfg.refillBelow, cfg.feederChunk);
+        };
         if (count) {
-            hipLaunchKernelGGL(k_connect<true>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1, cfg.refillBelow, cfg.feederChunk);
+            launch(k_connect<true, -1>);
+        } else if (sc.useQuantized) {
+            launch(k_connect<false, 1>);
         } else {
-            hipLaunchKernelGGL(k_connect<false>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1, cfg.refillBelow, cfg.feederChunk);
+            launch(k_connect<false, 0>);
         }
     }
     const uint32_t stride = cfg.traceGrid * kTraceBlock;
@@ -1937,7 +2172,7 @@ void launchTail(const RenderParams& rp, const SceneView& sc, const PathPool& poo
     const uint32_t collectGrid = std::max(1u, std::min(cfg.traceGrid, ceilDiv(pool.slots, 256u * 16u)));
     hipLaunchKernelGGL(k_tail_collect, dim3(collectGrid), dim3(256), 0, stream, pool, dList, dListCount);
     const uint32_t stride = cfg.traceGrid * kTraceBlock;
-    const bool sss = (rp.mediaMode & (PTR_METAL_SSS | PTR_METAL_PBR)) != 0u;
+    const bool sss = (rp.mediaMode & (PTR_METAL_SSS | PTR_METAL_PBR | PTR_METAL_CLAMPS)) != 0u;
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, dList, dListCount, dListHead, cfg.spill, stride);
     };
@@ -1985,6 +2220,10 @@ void launchDebugEvalBsdf(const float4* dMaterial, const RenderParams& rp, const 
 void launchDebugSampleBsdf(const float4* dMaterial, const RenderParams& rp, const float* dIn, const uint32_t* dFront, const uint32_t* dRng,
                            uint64_t n, float* dOut, uint32_t* dRngOut, hipStream_t stream) {
     hipLaunchKernelGGL(k_debug_sample, dim3(std::max(1u, ceilDiv(n, 128))), dim3(128), 0, stream, dMaterial, rp, dIn, dFront, dRng, n, dOut, dRngOut);
+}
+
+void launchDebugTexSample(const SceneView& sc, uint32_t texture, const float* dIn, uint64_t n, float4* dOut, hipStream_t stream) {
+    hipLaunchKernelGGL(k_debug_tex_sample, dim3(std::max(1u, ceilDiv(n, 128))), dim3(128), 0, stream, sc, texture, dIn, n, dOut);
 }
 
 void launchDebugCameraRays(const RenderParams& rp, const uint32_t* dXys, uint64_t n, float* dOut, uint32_t* dRngOut, hipStream_t stream) {

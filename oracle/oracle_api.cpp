@@ -60,6 +60,11 @@ double oracle_render_signatures(const OracleScene* s, const PtrSettings* setting
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// Texture filtering rule (oracle_integrator.cpp "material textures"): in: n * 3 floats {u, v, lod}; out: n * 4 floats RGBA
+void oracle_texture_sample(const PtrSceneDesc* desc, uint32_t texture, const float* in, uint64_t n, float* out) {
+    sampleTextures(*desc, texture, in, n, out);
+}
+
 // rays: n * 8 floats {ox,oy,oz,tmin,dx,dy,dz,tmax}
 void oracle_trace_rays(const OracleScene* s, const float* rays, uint64_t n, int any_hit, int brute_force, PtrHit* out) {
     for (uint64_t i = 0; i < n; ++i) {

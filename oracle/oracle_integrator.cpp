@@ -3,6 +3,7 @@
 #include "oracle_integrator.h"
 
 #include <atomic>
+#include <cstring>
 #include <limits>
 #include <thread>
 
@@ -1188,6 +1189,12 @@ PbrMetal loadPbrMetal(const PtrMaterial& m) {  // M:4656-4678 / 4789-4811
     p.roughness = clampf(m.baseColorRoughness[3], 0.0f, 1.0f);
     p.f0 = mix3(splat(dielectricF0FromIor(m.typeEta[1])), base, metallic);
     p.diffuseColor = base * (1.0f - metallic);
+    // diffuseOcclusion (M:4661): the textured path parks it in the per-hit copy of the material (materialPad[0], flagged by [1])
+    if (m.materialPad[1] == 0x4F43434Cu) {
+        float occlusion;
+        std::memcpy(&occlusion, &m.materialPad[0], 4);
+        p.diffuseColor = p.diffuseColor * clampf(occlusion, 0.0f, 1.0f);
+    }
     p.transmission = clampf(m.pbrExtras[2], 0.0f, 1.0f) * (1.0f - metallic);
     p.reflectScale = 1.0f - p.transmission;
     const float specWeightBase = pbrSpecularWeight(p.f0);
@@ -1294,6 +1301,8 @@ BsdfSample samplePbrMetal(const PtrMaterial& m, V3 normal, V3 wo, V3 incidentDir
     V3 wi, f;
     float pdfSpec = 0.0f, pdfDiffuse = 0.0f, pdfTrans = 0.0f;
     bool isDelta = false;
+    r.lobe = choose < p.pSpec ? 1 : (choose < p.pSpec + p.pDiff ? 0 : 2);
+    r.lobeRoughness = p.roughness;
     if (choose < p.pSpec) {
         if (p.roughness <= 1.0e-3f) {
             wi = reflect(incidentDir, normal);
@@ -1754,6 +1763,9 @@ bool intersectScene(const Scene& scene, const Ray& ray, HitInfo& out, Counters* 
     V3 shading = adjusted;
     uint32_t material = g.materialIndex;
     out.primitiveType = g.type;
+    out.geom = rh.geom;
+    out.bu = rh.u;
+    out.bv = rh.v;
     out.primitiveIndex = rh.primId;
     out.geomIndex = g.type == GeomType::Mesh ? g.meshIndex : 0u;
     out.twoSided = false;
@@ -1792,6 +1804,339 @@ bool intersectScene(const Scene& scene, const Ray& ray, HitInfo& out, Counters* 
     out.shadingNormal = shading;
     out.materialIndex = material;
     return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// material textures of the Metal metallic-roughness model                  M:108-198, 583-940, 2923-3216, 5919-6400
+// ---------------------------------------------------------------------------------------------
+// The reference samples through the GPU's texture units; a software path has to fix a filtering rule.  This is the rule of
+// csrc/kernels/texture.h, restated: linear RGBA floats with a full mip chain (2x2 box, ((a+b)+(c+d))*0.25, second tap clamped at
+// odd edges), ray-cone level of detail, bilinear inside a level (texel centres at (i+0.5)/W, glTF wrap modes), linear between the
+// two nearest levels, NEAREST samplers = one texel of the rounded level.  No first-hit ray differentials.
+struct C4 {
+    float x = 0.0f, y = 0.0f, z = 0.0f, w = 0.0f;
+};
+
+struct OracleTexture {
+    uint32_t width = 0, height = 0, levels = 0, wrapS = 0, wrapT = 0, filter = 1;
+    std::vector<std::vector<float>> mips;   // RGBA per level
+};
+
+static std::vector<OracleTexture> buildTextures(const PtrSceneDesc& desc) {
+    std::vector<OracleTexture> out;
+    if (!desc.textures) return out;
+    for (uint32_t i = 0; i < desc.textureCount; ++i) {
+        const PtrTexture& t = desc.textures[i];
+        OracleTexture o;
+        o.width = t.width;
+        o.height = t.height;
+        o.wrapS = t.wrapS & 3u;
+        o.wrapT = t.wrapT & 3u;
+        o.filter = t.filter ? 1u : 0u;
+        o.mips.emplace_back(t.rgba, t.rgba + static_cast<size_t>(t.width) * t.height * 4u);
+        uint32_t w = t.width, h = t.height;
+        while ((w > 1u || h > 1u) && o.mips.size() < 16u) {
+            const uint32_t nw = std::max(w / 2u, 1u), nh = std::max(h / 2u, 1u);
+            const std::vector<float>& src = o.mips.back();
+            std::vector<float> dst(static_cast<size_t>(nw) * nh * 4u);
+            for (uint32_t y = 0; y < nh; ++y) {
+                const uint32_t y0 = std::min(2u * y, h - 1u), y1 = std::min(2u * y + 1u, h - 1u);
+                for (uint32_t x = 0; x < nw; ++x) {
+                    const uint32_t x0 = std::min(2u * x, w - 1u), x1 = std::min(2u * x + 1u, w - 1u);
+                    for (int c = 0; c < 4; ++c) {
+                        const float a = src[(static_cast<size_t>(y0) * w + x0) * 4u + c], b = src[(static_cast<size_t>(y0) * w + x1) * 4u + c];
+                        const float cc = src[(static_cast<size_t>(y1) * w + x0) * 4u + c], d = src[(static_cast<size_t>(y1) * w + x1) * 4u + c];
+                        dst[(static_cast<size_t>(y) * nw + x) * 4u + c] = ((a + b) + (cc + d)) * 0.25f;
+                    }
+                }
+            }
+            o.mips.push_back(std::move(dst));
+            w = nw;
+            h = nh;
+        }
+        o.levels = static_cast<uint32_t>(o.mips.size());
+        out.push_back(std::move(o));
+    }
+    return out;
+}
+
+static int texWrap(int i, int n, uint32_t mode) {
+    if (mode == 1u) return std::min(std::max(i, 0), n - 1);
+    if (mode == 2u) {
+        const int period = 2 * n;
+        int j = i % period;
+        if (j < 0) j += period;
+        return j < n ? j : period - 1 - j;
+    }
+    int j = i % n;
+    return j < 0 ? j + n : j;
+}
+
+static C4 texFetch(const OracleTexture& t, uint32_t level, int x, int y) {
+    const uint32_t w = std::max(t.width >> level, 1u);
+    const float* p = &t.mips[level][(static_cast<size_t>(y) * w + static_cast<size_t>(x)) * 4u];
+    return C4{p[0], p[1], p[2], p[3]};
+}
+
+static C4 texBilinear(const OracleTexture& t, uint32_t level, float u, float v) {
+    const int W = static_cast<int>(std::max(t.width >> level, 1u)), H = static_cast<int>(std::max(t.height >> level, 1u));
+    if (t.filter == 0u) {
+        return texFetch(t, level, texWrap(static_cast<int>(std::floor(u * static_cast<float>(W))), W, t.wrapS),
+                        texWrap(static_cast<int>(std::floor(v * static_cast<float>(H))), H, t.wrapT));
+    }
+    const float fx = u * static_cast<float>(W) - 0.5f, fy = v * static_cast<float>(H) - 0.5f;
+    const float x0f = std::floor(fx), y0f = std::floor(fy);
+    const float tx = fx - x0f, ty = fy - y0f;
+    const int x0 = texWrap(static_cast<int>(x0f), W, t.wrapS), x1 = texWrap(static_cast<int>(x0f) + 1, W, t.wrapS);
+    const int y0 = texWrap(static_cast<int>(y0f), H, t.wrapT), y1 = texWrap(static_cast<int>(y0f) + 1, H, t.wrapT);
+    const C4 c00 = texFetch(t, level, x0, y0), c10 = texFetch(t, level, x1, y0), c01 = texFetch(t, level, x0, y1), c11 = texFetch(t, level, x1, y1);
+    const float ix = 1.0f - tx, iy = 1.0f - ty;
+    return C4{(c00.x * ix + c10.x * tx) * iy + (c01.x * ix + c11.x * tx) * ty, (c00.y * ix + c10.y * tx) * iy + (c01.y * ix + c11.y * tx) * ty,
+              (c00.z * ix + c10.z * tx) * iy + (c01.z * ix + c11.z * tx) * ty, (c00.w * ix + c10.w * tx) * iy + (c01.w * ix + c11.w * tx) * ty};
+}
+
+static C4 texSample(const std::vector<OracleTexture>& textures, uint32_t index, float u, float v, float lod, C4 fallback) {
+    if (index == 0xFFFFFFFFu || index >= textures.size()) return fallback;
+    const OracleTexture& t = textures[index];
+    const float maxMip = static_cast<float>(t.levels - 1u);
+    const float l = std::min(std::max(lod, 0.0f), maxMip);
+    if (t.filter == 0u) return texBilinear(t, static_cast<uint32_t>(std::floor(l + 0.5f)), u, v);
+    const float l0f = std::floor(l);
+    const uint32_t l0 = static_cast<uint32_t>(l0f), l1 = std::min(l0 + 1u, t.levels - 1u);
+    const float f = l - l0f;
+    const C4 a = texBilinear(t, l0, u, v);
+    if (!(f > 0.0f) || l1 == l0) return a;
+    const C4 b = texBilinear(t, l1, u, v);
+    return C4{a.x + (b.x - a.x) * f, a.y + (b.y - a.y) * f, a.z + (b.z - a.z) * f, a.w + (b.w - a.w) * f};
+}
+
+void sampleTextures(const PtrSceneDesc& desc, uint32_t texture, const float* in, uint64_t n, float* out) {
+    const std::vector<OracleTexture> textures = buildTextures(desc);
+    for (uint64_t i = 0; i < n; ++i) {
+        const C4 c = texSample(textures, texture, in[i * 3], in[i * 3 + 1], in[i * 3 + 2], C4{-1.0f, -1.0f, -1.0f, -1.0f});
+        out[i * 4] = c.x;
+        out[i * 4 + 1] = c.y;
+        out[i * 4 + 2] = c.z;
+        out[i * 4 + 3] = c.w;
+    }
+}
+
+static float texLod(const std::vector<OracleTexture>& textures, uint32_t index, float uvPerWorld, float footprintWorld) {   // M:162-176
+    if (index == 0xFFFFFFFFu || index >= textures.size()) return 0.0f;
+    const OracleTexture& t = textures[index];
+    if (t.width == 0u || t.height == 0u) return 0.0f;
+    if (t.levels <= 1u || uvPerWorld <= 0.0f || footprintWorld <= 0.0f) return 0.0f;
+    const float maxRes = std::max(static_cast<float>(t.width), static_cast<float>(t.height));
+    const float texelFootprint = footprintWorld * uvPerWorld * maxRes;
+    const float lod = std::log2(std::max(texelFootprint, 1.0e-7f));
+    return std::min(std::max(lod, 0.0f), static_cast<float>(t.levels - 1u));
+}
+
+static V3 decodeNormalMap(V3 s, float normalScale, float& outLength) {   // M:108-127
+    V3 n = s * 2.0f - splat(1.0f);
+    n.x *= normalScale;
+    n.y *= normalScale;
+    outLength = length(n);
+    const float xyLen2 = n.x * n.x + n.y * n.y;
+    n.z = std::sqrt(std::max(1.0f - xyLen2, 0.0f));
+    const float len2 = dot(n, n);
+    if (len2 > 1.0e-12f) {
+        n = n * (1.0f / std::sqrt(len2));
+    } else {
+        n = V3(0.0f, 0.0f, 1.0f);
+    }
+    return n;
+}
+
+struct TexSlot {
+    float u = 0.0f, v = 0.0f, uvPerWorld = 0.0f;
+};
+
+static TexSlot texSlot(const PtrMaterial& m, uint32_t slot, uint32_t uvSet, const float uv0[2], const float uv1[2], float perWorld0, float perWorld1) {
+    V3 row0(m.textureTransform[2 * slot]), row1(m.textureTransform[2 * slot + 1]);
+    const float linearSum = (std::fabs(row0.x) + std::fabs(row0.y)) + (std::fabs(row1.x) + std::fabs(row1.y));
+    if (!finite3(row0) || !finite3(row1) || !(linearSum > 1.0e-8f)) {   // M:2942-2983
+        row0 = V3(1.0f, 0.0f, 0.0f);
+        row1 = V3(0.0f, 1.0f, 0.0f);
+    }
+    const float* uv = uvSet == 0u ? uv0 : uv1;
+    TexSlot t;
+    t.u = (row0.x * uv[0] + row0.y * uv[1]) + row0.z;
+    t.v = (row1.x * uv[0] + row1.y * uv[1]) + row1.z;
+    const float sx = std::sqrt(row0.x * row0.x + row1.x * row1.x), sy = std::sqrt(row0.y * row0.y + row1.y * row1.y);
+    t.uvPerWorld = (uvSet == 0u ? perWorld0 : perWorld1) * std::max(std::max(sx, sy), 1.0e-6f);   // M:3002-3009
+    return t;
+}
+
+// uv-per-world of one set over a triangle (triangle_surface_partials, M:741-820) in world space
+static float triangleUvPerWorld(V3 edge1, V3 edge2, float du1, float dv1, float du2, float dv2) {
+    const float det = du1 * dv2 - dv1 * du2;
+    if (std::fabs(det) > 1.0e-9f) {
+        const float inv = 1.0f / det;
+        const V3 dPdu = (edge1 * dv2 - edge2 * dv1) * inv, dPdv = (edge2 * du1 - edge1 * du2) * inv;
+        const float lenU = length(dPdu), lenV = length(dPdv);
+        if (lenU > 1.0e-8f && lenV > 1.0e-8f) {
+            const float perWorld = std::max(1.0f / lenU, 1.0f / lenV);
+            if (std::isfinite(perWorld) && perWorld > 0.0f) return perWorld;
+        }
+    }
+    const float worldArea = length(cross(edge1, edge2)), uvArea = std::fabs(det);
+    const float perWorld = (worldArea > 1.0e-12f && uvArea > 1.0e-12f) ? std::sqrt(uvArea / worldArea) : 0.0f;
+    return std::isfinite(perWorld) ? perWorld : 0.0f;
+}
+
+// The per-hit material of the textured model (M:5919-6400).  `material` is the hit's own copy and is modified in place;
+// returns true when the alpha test discards the hit.
+static bool applyPbrTextures(const Scene& scene, const std::vector<OracleTexture>& textures, const HitInfo& hit, PtrMaterial& material, V3 wo,
+                             float coneWidth, float coneSpread, float hitDistance, Rng& rng, V3& shadingNormalOut, bool& twoSidedOut) {
+    const Geom& g = scene.geoms[hit.geom];
+    const uint32_t base = hit.primitiveIndex * 3u;
+    const uint32_t i0 = g.indices[base], i1 = g.indices[base + 1u], i2 = g.indices[base + 2u];
+    // saturated barycentric weights (M:583-591)
+    V3 w = vmax(V3(1.0f - hit.bu - hit.bv, hit.bu, hit.bv), V3());
+    const float wsum = (w.x + w.y) + w.z;
+    w = (wsum > 1.0e-8f) ? w / wsum : V3(1.0f, 0.0f, 0.0f);
+    auto uvOf = [&](const std::vector<float>& set, uint32_t v, int c) { return set.empty() ? 0.0f : set[2 * v + c]; };
+    const float a0[2] = {uvOf(g.uv0, i0, 0), uvOf(g.uv0, i0, 1)}, b0[2] = {uvOf(g.uv0, i1, 0), uvOf(g.uv0, i1, 1)}, c0[2] = {uvOf(g.uv0, i2, 0), uvOf(g.uv0, i2, 1)};
+    const float a1[2] = {uvOf(g.uv1, i0, 0), uvOf(g.uv1, i0, 1)}, b1[2] = {uvOf(g.uv1, i1, 0), uvOf(g.uv1, i1, 1)}, c1[2] = {uvOf(g.uv1, i2, 0), uvOf(g.uv1, i2, 1)};
+    const float uv0[2] = {(a0[0] * w.x + b0[0] * w.y) + c0[0] * w.z, (a0[1] * w.x + b0[1] * w.y) + c0[1] * w.z};
+    const float uv1[2] = {(a1[0] * w.x + b1[0] * w.y) + c1[0] * w.z, (a1[1] * w.x + b1[1] * w.y) + c1[1] * w.z};
+    const V3 edge1 = g.positions[i1] - g.positions[i0], edge2 = g.positions[i2] - g.positions[i0];
+    const float perWorld0 = triangleUvPerWorld(edge1, edge2, b0[0] - a0[0], b0[1] - a0[1], c0[0] - a0[0], c0[1] - a0[1]);
+    const float perWorld1 = triangleUvPerWorld(edge1, edge2, b1[0] - a1[0], b1[1] - a1[1], c1[0] - a1[0], c1[1] - a1[1]);
+    const float coneFootprint = std::max(coneWidth + coneSpread * std::max(hitDistance, 0.0f), 1.0e-7f);   // M:158-160
+    const float surfaceFootprint = coneFootprint / std::max(std::fabs(dot(normalize(hit.normal), normalize(wo))), 1.0e-3f);   // M:178-185
+    const uint32_t uvSetOf[6] = {std::min(material.textureUvSet0[0], 1u), std::min(material.textureUvSet0[1], 1u), std::min(material.textureUvSet0[2], 1u),
+                                 std::min(material.textureUvSet0[3], 1u), std::min(material.textureUvSet1[0], 1u), std::min(material.textureUvSet1[1], 1u)};
+    auto slot = [&](uint32_t k) { return texSlot(material, k, uvSetOf[k], uv0, uv1, perWorld0, perWorld1); };
+    auto lodOf = [&](uint32_t tex, const TexSlot& t) { return texLod(textures, tex, t.uvPerWorld, surfaceFootprint); };
+    auto valid = [&](uint32_t tex) { return tex != 0xFFFFFFFFu && tex < textures.size(); };
+    const C4 one{1.0f, 1.0f, 1.0f, 1.0f};
+    const uint32_t texBase = material.textureIndices0[0], texOrm = material.textureIndices0[1], texNormal = material.textureIndices0[2],
+                   texOcc = material.textureIndices0[3], texEmissive = material.textureIndices1[0], texTrans = material.textureIndices1[1];
+
+    const TexSlot sBase = slot(0u);
+    const C4 baseSample = texSample(textures, texBase, sBase.u, sBase.v, lodOf(texBase, sBase), one);
+    const V3 baseColor = V3(material.baseColorRoughness) * V3(baseSample.x, baseSample.y, baseSample.z);
+    float metallic = clampf(material.pbrParams[0], 0.0f, 1.0f), roughness = clampf(material.pbrParams[1], 0.0f, 1.0f);
+    const bool disableOrm = (material.materialFlags & 1u) != 0u;
+    if (!disableOrm && valid(texOrm)) {
+        const TexSlot sOrm = slot(1u);
+        const C4 mr = texSample(textures, texOrm, sOrm.u, sOrm.v, lodOf(texOrm, sOrm), one);
+        metallic = clampf(mr.z * metallic, 0.0f, 1.0f);
+        roughness = clampf(mr.y * roughness, 0.0f, 1.0f);
+    }
+    float transmission = clampf(material.pbrExtras[2], 0.0f, 1.0f);
+    if (valid(texTrans)) {
+        const TexSlot sT = slot(5u);
+        transmission = clampf(transmission * texSample(textures, texTrans, sT.u, sT.v, lodOf(texTrans, sT), one).x, 0.0f, 1.0f);
+    }
+    transmission *= (1.0f - metallic);
+    const float alpha = clampf(clampf(material.pbrExtras[0], 0.0f, 1.0f) * baseSample.w, 0.0f, 1.0f);   // M:6196-6217
+    if (material.pbrExtras[3] > 0.5f) {
+        const bool discard = material.pbrExtras[3] < 1.5f ? (alpha < clampf(material.pbrExtras[1], 0.0f, 1.0f)) : (rng.nextFloat() > alpha);
+        if (discard) return true;
+    }
+    float occlusion = 1.0f;
+    if (!disableOrm && valid(texOcc)) {
+        const TexSlot sO = slot(3u);
+        const float occ = texSample(textures, texOcc, sO.u, sO.v, lodOf(texOcc, sO), one).x;
+        const float strength = clampf(material.pbrParams[2], 0.0f, 1.0f);
+        occlusion = 1.0f + (occ - 1.0f) * strength;
+    }
+    V3 emissive(material.emission);
+    if (valid(texEmissive)) {
+        const TexSlot sE = slot(4u);
+        const C4 e = texSample(textures, texEmissive, sE.u, sE.v, lodOf(texEmissive, sE), one);
+        emissive *= V3(e.x, e.y, e.z);
+    }
+    V3 shadingNormal = hit.shadingNormal;
+    if (dot(shadingNormal, shadingNormal) <= 0.0f) shadingNormal = hit.normal;
+    shadingNormal = normalize(shadingNormal);
+    const float normalScale = material.pbrParams[3];
+    if (valid(texNormal) && normalScale > 1.0e-4f) {   // M:6281-6346
+        const TexSlot sN = slot(2u);
+        const C4 ns = texSample(textures, texNormal, sN.u, sN.v, lodOf(texNormal, sN), C4{0.5f, 0.5f, 1.0f, 1.0f});
+        float normalLength = 1.0f;
+        const V3 nts = decodeNormalMap(V3(ns.x, ns.y, ns.z), normalScale, normalLength);
+        V3 t(1.0f, 0.0f, 0.0f), bt;
+        bool hasBasis = false;
+        if (!g.tangents.empty()) {
+            const float* t0 = &g.tangents[4 * i0];
+            const float* t1 = &g.tangents[4 * i1];
+            const float* t2 = &g.tangents[4 * i2];
+            V3 tw = (V3(t0) * w.x + V3(t1) * w.y) + V3(t2) * w.z;
+            const float tsign = (t0[3] * w.x + t1[3] * w.y) + t2[3] * w.z;
+            const float len2 = dot(tw, tw);
+            tw = (finite3(tw) && len2 > 1.0e-12f) ? tw * (1.0f / std::sqrt(len2)) : V3(1.0f, 0.0f, 0.0f);
+            if (std::fabs(tsign) > 0.5f) {
+                t = tw - shadingNormal * dot(shadingNormal, tw);
+                if (finite3(t) && dot(t, t) > 1.0e-6f) {
+                    t = normalize(t);
+                    bt = normalize(cross(shadingNormal, t)) * (tsign < 0.0f ? -1.0f : 1.0f);
+                    hasBasis = finite3(bt) && dot(bt, bt) > 1.0e-6f;
+                }
+            }
+        }
+        if (!hasBasis) {   // M:843-911, in world space
+            const bool set1 = uvSetOf[2] != 0u;
+            const float* q0 = set1 ? a1 : a0;
+            const float* q1 = set1 ? b1 : b0;
+            const float* q2 = set1 ? c1 : c0;
+            const float du1 = q1[0] - q0[0], dv1 = q1[1] - q0[1], du2 = q2[0] - q0[0], dv2 = q2[1] - q0[1];
+            const float denom = du1 * dv2 - dv1 * du2;
+            if (std::fabs(denom) >= 1.0e-8f) {
+                const float r = 1.0f / denom;
+                // the device reads the edges from its triangle record (v0 - v1 negated, v2 - v0): the same differences
+                const Prim tri = [&] {
+                    Prim p{};
+                    p.e1 = g.positions[i0] - g.positions[i1];
+                    p.e2 = g.positions[i2] - g.positions[i0];
+                    return p;
+                }();
+                const V3 e1 = -tri.e1, e2 = tri.e2;
+                V3 tangentW = (e1 * dv2 - e2 * dv1) * r;
+                V3 bitangentW = (e2 * du1 - e1 * du2) * r;
+                const float tl = dot(tangentW, tangentW), bl = dot(bitangentW, bitangentW);
+                if (finite3(tangentW) && tl > 1.0e-12f && finite3(bitangentW) && bl > 1.0e-12f) {
+                    tangentW = tangentW * (1.0f / std::sqrt(tl));
+                    bitangentW = bitangentW * (1.0f / std::sqrt(bl));
+                    t = tangentW - shadingNormal * dot(shadingNormal, tangentW);
+                    if (finite3(t) && dot(t, t) > 1.0e-6f) {
+                        t = normalize(t);
+                        const float handed = dot(cross(shadingNormal, t), bitangentW) < 0.0f ? -1.0f : 1.0f;
+                        bt = normalize(cross(shadingNormal, t)) * (handed * (g.detSign < 0.0f ? -1.0f : 1.0f));
+                        hasBasis = true;
+                    }
+                }
+            }
+        }
+        if (!hasBasis) {   // M:934-940
+            const V3 up = std::fabs(shadingNormal.z) < 0.999f ? V3(0.0f, 0.0f, 1.0f) : V3(1.0f, 0.0f, 0.0f);
+            t = normalize(cross(up, shadingNormal));
+            bt = cross(shadingNormal, t);
+        }
+        V3 mapped = normalize((t * nts.x + bt * nts.y) + shadingNormal * nts.z);
+        if (dot(mapped, hit.normal) < 0.0f) mapped = -mapped;
+        shadingNormal = mapped;
+        const float tok = std::max((1.0f - normalLength) / std::max(normalLength, 1.0e-6f), 0.0f);   // M:6348-6388 without the gradient term
+        roughness = clampf(std::sqrt(roughness * roughness + tok), 0.0f, 1.0f);
+    }
+    material.baseColorRoughness[0] = baseColor.x;
+    material.baseColorRoughness[1] = baseColor.y;
+    material.baseColorRoughness[2] = baseColor.z;
+    material.baseColorRoughness[3] = roughness;
+    material.pbrParams[0] = metallic;
+    material.pbrExtras[2] = transmission;
+    material.emission[0] = emissive.x;
+    material.emission[1] = emissive.y;
+    material.emission[2] = emissive.z;
+    material.emission[3] = 0.0f;
+    std::memcpy(&material.materialPad[0], &occlusion, 4);
+    material.materialPad[1] = 0x4F43434Cu;
+    shadingNormalOut = shadingNormal;
+    twoSidedOut = hit.twoSided || material.typeEta[2] > 0.5f;
+    return false;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1866,6 +2211,20 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
     // test knob (PtrSettings.debugShadowSlack): 0 = the reference's shadow-ray length, quirk Q9
     const float shadowSlack = (settings.debugShadowSlack > 0.0f && settings.debugShadowSlack < 1.0f) ? settings.debugShadowSlack : 0.0f;
     const bool wantSignature = outSignature != nullptr || outMarginal != nullptr;
+    // material textures: sampled by the Metal metallic-roughness model only (the Embree backend never reads them)
+    const std::vector<OracleTexture> textures = cp.metalPbr ? buildTextures(desc) : std::vector<OracleTexture>();
+    const bool texturedScene = !textures.empty();
+    // make_primary_ray_cone (M:141-152)
+    float primaryConeWidth = 0.0f, primaryConeSpread = 0.0f;
+    {
+        const float pixelX = length(camera.horizontal) / std::max(static_cast<float>(width), 1.0f);
+        const float pixelY = length(camera.vertical) / std::max(static_cast<float>(height), 1.0f);
+        const float pixelFootprint = std::max(std::max(pixelX, pixelY), 1.0e-6f);
+        const V3 centre = (camera.lowerLeft + 0.5f * camera.horizontal) + 0.5f * camera.vertical;
+        const float focus = length(centre - camera.origin);
+        primaryConeWidth = std::max(2.0f * camera.lensRadius, 0.0f);
+        primaryConeSpread = pixelFootprint / std::max(focus, 1.0e-6f);
+    }
 
     auto renderPixel = [&](uint32_t x, uint32_t y, RenderCounters& rc) -> V3 {
         V3 pixelRadiance;
@@ -1899,6 +2258,7 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
             uint32_t mediumStack[kMaxMediumStack] = {0};
             uint32_t mediumDepth = 0;
             const bool media = (settings.metalSemantics & PTR_METAL_MEDIA) != 0u;
+            float coneWidth = primaryConeWidth, coneSpread = primaryConeSpread;   // ray cone of the path (textured scenes)
 
             for (uint32_t depth = 0; depth < settings.maxDepth; ++depth) {
                 HitInfo hit;
@@ -1934,8 +2294,9 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
                     }
                 }
 
-                const PtrMaterial& material = materials[std::min(hit.materialIndex, materialCount - 1)];
-                const uint32_t type = matType(material);
+                PtrMaterial texturedMaterial;   // the hit's own copy when textures modulate it (M:6391-6394)
+                const PtrMaterial* materialPtr = &materials[std::min(hit.materialIndex, materialCount - 1)];
+                const uint32_t type = matType(*materialPtr);
                 const V3 incidentDir = normalize(ray.direction);
                 const V3 wo = -incidentDir;
                 V3 shadingNormal = hit.shadingNormal;
@@ -1946,6 +2307,33 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
                     if ((settings.metalSemantics & PTR_METAL_FACE_NORMAL) && !hit.frontFace) shadingNormal = -shadingNormal;
                 }
                 shadingNormal = normalize(shadingNormal);
+                if (cp.metalPbr && type == PTR_MAT_PBR) {
+                    bool passThrough = false;
+                    if (texturedScene && hit.primitiveType == GeomType::Mesh && !scene.geoms[hit.geom].positions.empty()) {
+                        texturedMaterial = *materialPtr;
+                        V3 mapped;
+                        bool twoSided = hit.twoSided;
+                        passThrough = applyPbrTextures(scene, textures, hit, texturedMaterial, wo, coneWidth, coneSpread, hit.t, rng, mapped, twoSided);
+                        if (!passThrough) {
+                            materialPtr = &texturedMaterial;
+                            shadingNormal = mapped;
+                            hit.twoSided = twoSided;
+                        }
+                    }
+                    if (passThrough) {   // M:6206-6216: the alpha test discarded the hit, the ray carries on
+                        ray.origin = offsetRayOrigin(hit, ray.direction);
+                        lastBsdfPdf = 1.0f;
+                        lastScatterWasDelta = true;
+                        specularDepth += 1u;
+                        continue;
+                    }
+                    // an emissive metallic-roughness surface adds its emission and the path goes on (M:6437-6442)
+                    const V3 emission(materialPtr->emission);
+                    if ((emission.x != 0.0f || emission.y != 0.0f || emission.z != 0.0f) && (hit.frontFace || hit.twoSided)) {
+                        radiance += clampFireflyContribution(throughput, emission, cp);
+                    }
+                }
+                const PtrMaterial& material = *materialPtr;
 
                 if (type == PTR_MAT_DIFFUSE_LIGHT) {  // E:2660-2706
                     V3 emission = V3(material.emission) * emissionScale;
@@ -2136,6 +2524,17 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
                 const float maxComp = std::max(std::max(throughput.x, throughput.y), throughput.z);
                 if (maxComp <= 0.0f) break;
 
+                if (texturedScene) {   // the path's ray cone (M:7262-7267, 5703-5715)
+                    coneWidth = std::max(coneWidth + coneSpread * std::max(hit.t, 0.0f), 1.0e-7f);
+                    float inc = 0.0f;
+                    if (!bs.isDelta) {
+                        const bool pbr = cp.metalPbr && type == PTR_MAT_PBR;
+                        const int lobe = pbr ? bs.lobe : ((type == PTR_MAT_LAMBERTIAN || type == PTR_MAT_SUBSURFACE) ? 0 : 1);
+                        const float r = clampf(pbr ? bs.lobeRoughness : material.baseColorRoughness[3], 0.0f, 1.0f);
+                        inc = lobe == 0 ? 0.55f : (lobe == 1 ? 0.03f + (0.45f - 0.03f) * r : 0.10f + (0.60f - 0.10f) * r);
+                    }
+                    coneSpread = std::min(coneSpread + inc, 1.5f);
+                }
                 lastBsdfPdf = bs.pdf > 0.0f ? bs.pdf : lastBsdfPdf;
                 lastScatterWasDelta = bs.isDelta;
                 ray.origin = bs.hasExitPoint ? sssExitOrigin(bs.exitPoint, dot(bs.exitNormal, bs.exitNormal) > 0.0f ? bs.exitNormal : shadingNormal, bs.direction)

@@ -98,6 +98,8 @@ struct BsdfSample {
     bool hasExitPoint = false;   // Metal-only subsurface samples: the path leaves at exitPoint
     V3 exitPoint;
     V3 exitNormal;               // random walk: outward normal at the exit (zero: use the shading normal of the entry)
+    int lobe = 0;                // Metal metallic-roughness sampler: 0 diffuse, 1 specular, 2 transmission (ray-cone widening)
+    float lobeRoughness = 0.0f;
 };
 
 struct HitInfo {  // :97-107
@@ -108,6 +110,8 @@ struct HitInfo {  // :97-107
     GeomType primitiveType = GeomType::Mesh;
     uint32_t primitiveIndex = 0;
     uint32_t geomIndex = 0;   // mesh index of a mesh hit (path signatures only)
+    uint32_t geom = 0;        // Scene::geoms index of the hit geometry, barycentrics of a triangle hit (textured materials)
+    float bu = 0.0f, bv = 0.0f;
 };
 
 struct RenderCounters {
@@ -126,6 +130,8 @@ BsdfEval evaluateBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 wi
 BsdfSample sampleBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 incidentDir, bool frontFace, Rng& rng,
                       const ClampParams& cp);
 bool intersectScene(const Scene& scene, const Ray& ray, HitInfo& out, Counters* counters = nullptr);
+// Samples texture `texture` of the scene with the filtering rule of the textured metallic-roughness model: in n * {u, v, lod}, out n * RGBA.
+void sampleTextures(const PtrSceneDesc& desc, uint32_t texture, const float* in, uint64_t n, float* out);
 
 // Renders pixels with y in [y0, y1) (full width); out_rgb is the full W*H*3 image, other rows untouched.
 // out_signature / out_marginal (optional, W*H each): path signature of every pixel's last sample and whether one of its

@@ -180,6 +180,28 @@ void Scene::build(const PtrSceneDesc& desc) {
             g.normals[v] = length(wn) > 0.0f ? normalize(wn) : wn;
         }
         g.indices.assign(mesh.indices, mesh.indices + mesh.indexCount);
+        // texture attributes (shaders/pathtrace.metal:640-739): world-space tangents through the linear part of localToWorld
+        const float det3 = l2w.m[0][0] * (l2w.m[1][1] * l2w.m[2][2] - l2w.m[2][1] * l2w.m[1][2]) -
+                           l2w.m[1][0] * (l2w.m[0][1] * l2w.m[2][2] - l2w.m[2][1] * l2w.m[0][2]) +
+                           l2w.m[2][0] * (l2w.m[0][1] * l2w.m[1][2] - l2w.m[1][1] * l2w.m[0][2]);
+        g.detSign = det3 < 0.0f ? -1.0f : 1.0f;
+        if (mesh.uv0 || mesh.uv1) {
+            g.positions = positions;
+            g.uv0.assign(static_cast<size_t>(mesh.vertexCount) * 2, 0.0f);
+            g.uv1.assign(static_cast<size_t>(mesh.vertexCount) * 2, 0.0f);
+            if (mesh.uv0) g.uv0.assign(mesh.uv0, mesh.uv0 + static_cast<size_t>(mesh.vertexCount) * 2);
+            if (mesh.uv1) g.uv1.assign(mesh.uv1, mesh.uv1 + static_cast<size_t>(mesh.vertexCount) * 2);
+            if (mesh.tangents) {
+                g.tangents.resize(static_cast<size_t>(mesh.vertexCount) * 4);
+                for (uint32_t v = 0; v < mesh.vertexCount; ++v) {
+                    const float* tl = mesh.tangents + 4 * v;
+                    g.tangents[4 * v + 0] = (l2w.m[0][0] * tl[0] + l2w.m[1][0] * tl[1]) + l2w.m[2][0] * tl[2];
+                    g.tangents[4 * v + 1] = (l2w.m[0][1] * tl[0] + l2w.m[1][1] * tl[1]) + l2w.m[2][1] * tl[2];
+                    g.tangents[4 * v + 2] = (l2w.m[0][2] * tl[0] + l2w.m[1][2] * tl[1]) + l2w.m[2][2] * tl[2];
+                    g.tangents[4 * v + 3] = tl[3] == 0.0f ? 0.0f : (tl[3] < 0.0f ? -1.0f : 1.0f) * g.detSign;
+                }
+            }
+        }
         const uint32_t geomId = static_cast<uint32_t>(geoms.size());
         for (uint32_t t = 0; t + 2 < mesh.indexCount; t += 3) {
             prims.push_back(makeTriangle(positions[mesh.indices[t]], positions[mesh.indices[t + 1]],

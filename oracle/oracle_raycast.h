@@ -40,6 +40,11 @@ struct Geom {
     std::vector<uint32_t> indices;      // triangle indices
     std::vector<uint32_t> primMaterial; // Rectangles: per triangle; Spheres: per sphere
     std::vector<uint32_t> triToRect;    // Rectangles: triangle -> rectangle index
+    // textured metallic-roughness model (Metal semantics only): per-vertex texture coordinates / world-space tangents, world positions
+    std::vector<V3> positions;          // world space (Mesh)
+    std::vector<float> uv0, uv1;        // 2 per vertex (empty: none)
+    std::vector<float> tangents;        // 4 per vertex: world-space tangent (unnormalised), w = handedness x sign of det(localToWorld); empty: none
+    float detSign = 1.0f;
 };
 
 struct RayHit {

@@ -30,6 +30,7 @@ def lib():
         l.oracle_render.restype = C.c_double
         l.oracle_render_signatures.argtypes = [vp, C.POINTER(pt.PtrSettings), u32, u32, u32, u32, fp, up, C.POINTER(C.c_uint8)]
         l.oracle_render_signatures.restype = C.c_double
+        l.oracle_texture_sample.argtypes = [C.POINTER(pt.PtrSceneDesc), u32, fp, u64, fp]
         l.oracle_trace_rays.argtypes = [vp, fp, u64, C.c_int, C.c_int, vp]
         l.oracle_rng_hash.argtypes = [u32]
         l.oracle_rng_hash.restype = u32
@@ -99,6 +100,14 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+
+def texture_sample(host_scene, texture, uv_lod):
+    """The oracle's restatement of the texture filtering rule: uv_lod [n, 3] -> [n, 4] RGBA."""
+    uv_lod = np.ascontiguousarray(uv_lod, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros((uv_lod.shape[0], 4), dtype=np.float32)
+    lib().oracle_texture_sample(C.byref(host_scene.desc), texture, _f(uv_lod), uv_lod.shape[0], _f(out))
+    return out
 
 
 def rng_hash(x):

@@ -539,7 +539,7 @@ def test_metal_clamp_variants_restated():
     luminance at the clamp floor (4) while the Metal variants leave it alone."""
     host = pt.HostScene.load(os.path.join(GOLDEN, "materials.scene"))
     d = host.desc
-    metal = next(i for i in range(d.materialCount) if int(d.materials[i].typeEta[0]) == 1 and d.materials[i].baseColorRoughness[3] < 0.3)
+    metal = next(i for i in range(d.materialCount) if int(d.materials[i].typeEta[0]) == 1 and 0.05 < d.materials[i].baseColorRoughness[3] < 0.3)
     s0 = host.settings_for(width=32, height=32)
     s1 = s0.copy()
     s1.metalSemantics = 64
