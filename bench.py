@@ -25,7 +25,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6.29 TB/s
 # ONE group so kernels never overlap): config 2 = this benchmark's own command line, config 5 = the scene whose BVH lives in HBM
 SOLO_FILE = os.path.join(ROOT, "profiles", "r2_solo_cfg2.json")
 SOLO_FILE_CFG5 = os.path.join(ROOT, "profiles", "r2_solo_cfg5.json")
-EXTEND_KERNEL = "k_extend<false,false>"
+EXTEND_KERNEL = "k_extend<false,false"   # prefix: the third template argument names the node format (1 = 32 B quantised, 0 = 64 B float)
 
 
 def measured_stream_gbs(torch, device):
@@ -77,10 +77,11 @@ def recorded_kernel(path, kernel=EXTEND_KERNEL):
     try:
         with open(path) as f:
             rec = json.load(f)
-        row = dict(rec["kernels"][kernel])
+        names = [k for k in rec["kernels"] if k.startswith(kernel)]
+        row = dict(rec["kernels"][max(names, key=lambda k: rec["kernels"][k].get("dispatches", 0) * rec["kernels"][k].get("avg_ms", 0.0))])
         row["command"] = rec.get("command", "")
         return row
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, TypeError):
         return None
 
 

@@ -280,8 +280,18 @@ void prepareScene(const PtrSceneDesc& desc, PreparedScene& ps) {
             put4(ps.lights, c, ptr::length(ptr::cross(eu, ev)));
             put4(ps.lights, eu, r.materialTwoSided[1] != 0u ? 1.0f : 0.0f);
             put4(ps.lights, ev, bitsToFloat(i));
-            put4(ps.lights, n, 0.0f);
+            // rows 5..10: the light's own two triangles exactly as the traversal reads them (leaf-order records), for k_shade's
+            // self-occlusion test of a light sample; normal.w = 1 when they are present
+            const uint32_t t0 = ps.geo.rectTriLeaf[static_cast<size_t>(i) * 2u], t1 = ps.geo.rectTriLeaf[static_cast<size_t>(i) * 2u + 1u];
+            const bool haveTris = t0 != 0xFFFFFFFFu && t1 != 0xFFFFFFFFu;
+            put4(ps.lights, n, haveTris ? 1.0f : 0.0f);
             put4(ps.lights, e, 0.0f);
+            for (uint32_t t : {t0, t1}) {
+                for (int row = 0; row < 3; ++row) {
+                    const float* src = haveTris ? &ps.geo.triData[static_cast<size_t>(t) * 12u + static_cast<size_t>(row) * 4u] : nullptr;
+                    for (int c = 0; c < 4; ++c) ps.lights.push_back(src ? src[c] : 0.0f);
+                }
+            }
             ps.lightIndexByRect[i] = static_cast<int32_t>(ps.lightCount++);
         }
     }

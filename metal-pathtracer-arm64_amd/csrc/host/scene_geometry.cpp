@@ -291,6 +291,14 @@ bool BuildSceneGeometry(const PtrSceneDesc& desc, uint32_t leafMax, SceneGeometr
             std::memcpy(&out.triNormals[k * 12], &nrmIn[static_cast<size_t>(order[k]) * 12], 48);
         }
     });
+    // where the two halves of every rectangle ended up (k_shade tests a sampled light's own triangles before queueing a shadow ray)
+    out.rectTriLeaf.assign(static_cast<size_t>(desc.rectCount) * 2u, 0xFFFFFFFFu);
+    {
+        const size_t meshTriTotal = static_cast<size_t>(triCount) - static_cast<size_t>(desc.rectCount) * 2u;   // rectangle halves follow the meshes in input order
+        for (size_t k = 0; k < order.size(); ++k) {
+            if (order[k] >= meshTriTotal) out.rectTriLeaf[order[k] - meshTriTotal] = static_cast<uint32_t>(k);
+        }
+    }
     if (textured) {
         out.triUv.resize(static_cast<size_t>(triCount) * 16);
         out.triTangent.resize(static_cast<size_t>(triCount) * 12);

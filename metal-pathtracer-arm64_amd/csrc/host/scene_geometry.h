@@ -25,6 +25,7 @@ struct SceneGeometry {
     // textured scenes only (desc.textureCount > 0 and some mesh carries texture coordinates); leaf order:
     std::vector<float> triUv;        // 16 floats per triangle: (uv0, uv1) of the three vertices, then (uvPerWorld0, uvPerWorld1, sign of det(localToWorld), 0)
     std::vector<float> triTangent;   // 12 floats per triangle: world-space vertex tangents, w = handedness x sign of det (0: no tangent)
+    std::vector<uint32_t> rectTriLeaf;   // 2 per rectangle: leaf-order indices of its two triangles
     uint32_t triCount = 0, sphereCount = 0;
     double gatherSeconds = 0.0, buildSeconds = 0.0, flattenSeconds = 0.0;
 };

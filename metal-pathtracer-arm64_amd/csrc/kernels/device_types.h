@@ -33,7 +33,8 @@ struct SceneView {
     const uint2* sphereInfo;
     const float4* materials;       // kMaterialVec4 float4 per material
     const float4* rects;           // 5 float4 per rectangle (PtrRect layout)
-    const float4* rectLights;      // 4 float4 per light: corner|area, edgeU|twoSided, edgeV|rectIndex, normal|0 ; +1: emission
+    const float4* rectLights;      // kRectLightVec4 float4 per light: corner|area, edgeU|twoSided, edgeV|rectIndex, normal|has-triangles,
+                                   // emission, then the light's own two triangles as the traversal stores them (v0, v0-v1, v2-v0 each)
     const int32_t* lightIndexByRect;
     const float4* envRgba;
     const float2* envCond;         // (threshold, bits(alias)) per texel
@@ -64,6 +65,8 @@ struct SceneView {
 // uv-set bits (bit k = slot k reads TEXCOORD_1), materialFlags), [14] pbrParams (metallic, roughness, occlusion strength, normal
 // scale), [15] pbrExtras (alpha factor, alpha cutoff, transmission factor, alpha mode)
 constexpr uint32_t kMaterialTexVec4 = 16u;
+
+constexpr uint32_t kRectLightVec4 = 11u;
 
 // Compact material record: the MaterialData fields the Embree-semantics integrator reads.
 constexpr uint32_t kMaterialVec4 = 16u;

@@ -140,6 +140,9 @@ struct WaveFeeder {
     }
 };
 
+#ifndef PTR_LIGHT_PRETEST   // A/B switch of the light self-occlusion test in k_shade
+#define PTR_LIGHT_PRETEST 1
+#endif
 constexpr uint32_t kItemReserve = 64u;   // work items a wave reserves per atomic on the global head
 
 // ---------------------------------------------------------------- camera
@@ -401,7 +404,7 @@ __device__ __forceinline__ bool rectLightHit(const SceneView& sc, const Surface&
     if (s.primType != 2u || s.primIndex >= sc.rectCount) return false;
     const int32_t li = sc.lightIndexByRect[s.primIndex];
     if (li < 0) return false;
-    const float4* L = sc.rectLights + static_cast<size_t>(li) * 5u;
+    const float4* L = sc.rectLights + static_cast<size_t>(li) * kRectLightVec4;
     const bool twoSided = L[1].w != 0.0f;
     if (!s.frontFace && !twoSided) return false;
     emission = mk3(L[4]) * emissionScale;
@@ -1081,7 +1084,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                         const uint32_t sel = min(static_cast<uint32_t>(rngNext(rng) * static_cast<float>(nL)), nL - 1u);
                         const float lu = rngNext(rng);
                         const float lv = rngNext(rng);
-                        const float4* L = sc.rectLights + static_cast<size_t>(sel) * 5u;
+                        const float4* L = sc.rectLights + static_cast<size_t>(sel) * kRectLightVec4;
                         const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3];
                         const f3 samplePoint = (mk3(l0) + lu * mk3(l1)) + lv * mk3(l2);
                         const f3 toLight = samplePoint - sf.position;
@@ -1109,10 +1112,25 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                                                 // tfar is measured from the un-offset hit point (reference quirk Q9)
                                                 // (rp.shadowSlack is a test knob, 0 in every product render: x * 1.0f is x)
                                                 const float shadowMax = smax(distance * (1.0f - rp.shadowSlack) - kEps, kEps);
-                                                // a.w: depth of this vertex, for the path signature of the counting build
-                                                storeRecord(pool, slot, 0u, 0u, offsetOrigin(sf, ldir), shadowMax, ldir, clamped,
-                                                            static_cast<float>(depth), mk3(0.0f));
-                                                want[0] = true;
+                                                const f3 shadowOrg = offsetOrigin(sf, ldir);
+                                                // The shadow ray starts off the surface but its length is measured from the surface (quirk Q9), so from
+                                                // any surface that faces the light's plane it reaches the light's OWN rectangle and is occluded by it -
+                                                // after walking the whole scene on the way.  An any-hit query is occluded as soon as one primitive is
+                                                // hit: test the light's two triangles first (the same test on the same operands as the traversal's),
+                                                // and queue a shadow ray only when they do not settle it.  Half of config 2's shadow rays end here.
+                                                // The light's own two triangles ride in its record (rows 5..10, l3.w says so); they are read here, where few
+                                                // registers are live, not with the rest of the record.
+                                                float tt, tu, tv;
+                                                bool occludedByLight = false;
+                                                if (PTR_LIGHT_PRETEST != 0 && l3.w != 0.0f) {
+                                                    occludedByLight = triangleTest(mk3(L[5]), mk3(L[6]), mk3(L[7]), shadowOrg, ldir, kEps, shadowMax, tt, tu, tv) ||
+                                                                      triangleTest(mk3(L[8]), mk3(L[9]), mk3(L[10]), shadowOrg, ldir, kEps, shadowMax, tt, tu, tv);
+                                                }
+                                                if (!occludedByLight) {
+                                                    // a.w: depth of this vertex, for the path signature of the counting build
+                                                    storeRecord(pool, slot, 0u, 0u, shadowOrg, shadowMax, ldir, clamped, static_cast<float>(depth), mk3(0.0f));
+                                                    want[0] = true;
+                                                }
                                             }
                                         }
                                     }

@@ -21,7 +21,8 @@ for CNT in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d "$OUT/pass$i" -- $BENCH > "$OUT/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -3 "$OUT/pass$i.log"; }
 done
-python3 "$ROOT/tools/summarize_solo.py" "$OUT" "$ROOT/gpurun_out/$TAG.json" "$*"
+ARGS="$*"
+python3 "$ROOT/tools/summarize_solo.py" "$OUT" "$ROOT/gpurun_out/$TAG.json" "${ARGS//$ROOT\//}"   # repository-relative paths in the record
 find "$OUT" -name "*kernel_trace.csv" -delete
 find "$OUT" -name "*counter_collection.csv" -delete
 cp "$OUT"/stats/*/*kernel_stats.csv "$ROOT/gpurun_out/${TAG}_kernel_stats.csv" 2>/dev/null
