@@ -152,7 +152,8 @@ struct PtrDeviceScene {
     DeviceBuffer<float4> rayBatch;
     DeviceBuffer<PtrHit> hitBatch;
     uint32_t* pinnedAlive = nullptr;
-    uint32_t traceGrid = 0;
+    uint32_t traceGrid = 0;       // persistent blocks of the traversal kernels: fills every wave slot (also sizes the spill area)
+    uint32_t traceGridHalf = 0;   // ... of k_extend / k_connect when several pool groups run large launches side by side
     // cached partition
     uint32_t cachedW = 0, cachedH = 0, cachedPart = 0, cachedParts = 0, cachedLocalPixels = 0;
 
@@ -170,6 +171,7 @@ namespace {
 constexpr uint32_t kAliveRing = 16;
 constexpr uint32_t kAliveBase = 4;
 constexpr uint32_t kScalarCount = kAliveBase + kAliveRing;
+constexpr uint64_t kHalfGridGroupSlots = 3ull << 20;   // groups at least this large launch k_extend / k_connect on half the wave slots
 constexpr uint32_t kMaxPoolGroups = 8;        // one block of scalars / one spill area per group
 constexpr uint32_t kPinnedHeadsOffset = 16;
 constexpr uint32_t kTexInfoWords = 20;   // kernels/texture.h kTexInfoVec4 uint4 per texture   // pinned staging: [0..15] per-group live-slot counts, then kItemHeads range heads
@@ -177,8 +179,8 @@ constexpr uint32_t kTexInfoWords = 20;   // kernels/texture.h kTexInfoVec4 uint4
 // Stack spill area of one pool group: the larger of the one-ray layout (levels beyond kLdsStackLevels, one column per thread of
 // the persistent grid) and the two-ray layout (levels beyond kDualLdsLevels, two columns per thread).
 size_t spillWordsPerGroup(const PtrDeviceScene& ds) {
-    const size_t classic = static_cast<size_t>(kTraversalStackDepth - kLdsStackLevels) * ds.traceGrid * kTraceBlock;
-    const size_t dual = static_cast<size_t>(kDualSpillLevels) * ds.dualGrid * kTraceBlock * 2u;
+    const size_t classic = static_cast<size_t>(kTraversalStackDepth - kLdsStackLevels) * ds.traceGrid * kTraceGridUnit;
+    const size_t dual = static_cast<size_t>(kDualSpillLevels) * ds.dualGrid * kTraceGridUnit * 2u;
     return std::max(classic, dual);
 }
 
@@ -425,9 +427,14 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
         const int v = std::atoi(e);
         if (v >= 1 && v <= 64) ds.refillBelow = v;
     }
+    // Half the wave slots when the pool runs as several groups of large launches: the kernels of the other groups (k_shade above all,
+    // which needs 128 VGPRs a wave) then always find room beside a traversal kernel instead of queueing behind its last waves, and each
+    // persistent wave sees twice as many rays before its own tail.  Measured on configs 2 / 3 / 4: +3.5 / +1.5 / +1.5 %, one rank of
+    // eight 47.7 -> 44.5 ms; frames of a few milliseconds (config 1) lose 10 % and keep the full grid (profiles/r2_ab_grid_pool_knobs.txt).
+    ds.traceGridHalf = cus * 4u;
     if (const char* e = std::getenv("PTR_TRACE_BLOCKS_PER_CU")) {   // tuning knob
         const int v = std::atoi(e);
-        if (v >= 1 && v <= 16) ds.traceGrid = cus * static_cast<uint32_t>(v);
+        if (v >= 1 && v <= 8) ds.traceGridHalf = ds.traceGrid = cus * static_cast<uint32_t>(v);
     }
     ds.dualGrid = cus * 5u;      // PTR_DUAL_WAVES blocks of 256 threads per CU (kernels/wavefront.hip)
     if (const char* e = std::getenv("PTR_TRAVERSAL")) ds.dualTraversal = std::string(e) == "dual";   // A/B knob
@@ -731,7 +738,8 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         gr.pool.itemReserve += first / 64u;
         gr.pool.slots = std::min(groupSlots, slots - first);
         gr.scalars = ds.scalars.ptr + static_cast<size_t>(g) * kScalarCount;
-        gr.cfg = LaunchConfig{ds.traceGrid, ds.spill.ptr + g * spillWords, gr.scalars + 1, ds.refillBelow};
+        const bool sideBySide = groupCount > 1 && gr.pool.slots >= kHalfGridGroupSlots;
+        gr.cfg = LaunchConfig{sideBySide ? ds.traceGridHalf : ds.traceGrid, ds.spill.ptr + g * spillWords, gr.scalars + 1, ds.refillBelow};
         gr.cfg.dual = ds.dualTraversal;
         gr.cfg.dualGrid = ds.dualGrid;
         gr.cfg.dualRefillAt = ds.dualRefillAt;
@@ -844,7 +852,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
                     // up to the point where the static first chunks of the resident waves cover the whole list and
                     // the head is not touched at all
                     const uint32_t thin = gr.pool.slots / std::max(ds.pinnedAlive[g], 1u);
-                    const uint32_t waves = std::max((gr.cfg.dual ? gr.cfg.dualGrid : gr.cfg.traceGrid) * (kTraceBlock / 64u), 1u);
+                    const uint32_t waves = std::max((gr.cfg.dual ? gr.cfg.dualGrid : gr.cfg.traceGrid) * (kTraceGridUnit / 64u), 1u);
                     const uint32_t perWave = ((gr.pool.slots + waves - 1u) / waves + 63u) / 64u * 64u;
                     const uint32_t cap = ds.feederChunkSparse ? ds.feederChunkSparse : std::max(perWave, ds.feederChunk);
                     gr.feederChunk = std::min(cap, ds.feederChunk * std::max(thin, 1u));

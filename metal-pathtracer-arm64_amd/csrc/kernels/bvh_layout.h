@@ -17,7 +17,11 @@ constexpr uint32_t kRefOffsetMask = 0x03FFFFFFu;
 constexpr uint32_t kMaxLeafPrims = 8u;
 constexpr uint32_t kTraversalStackDepth = 48u;   // builder bounds tree depth below this
 constexpr uint32_t kLdsStackLevels = 16u;        // stack levels kept in LDS; deeper levels spill to HBM
-constexpr uint32_t kTraceBlock = 256u;           // threads per block of the traversal kernels
+#ifndef PTR_TRACE_BLOCK   // 64, 128 or 256
+#define PTR_TRACE_BLOCK 256
+#endif
+constexpr uint32_t kTraceBlock = PTR_TRACE_BLOCK;   // threads per block of the traversal kernels
+constexpr uint32_t kTraceGridUnit = 256u;           // the host sizes traversal grids (and the spill area) in units of this many threads
 // two-rays-per-lane kernels (traverse_dual.h): stack levels per ray kept in LDS - 2 rays x 14 levels x 256 lanes x 4 B = 28 KB per
 // block, 140 KB for the 5 blocks a CU holds (the kernels need 93-96 VGPRs: 5 waves per SIMD)
 #ifndef PTR_DUAL_LDS_LEVELS

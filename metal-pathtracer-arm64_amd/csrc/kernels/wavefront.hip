@@ -2098,11 +2098,20 @@ __global__ void k_debug_camera(RenderParams rp, const uint32_t* xys, uint64_t n,
 // =====================================================================================================
 static inline uint32_t ceilDiv(uint64_t a, uint32_t b) { return static_cast<uint32_t>((a + b - 1) / b); }
 
+// The host sizes the traversal grids in units of kTraceGridUnit threads; the kernels may be built with smaller blocks (PTR_TRACE_BLOCK in
+// bvh_layout.h): same number of resident threads, so the spill area and its stride are unchanged.
+static inline LaunchConfig perBlockSize(LaunchConfig cfg) {
+    cfg.traceGrid *= kTraceGridUnit / kTraceBlock;
+    cfg.dualGrid *= kTraceGridUnit / kTraceBlock;
+    return cfg;
+}
+
 void launchGenerate(const RenderParams& rp, const PathPool& pool, hipStream_t stream) {
     hipLaunchKernelGGL(k_generate, dim3(ceilDiv(pool.slots, 256)), dim3(256), 0, stream, rp, pool);
 }
 
-void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, uint32_t* aliveOut, bool count, hipStream_t stream) {
+void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig& cfgIn, uint32_t* aliveOut, bool count, hipStream_t stream) {
+    const LaunchConfig cfg = perBlockSize(cfgIn);
     if (cfg.dual) {
         // two rays per lane: PTR_DUAL_WAVES blocks per CU are resident, each thread owns two spill columns
         const uint32_t stride = cfg.dualGrid * kTraceBlock * 2u;
@@ -2148,7 +2157,8 @@ void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& po
     }
 }
 
-void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count, hipStream_t stream) {
+void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfgIn, bool count, hipStream_t stream) {
+    const LaunchConfig cfg = perBlockSize(cfgIn);
     if (cfg.dual) {
         const uint32_t stride = cfg.dualGrid * kTraceBlock * 2u;
         auto launch = [&](auto kernel) {
@@ -2184,8 +2194,9 @@ void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& 
     }
 }
 
-void launchTail(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, uint32_t* dList, uint32_t* dListCount,
+void launchTail(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfgIn, uint32_t* dList, uint32_t* dListCount,
                 uint32_t* dListHead, bool count, hipStream_t stream) {
+    const LaunchConfig cfg = perBlockSize(cfgIn);
     // dListCount and dListHead are zero on entry (the caller clears them on the same stream)
     const uint32_t collectGrid = std::max(1u, std::min(cfg.traceGrid, ceilDiv(pool.slots, 256u * 16u)));
     hipLaunchKernelGGL(k_tail_collect, dim3(collectGrid), dim3(256), 0, stream, pool, dList, dListCount);
@@ -2212,8 +2223,9 @@ void launchInterleaveBands(const float* dGathered, const uint64_t* dPartOffset, 
     hipLaunchKernelGGL(k_interleave_bands, dim3(ceilDiv(floats, 256)), dim3(256), 0, stream, dGathered, dPartOffset, parts, width, height, dImage);
 }
 
-void launchTraceRays(const SceneView& sc, const float4* dRays, uint64_t n, bool anyHit, PtrHit* dOut, const LaunchConfig& cfg,
+void launchTraceRays(const SceneView& sc, const float4* dRays, uint64_t n, bool anyHit, PtrHit* dOut, const LaunchConfig& cfgIn,
                      uint64_t* dCounters, hipStream_t stream) {
+    const LaunchConfig cfg = perBlockSize(cfgIn);
     const uint32_t stride = cfg.traceGrid * kTraceBlock;
     const uint32_t grid = std::min(cfg.traceGrid, std::max(1u, ceilDiv(n, kTraceBlock)));
     if (anyHit) {
@@ -2223,8 +2235,9 @@ void launchTraceRays(const SceneView& sc, const float4* dRays, uint64_t n, bool 
     }
 }
 
-void launchAovs(const RenderParams& rp, const SceneView& sc, uint32_t sample, float4* dAlbedo, float4* dNormal, const LaunchConfig& cfg,
+void launchAovs(const RenderParams& rp, const SceneView& sc, uint32_t sample, float4* dAlbedo, float4* dNormal, const LaunchConfig& cfgIn,
                 hipStream_t stream) {
+    const LaunchConfig cfg = perBlockSize(cfgIn);
     const uint32_t pixels = rp.width * rp.height;
     const uint32_t stride = cfg.traceGrid * kTraceBlock;
     const uint32_t grid = std::min(cfg.traceGrid, std::max(1u, ceilDiv(pixels, kTraceBlock)));
