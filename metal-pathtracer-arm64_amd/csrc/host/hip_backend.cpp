@@ -128,6 +128,8 @@ struct PtrDeviceScene {
     DeviceBuffer<float2> hit;
     DeviceBuffer<uint8_t> pending;
     DeviceBuffer<uint32_t> flushItem, signature, tailList, tailWords;
+    DeviceBuffer<uint32_t> connectList, connectCounts;   // PathPool::connectList: per group a list and two sets of sub-list counters
+    bool connectLists = true;                            // PTR_CONNECT_LIST=0: k_connect probes the slots (A/B knob)
     // end of the frame: once the item queue is dry and at most this many slots are still alive, the remaining paths are finished by
     // k_tail_run (one lane per path, no launches between bounces) instead of further extend / shade / connect rounds; 0 = never
     uint64_t tailBelow = 512ull << 10;
@@ -446,6 +448,7 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
         const int v = std::atoi(e);
         if (v >= 1 && v <= 128) ds.dualRefillAt = v;
     }
+    if (const char* e = std::getenv("PTR_CONNECT_LIST")) ds.connectLists = std::atoi(e) != 0;   // A/B knob
     if (const char* e = std::getenv("PTR_TAIL_BELOW")) ds.tailBelow = std::strtoull(e, nullptr, 10);   // tuning knob (0 = off)
     if (const char* e = std::getenv("PTR_POOL_SLOTS")) {   // tuning knob: resident path slots
         const unsigned long long v = std::strtoull(e, nullptr, 10);
@@ -699,6 +702,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         uint32_t* scalars;
         bool done;
         uint32_t feederChunk;   // slots per work-head atomic; grows as the group drains at the end of the frame
+        uint32_t* connectCounts = nullptr;   // two sets of sub-list counters, used in turn
     };
     uint32_t groupCount = std::min<uint32_t>(soloGroup ? 1u : ds.poolGroups, std::max<uint32_t>(1u, slots >> 20));   // >= 1 Mi slots per group
     const uint32_t groupSlots = ((slots + groupCount - 1u) / groupCount + 255u) & ~255u;
@@ -714,6 +718,15 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         ds.groupEvents.push_back(e);
     }
     const size_t spillWords = spillWordsPerGroup(ds);
+    // connect lists: sub-list w % 64 takes the entries of k_shade's wave w, at most 64 each
+    const uint32_t connectRegion = ((groupSlots + 63u) / 64u + kConnectQueues - 1u) / kConnectQueues * 64u;
+    const size_t connectListWords = static_cast<size_t>(connectRegion) * kConnectQueues;
+    const size_t connectCountWords = static_cast<size_t>(kConnectQueues) * kConnectCountStride;   // one set
+    const bool connectLists = ds.connectLists && !ds.dualTraversal && slots < (1u << kConnectMaskShift);
+    if (connectLists) {
+        ds.connectList.ensure(connectListWords * groupCount);
+        ds.connectCounts.ensure(connectCountWords * 2u * kMaxPoolGroups);
+    }
     std::vector<Group> groups(groupCount);
     for (uint32_t g = 0; g < groupCount; ++g) {
         Group& gr = groups[g];
@@ -737,6 +750,11 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         }
         gr.pool.itemReserve += first / 64u;
         gr.pool.slots = std::min(groupSlots, slots - first);
+        if (connectLists) {
+            gr.pool.connectList = ds.connectList.ptr + connectListWords * g;
+            gr.pool.connectRegion = connectRegion;
+            gr.connectCounts = ds.connectCounts.ptr + connectCountWords * 2u * g;
+        }
         gr.scalars = ds.scalars.ptr + static_cast<size_t>(g) * kScalarCount;
         const bool sideBySide = groupCount > 1 && gr.pool.slots >= kHalfGridGroupSlots;
         gr.cfg = LaunchConfig{sideBySide ? ds.traceGridHalf : ds.traceGrid, ds.spill.ptr + g * spillWords, gr.scalars + 1, ds.refillBelow};
@@ -770,6 +788,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
 
     if (count && (passFlags & 1u)) HIP_CHECK(hipMemsetAsync(ds.counters.ptr, 0, sizeof(uint64_t) * kCounterSlots, stream));   // counters add up over the passes
     HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * kScalarCount * kMaxPoolGroups, stream));
+    if (connectLists) HIP_CHECK(hipMemsetAsync(ds.connectCounts.ptr, 0, sizeof(uint32_t) * connectCountWords * 2u * kMaxPoolGroups, stream));
     {
         uint32_t* heads = ds.pinnedAlive + kPinnedHeadsOffset;
         for (uint32_t k = 0; k < kItemHeads; ++k) {
@@ -817,6 +836,10 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
             // work heads and the next live-slot counter are cleared by k_shade (all zero at the start of the frame)
             const ShadeResets resets{gr.scalars + 1, gr.scalars + 2, gr.scalars + kAliveBase + (ring + 1u) % kAliveRing,
                                      (queueDry && gr.feederChunk > ds.feederChunk) ? 1u : 0u};
+            if (gr.connectCounts) {   // this iteration's counters, and the set k_shade clears for the next one
+                gr.pool.connectCount = gr.connectCounts + connectCountWords * (iterations & 1u);
+                gr.pool.connectClear = gr.connectCounts + connectCountWords * ((iterations + 1u) & 1u);
+            }
             timedLaunch(0, gr.stream, [&] { launchExtend(ds.view, gr.pool, gr.cfg, queueDry ? aliveSlot : nullptr, count, gr.stream); });
             timedLaunch(1, gr.stream, [&] { launchShade(rp, ds.view, gr.pool, resets, count, gr.stream); });
             timedLaunch(2, gr.stream, [&] { launchConnect(rp, ds.view, gr.pool, gr.cfg, count, gr.stream); });

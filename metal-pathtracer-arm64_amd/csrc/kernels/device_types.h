@@ -168,7 +168,19 @@ struct PathPool {
     uint64_t* counters;        // kCounterSlots
     uint32_t slots;            // slots of this pool (or of this group of the pool)
     uint32_t recStride;        // slots of the WHOLE pool: distance between the fields / record slots of `rec`
+    // Connect list: k_shade appends every slot that queued light-connection records (entry = slot | record mask << kConnectMaskShift)
+    // and k_connect walks the list instead of probing every slot's pending byte.  kConnectQueues sub-lists, each with its own
+    // counter kConnectCountStride words apart (one shared counter would be a same-address atomic per k_shade wave); wave w of
+    // k_shade appends to sub-list w % kConnectQueues, which therefore never holds more than connectRegion entries.  The counters are
+    // double-buffered by iteration parity so that k_shade can clear the set the next iteration appends to.
+    uint32_t* connectList;     // null: k_connect probes the slots (two-rays-per-lane build, end-of-frame kernels)
+    uint32_t* connectCount;    // counters of this iteration
+    uint32_t* connectClear;    // counters of the next iteration (k_shade zeroes them)
+    uint32_t connectRegion;    // entries per sub-list
 };
+constexpr uint32_t kConnectQueues = 64u;
+constexpr uint32_t kConnectCountStride = 64u;    // words: 256 B between counters
+constexpr uint32_t kConnectMaskShift = 27u;      // slot indices stay below 2^27 (the pool is capped at 64 Mi slots)
 
 // flags word (ray1.w)
 constexpr uint32_t kFlagAlive = 1u << 0;

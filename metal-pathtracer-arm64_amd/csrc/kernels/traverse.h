@@ -176,10 +176,18 @@ struct Trav {
     f3 oi;               // org*inv in the space of the node boxes (world, or grid cells for quantised nodes)
     float tnear;
     TraceHit hit;
-    uint32_t cur;        // internal node index, or leaf reference while primitives remain
-    uint32_t leafPos;    // next primitive inside the current leaf
+    uint32_t cur;        // internal node index, or leaf reference while primitives remain (postponing build: kRefEmpty = nothing left to walk)
+    uint32_t leafPos;    // next primitive inside the current leaf (postponing build: the postponed leaf's reference, advanced in place)
     bool anyHit;
 };
+
+// PTR_POSTPONE_LEAVES: a lane that reaches a leaf parks it (one leaf per lane) and keeps walking; primitive steps then serve the
+// parked leaves of many lanes at once (Aila & Laine's speculative traversal, adapted to the wave vote).  The walk after a parked
+// leaf uses the ray's old extent, so it may fetch nodes the leaf's hit would have culled - work a waiting lane would not have done
+// at all, so it costs no wave step.  Every leaf whose box passes the test is still tested: results are unchanged.
+#ifndef PTR_POSTPONE_LEAVES
+#define PTR_POSTPONE_LEAVES 0
+#endif
 
 // NODES: 1 = 32 B quantised nodes, 0 = 64 B float nodes (compile-time choice of the persistent kernels), -1 = decided by the scene's
 // flag at run time (the cold kernels: ray-batch queries, feature buffers, chains, the end-of-frame kernel)
@@ -212,18 +220,29 @@ __device__ __forceinline__ bool travBegin(const SceneView& sc, Trav& t, f3 org, 
     t.hit.prim = kHitMiss;
     t.anyHit = anyHit;
     t.cur = sc.rootRef;
-    t.leafPos = 0u;
+    t.leafPos = PTR_POSTPONE_LEAVES ? kRefEmpty : 0u;
     stack.sp = 0;
     if (sc.oversizeRef != kRefEmpty) {
         // the few triangles kept out of the tree (bvh_builder.cpp) come first: their hits shorten the ray before the walk
+        if (PTR_POSTPONE_LEAVES) {
+            t.leafPos = sc.oversizeRef;   // parked from the start; the walk begins at the root beside it
+            return true;
+        }
         if (sc.rootRef != kRefEmpty) stack.push(sc.rootRef);
         t.cur = sc.oversizeRef;
         return true;
+    }
+    if (PTR_POSTPONE_LEAVES && sc.rootRef != kRefEmpty && (sc.rootRef & kRefLeafBit)) {   // a scene of one leaf
+        t.leafPos = sc.rootRef;
+        t.cur = kRefEmpty;
     }
     return sc.rootRef != kRefEmpty;
 }
 
 __device__ __forceinline__ bool travAtLeaf(const Trav& t) { return (t.cur & kRefLeafBit) != 0u; }
+// postponing build: the lane can take a node step / has a parked leaf
+__device__ __forceinline__ bool travCanWalk(const Trav& t) { return (t.cur & kRefLeafBit) == 0u; }
+__device__ __forceinline__ bool travHasParked(const Trav& t) { return t.leafPos != kRefEmpty; }
 
 // pops the next subtree; false when the traversal is complete
 __device__ __forceinline__ bool travPop(Trav& t, LaneStack& stack) {
@@ -231,6 +250,18 @@ __device__ __forceinline__ bool travPop(Trav& t, LaneStack& stack) {
     t.cur = stack.pop();
     t.leafPos = 0u;
     return true;
+}
+
+// postponing build: next subtree or kRefEmpty
+__device__ __forceinline__ uint32_t travPopOrNone(LaneStack& stack) { return stack.sp == 0 ? kRefEmpty : stack.pop(); }
+// postponing build: a leaf in `cur` moves to the parking place when that is free, and the walk goes on below it
+template <bool COUNT>
+__device__ __forceinline__ void travPark(Trav& t, LaneStack& stack, TraceCounters& cnt) {
+    if (t.leafPos == kRefEmpty && t.cur != kRefEmpty && (t.cur & kRefLeafBit)) {
+        t.leafPos = t.cur;
+        t.cur = travPopOrNone(stack);
+        if (COUNT) { ++cnt.nodes; ++cnt.leaves; }
+    }
 }
 
 __device__ __forceinline__ f3 gridLo(uint32_t w0, uint32_t w1) {
@@ -266,26 +297,51 @@ __device__ __forceinline__ bool travNodeStep(const SceneView& sc, const SceneMem
     h0 = h0 & (ref0 != kRefEmpty);
     h1 = h1 & (ref1 != kRefEmpty);
     if (COUNT) ++cnt.nodes;
-    t.leafPos = 0u;
     const bool firstIs0 = e0 <= e1;
     const uint32_t nearRef = (h0 & (firstIs0 | !h1)) ? ref0 : ref1;
     const uint32_t farRef = firstIs0 ? ref1 : ref0;
+#if PTR_POSTPONE_LEAVES
+    uint32_t next = (h0 | h1) ? nearRef : kRefEmpty;
+    uint32_t other = (h0 & h1) ? farRef : kRefEmpty;
+    if ((next & kRefLeafBit) && next != kRefEmpty && t.leafPos == kRefEmpty) {
+        // a near leaf is parked and the walk continues with the far child (instead of pushing it)
+        t.leafPos = next;
+        next = other;
+        other = kRefEmpty;
+        if (COUNT) { ++cnt.nodes; ++cnt.leaves; }
+    }
+    if (other != kRefEmpty) stack.push(other);
+    if (next == kRefEmpty) next = travPopOrNone(stack);
+    t.cur = next;
+    travPark<COUNT>(t, stack, cnt);   // a popped leaf, parking place free: park it and pop once more
+    return t.cur != kRefEmpty || t.leafPos != kRefEmpty;
+#else
+    t.leafPos = 0u;
     if (h0 & h1) stack.push(farRef);
     if (h0 | h1) {
         t.cur = nearRef;
         return true;
     }
     return travPop(t, stack);
+#endif
 }
 
 // Primitive step (t.cur is a leaf): tests primitive number t.leafPos of the leaf.  Returns false once finished.
 template <bool COUNT>
 __device__ __forceinline__ bool travPrimStep(const SceneView& sc, const SceneMem& mem, Trav& t, LaneStack& stack, TraceCounters& cnt) {
+#if PTR_POSTPONE_LEAVES
+    // the parked leaf: its reference is advanced in place (first primitive + 1, count - 1)
+    const uint32_t cur = t.leafPos;
+    const uint32_t index = cur & kRefOffsetMask;
+    const bool last = ((cur >> kRefCountShift) & 0xFu) == 0u;
+    if (COUNT) ++cnt.prims;
+#else
     const uint32_t cur = t.cur;
     const uint32_t first = cur & kRefOffsetMask;
     const uint32_t count = ((cur >> kRefCountShift) & 0xFu) + 1u;
     const uint32_t index = first + t.leafPos;
     if (COUNT) { ++cnt.prims; if (t.leafPos == 0u) { ++cnt.nodes; ++cnt.leaves; } }
+#endif
     if (cur & kRefSphereBit) {
         float tt;
         if (sphereTest(sc.spheres[index], t.org, t.dir, t.tnear, t.hit.t, tt)) {
@@ -303,8 +359,18 @@ __device__ __forceinline__ bool travPrimStep(const SceneView& sc, const SceneMem
             if (t.anyHit) return false;
         }
     }
+#if PTR_POSTPONE_LEAVES
+    if (!last) {
+        t.leafPos = cur + 1u - (1u << kRefCountShift);
+        return true;
+    }
+    t.leafPos = kRefEmpty;
+    travPark<COUNT>(t, stack, cnt);   // a leaf that was waiting in `cur` takes the place
+    return t.cur != kRefEmpty || t.leafPos != kRefEmpty;
+#else
     if (++t.leafPos < count) return true;
     return travPop(t, stack);
+#endif
 }
 
 #ifndef PTR_EXTRA_NODE_STEPS
@@ -323,6 +389,44 @@ __device__ __forceinline__ bool travPrimStep(const SceneView& sc, const SceneMem
 
 // One wave iteration for all traversing lanes: majority vote between node steps and primitive steps.
 // Returns (per lane) false when that lane's ray has just finished.  Lanes not voted for return true unchanged.
+#if PTR_POSTPONE_LEAVES
+#ifndef PTR_PARK_PRIM_AT   // a primitive step is also taken once this many lanes have a leaf parked
+#define PTR_PARK_PRIM_AT 48
+#endif
+template <bool COUNT, int NODES = -1>
+__device__ __forceinline__ bool travVote(const SceneView& sc, const SceneMem& mem, Trav& t, bool active, LaneStack& stack,
+                                         TraceCounters& cnt) {
+    const bool canWalk = active && travCanWalk(t);
+    const bool stuck = active && !travCanWalk(t);   // nothing to walk before a primitive step: a second leaf, or only the parked one
+    const bool parked = active && travHasParked(t);
+    const int nWalk = __popcll(__ballot(canWalk));
+    const int nStuck = __popcll(__ballot(stuck));
+    const int nParked = __popcll(__ballot(parked));
+    bool more = true;
+    if (nWalk >= nStuck * PTR_PRIM_BIAS && nParked < PTR_PARK_PRIM_AT) {
+        if (COUNT) ++cnt.waveNodeSteps;
+        if (canWalk) more = travNodeStep<COUNT, NODES>(sc, mem, t, stack, cnt);
+#pragma unroll
+        for (int extra = 0; extra < PTR_EXTRA_NODE_STEPS; ++extra) {
+            const bool again = canWalk && more && travCanWalk(t);
+            if (static_cast<int>(__popcll(__ballot(again))) * PTR_REPEAT_DEN < nWalk * PTR_REPEAT_NUM) break;
+            if (COUNT) ++cnt.waveNodeSteps;
+            if (again) more = travNodeStep<COUNT, NODES>(sc, mem, t, stack, cnt);
+        }
+    } else {
+        if (COUNT) ++cnt.wavePrimSteps;
+        if (parked) more = travPrimStep<COUNT>(sc, mem, t, stack, cnt);
+#pragma unroll
+        for (int extra = 0; extra < PTR_EXTRA_PRIM_STEPS; ++extra) {
+            const bool again = parked && more && travHasParked(t);
+            if (static_cast<int>(__popcll(__ballot(again))) * PTR_REPEAT_DEN < nParked * PTR_REPEAT_NUM) break;
+            if (COUNT) ++cnt.wavePrimSteps;
+            if (again) more = travPrimStep<COUNT>(sc, mem, t, stack, cnt);
+        }
+    }
+    return more;
+}
+#else
 template <bool COUNT, int NODES = -1>
 __device__ __forceinline__ bool travVote(const SceneView& sc, const SceneMem& mem, Trav& t, bool active, LaneStack& stack,
                                          TraceCounters& cnt) {
@@ -356,6 +460,7 @@ __device__ __forceinline__ bool travVote(const SceneView& sc, const SceneMem& me
     }
     return more;
 }
+#endif
 
 // Whole-ray loop for one lane (ray-batch queries, MNEE chains): closest hit (ANY = false) or first hit
 // (ANY = true).  Returns hit.prim == kHitMiss on a miss.  Same step functions as the persistent kernels.
@@ -367,7 +472,11 @@ __device__ __forceinline__ TraceHit traverse(const SceneView& sc, f3 org, f3 dir
     if (!travBegin(sc, t, org, dir, tnear, tfar, ANY, stack)) return t.hit;
     bool more = true;
     while (more) {
+#if PTR_POSTPONE_LEAVES
+        more = travCanWalk(t) ? travNodeStep<COUNT>(sc, mem, t, stack, cnt) : travPrimStep<COUNT>(sc, mem, t, stack, cnt);
+#else
         more = travAtLeaf(t) ? travPrimStep<COUNT>(sc, mem, t, stack, cnt) : travNodeStep<COUNT>(sc, mem, t, stack, cnt);
+#endif
     }
     return t.hit;
 }

@@ -1413,6 +1413,20 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
         if (SSS && pool.cone && stillAlive && (haveCone || newSample)) pool.cone[slot] = newSample ? primaryCone(rp) : cone;
     }
 
+    if (!TAIL && pool.connectList) {
+        // one atomic per wave that queued anything, on the sub-list of this wave (see PathPool::connectList)
+        const bool queued = touched && pendingMask != 0u;
+        const unsigned long long mask = __ballot(queued);
+        if (mask != 0ull) {
+            const uint32_t queue = __builtin_amdgcn_readfirstlane(slot >> 6) & (kConnectQueues - 1u);
+            uint32_t base = 0u;
+            if (laneId() == 0u) base = atomicAdd(pool.connectCount + queue * kConnectCountStride, static_cast<uint32_t>(__popcll(mask)));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << laneId()) - 1ull)));
+            if (queued) pool.connectList[queue * pool.connectRegion + base + rank] = slot | (pendingMask << kConnectMaskShift);
+        }
+    }
+
     if (COUNT) {
         counts.shadedHit += shadedHit;
         counts.triHit += triHit;
@@ -1430,6 +1444,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
         if (resets.connectHead) *resets.connectHead = 0u;
         if (resets.nextAlive) *resets.nextAlive = 0u;
     }
+    if (slot < kConnectQueues && pool.connectClear) pool.connectClear[slot * kConnectCountStride] = 0u;   // the next iteration's counters
     ShadeCounts counts;
     shadeSlot<COUNT, SSS, false>(rp, sc, pool, slot, slot < pool.slots, resets.drained != 0u, counts);
     if (COUNT) {
@@ -1554,8 +1569,26 @@ __global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_e
     // The work list is the slot pool itself: a lane takes a slot, reads its pending mask and resolves that
     // slot's records one after another (no compaction queue -> no hot atomic counter in k_shade).
     const SceneMem mem = sceneMem(sc);
+    // With a connect list (PathPool::connectList) the work is the list's entries: lane l reads the counter of sub-list l, a wave
+    // prefix sum gives every sub-list its place in one dense index space, and a lane finds the sub-list of an index with six
+    // cross-lane reads.  Measured before: 3.5 slots probed per ray found on config 2 (a third of the slots queue a record), more as
+    // the frame drains, and the probing passes were a third of the kernel's instructions.
+    const bool listed = pool.connectList != nullptr;
+    uint32_t listBefore = 0u;   // lane l: entries in sub-lists 0..l-1
+    uint32_t listTotal = pool.slots;
+    if (listed) {
+        const uint32_t mine = min(pool.connectCount[laneId() * kConnectCountStride], pool.connectRegion);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (static_cast<int>(laneId()) >= off) incl += up;
+        }
+        listBefore = incl - mine;
+        listTotal = __builtin_amdgcn_readlane(incl, 63);
+    }
     WaveFeeder feeder;
-    feeder.init(workCounter, pool.slots, feederChunk);
+    feeder.init(workCounter, listTotal, listed ? 256u : feederChunk);
     Trav t;
     t.cur = 0u;
     bool active = false;
@@ -1572,7 +1605,22 @@ __global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_e
             // every idle lane.  Starting records lane by lane as they finish stalled the whole wave on each load.
             if (!feeder.exhausted) {
                 const uint32_t idx = feeder.take(!active && bits == 0u);
-                if (idx != WaveFeeder::kNone) {
+                if (listed) {
+                    // largest sub-list whose first index is <= idx (empty sub-lists share their successor's start and lose)
+                    const uint32_t want = idx != WaveFeeder::kNone ? idx : 0u;
+                    uint32_t queue = 0u;
+#pragma unroll
+                    for (uint32_t step = kConnectQueues / 2u; step != 0u; step >>= 1) {
+                        const uint32_t before = __shfl(listBefore, static_cast<int>(queue + step), 64);
+                        if (before <= want) queue += step;
+                    }
+                    const uint32_t before = __shfl(listBefore, static_cast<int>(queue), 64);
+                    if (idx != WaveFeeder::kNone) {
+                        const uint32_t entry = pool.connectList[queue * pool.connectRegion + (want - before)];
+                        mySlot = entry & ((1u << kConnectMaskShift) - 1u);
+                        bits = entry >> kConnectMaskShift;
+                    }
+                } else if (idx != WaveFeeder::kNone) {
                     mySlot = idx;
                     bits = pool.pending[idx] & kFlagPendingMask;
                 }

@@ -11,9 +11,13 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 # Tuning / debugging knobs of the library (csrc/host/hip_backend.cpp reads them at upload and render time).  A value
 # left in the caller's environment (a sweep, an A/B run) must not reach the tests: they pin the library's defaults.
-_KEEP = {"PTR_TEST_VERBOSE"}
+# PTR_TEST_VARIANT=<name> is the one deliberate exception: it runs the suite against variants/libptr_<name>.so (an A/B build of
+# tools/build_variant.sh), so a kernel variant is parity-checked before it is timed.
+_KEEP = {"PTR_TEST_VERBOSE", "PTR_TEST_VARIANT"}
 for _name in [k for k in os.environ if k.startswith("PTR_") and k not in _KEEP]:
     del os.environ[_name]
+if os.environ.get("PTR_TEST_VARIANT"):
+    os.environ["PTR_HIP_LIBRARY"] = os.path.join(ROOT, "variants", "libptr_%s.so" % os.environ["PTR_TEST_VARIANT"])
 
 
 def pytest_configure(config):
