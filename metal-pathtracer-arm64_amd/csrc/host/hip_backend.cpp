@@ -129,6 +129,8 @@ struct PtrDeviceScene {
     DeviceBuffer<uint8_t> pending;
     DeviceBuffer<uint32_t> flushItem, signature, tailList, tailWords;
     DeviceBuffer<uint32_t> connectList, connectCounts;   // PathPool::connectList: per group a list and two sets of sub-list counters
+    DeviceBuffer<uint32_t> busyLists, busyCounts;        // PathPool::busyIn / busyOut: per group two lists and three sets of counters
+    uint32_t busyBelow = 1;                              // PTR_BUSY_LISTS=0: no busy lists at the end of the frame (A/B knob)
     bool connectLists = true;                            // PTR_CONNECT_LIST=0: k_connect probes the slots (A/B knob)
     // end of the frame: once the item queue is dry and at most this many slots are still alive, the remaining paths are finished by
     // k_tail_run (one lane per path, no launches between bounces) instead of further extend / shade / connect rounds; 0 = never
@@ -448,6 +450,7 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
         const int v = std::atoi(e);
         if (v >= 1 && v <= 128) ds.dualRefillAt = v;
     }
+    if (const char* e = std::getenv("PTR_BUSY_LISTS")) ds.busyBelow = std::atoi(e) != 0 ? 1u : 0u;   // A/B knob
     if (const char* e = std::getenv("PTR_CONNECT_LIST")) ds.connectLists = std::atoi(e) != 0;   // A/B knob
     if (const char* e = std::getenv("PTR_TAIL_BELOW")) ds.tailBelow = std::strtoull(e, nullptr, 10);   // tuning knob (0 = off)
     if (const char* e = std::getenv("PTR_POOL_SLOTS")) {   // tuning knob: resident path slots
@@ -703,6 +706,13 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         bool done;
         uint32_t feederChunk;   // slots per work-head atomic; grows as the group drains at the end of the frame
         uint32_t* connectCounts = nullptr;   // two sets of sub-list counters, used in turn
+        // busy lists (end of the frame): two lists and three counter sets in rotation.  busyStage 0: the kernels walk the slots;
+        // 1: this iteration's k_shade (still walking the slots) fills the first list; 2: k_extend and k_shade walk the list of the
+        // previous iteration and k_shade fills the next one
+        uint32_t* busyLists = nullptr;
+        uint32_t* busyCounts = nullptr;
+        uint32_t busyStage = 0, busyTurn = 0;
+        bool shadeListed = false;
     };
     uint32_t groupCount = std::min<uint32_t>(soloGroup ? 1u : ds.poolGroups, std::max<uint32_t>(1u, slots >> 20));   // >= 1 Mi slots per group
     const uint32_t groupSlots = ((slots + groupCount - 1u) / groupCount + 255u) & ~255u;
@@ -726,6 +736,11 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
     if (connectLists) {
         ds.connectList.ensure(connectListWords * groupCount);
         ds.connectCounts.ensure(connectCountWords * 2u * kMaxPoolGroups);
+    }
+    const bool busyLists = connectLists && ds.busyBelow > 0u;
+    if (busyLists) {
+        ds.busyLists.ensure(connectListWords * 2u * groupCount);
+        ds.busyCounts.ensure(connectCountWords * 3u * kMaxPoolGroups);
     }
     std::vector<Group> groups(groupCount);
     for (uint32_t g = 0; g < groupCount; ++g) {
@@ -754,6 +769,10 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
             gr.pool.connectList = ds.connectList.ptr + connectListWords * g;
             gr.pool.connectRegion = connectRegion;
             gr.connectCounts = ds.connectCounts.ptr + connectCountWords * 2u * g;
+        }
+        if (busyLists) {
+            gr.busyLists = ds.busyLists.ptr + connectListWords * 2u * g;
+            gr.busyCounts = ds.busyCounts.ptr + connectCountWords * 3u * g;
         }
         gr.scalars = ds.scalars.ptr + static_cast<size_t>(g) * kScalarCount;
         const bool sideBySide = groupCount > 1 && gr.pool.slots >= kHalfGridGroupSlots;
@@ -789,6 +808,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
     if (count && (passFlags & 1u)) HIP_CHECK(hipMemsetAsync(ds.counters.ptr, 0, sizeof(uint64_t) * kCounterSlots, stream));   // counters add up over the passes
     HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * kScalarCount * kMaxPoolGroups, stream));
     if (connectLists) HIP_CHECK(hipMemsetAsync(ds.connectCounts.ptr, 0, sizeof(uint32_t) * connectCountWords * 2u * kMaxPoolGroups, stream));
+    if (busyLists) HIP_CHECK(hipMemsetAsync(ds.busyCounts.ptr, 0, sizeof(uint32_t) * connectCountWords * 3u * kMaxPoolGroups, stream));
     {
         uint32_t* heads = ds.pinnedAlive + kPinnedHeadsOffset;
         for (uint32_t k = 0; k < kItemHeads; ++k) {
@@ -840,9 +860,30 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
                 gr.pool.connectCount = gr.connectCounts + connectCountWords * (iterations & 1u);
                 gr.pool.connectClear = gr.connectCounts + connectCountWords * ((iterations + 1u) & 1u);
             }
+            if (queueDry && gr.busyLists && gr.busyStage == 0u) gr.busyStage = 1u;   // the kernels decide per launch whether a list pays
+            if (gr.busyStage != 0u) {
+                // k_shade fills list `busyTurn` (counter set busyTurn % 3) and clears the set after it; in stage 2 this iteration's
+                // k_extend and k_shade walk the list the previous iteration filled
+                const uint32_t turn = gr.busyTurn;
+                gr.pool.busyOut = gr.busyLists + connectListWords * (turn & 1u);
+                gr.pool.busyCountOut = gr.busyCounts + connectCountWords * (turn % 3u);
+                gr.pool.busyCountClear = gr.busyCounts + connectCountWords * ((turn + 1u) % 3u);
+                if (gr.busyStage == 2u) {
+                    gr.pool.busyIn = gr.busyLists + connectListWords * ((turn + 1u) & 1u);
+                    gr.pool.busyCountIn = gr.busyCounts + connectCountWords * ((turn + 2u) % 3u);
+                }
+            }
             timedLaunch(0, gr.stream, [&] { launchExtend(ds.view, gr.pool, gr.cfg, queueDry ? aliveSlot : nullptr, count, gr.stream); });
-            timedLaunch(1, gr.stream, [&] { launchShade(rp, ds.view, gr.pool, resets, count, gr.stream); });
+            // k_shade's list instantiation claims leftover work items lane by lane and is a fifth slower than the plain kernel while
+            // it still walks the slots: it is launched once the last count of live slots says its list is about to pay
+            PathPool shadePool = gr.pool;
+            if (!gr.shadeListed) shadePool.busyIn = nullptr;
+            timedLaunch(1, gr.stream, [&] { launchShade(rp, ds.view, shadePool, resets, count, gr.stream); });
             timedLaunch(2, gr.stream, [&] { launchConnect(rp, ds.view, gr.pool, gr.cfg, count, gr.stream); });
+            if (gr.busyStage != 0u) {
+                gr.busyStage = 2u;
+                ++gr.busyTurn;
+            }
         }
         ++iterations;
         if (iterations >= nextCheck || iterations >= maxIterations) {
@@ -879,6 +920,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
                     const uint32_t perWave = ((gr.pool.slots + waves - 1u) / waves + 63u) / 64u * 64u;
                     const uint32_t cap = ds.feederChunkSparse ? ds.feederChunkSparse : std::max(perWave, ds.feederChunk);
                     gr.feederChunk = std::min(cap, ds.feederChunk * std::max(thin, 1u));
+                    gr.shadeListed = static_cast<uint64_t>(ds.pinnedAlive[g]) * 5u < static_cast<uint64_t>(gr.pool.slots) * 2u;   // < 40 % live
                 }
                 allDone = allDone && gr.done;
             }

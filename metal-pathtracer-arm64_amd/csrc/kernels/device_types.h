@@ -176,8 +176,18 @@ struct PathPool {
     uint32_t* connectList;     // null: k_connect probes the slots (two-rays-per-lane build, end-of-frame kernels)
     uint32_t* connectCount;    // counters of this iteration
     uint32_t* connectClear;    // counters of the next iteration (k_shade zeroes them)
-    uint32_t connectRegion;    // entries per sub-list
+    uint32_t connectRegion;    // entries per sub-list (of the connect list and of the busy lists)
+    // Busy lists (end of the frame, same sub-list layout): once most slots of a group are dead, k_shade appends every slot that still
+    // needs a visit - its path goes on (kBusyAliveBit), or records / a finished item are outstanding - and the next k_extend and
+    // k_shade walk that list instead of the slots, so an iteration costs what its live paths cost.  Three counter sets in rotation:
+    // k_shade reads one, fills the next and clears the third.
+    const uint32_t* busyIn;        // list this iteration's k_extend and k_shade walk (null: they walk the slots)
+    const uint32_t* busyCountIn;
+    uint32_t* busyOut;             // list k_shade fills for the next iteration (null: none)
+    uint32_t* busyCountOut;
+    uint32_t* busyCountClear;
 };
+constexpr uint32_t kBusyAliveBit = 1u << 31;
 constexpr uint32_t kConnectQueues = 64u;
 constexpr uint32_t kConnectCountStride = 64u;    // words: 256 B between counters
 constexpr uint32_t kConnectMaskShift = 27u;      // slot indices stay below 2^27 (the pool is capped at 64 Mi slots)

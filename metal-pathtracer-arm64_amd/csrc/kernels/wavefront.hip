@@ -140,6 +140,47 @@ struct WaveFeeder {
     }
 };
 
+// One wave's view of the kConnectQueues sub-lists of a connect list or a busy list (PathPool): the counters become one dense index
+// space (lane l keeps the number of entries in sub-lists 0..l-1) and an index is turned into a position in the list's storage with
+// six cross-lane reads.
+struct SubLists {
+    uint32_t before;   // lane l: entries in sub-lists 0 .. l-1
+    uint32_t total;
+    __device__ __forceinline__ void init(const uint32_t* counts, uint32_t region) {
+        const uint32_t mine = min(counts[laneId() * kConnectCountStride], region);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (static_cast<int>(laneId()) >= off) incl += up;
+        }
+        before = incl - mine;
+        total = __builtin_amdgcn_readlane(incl, 63);
+    }
+    // must be called by all 64 lanes (converged); idx < total, or anything for lanes that will not use the result
+    __device__ __forceinline__ uint32_t position(uint32_t idx, uint32_t region) const {
+        // largest sub-list whose first index is <= idx (empty sub-lists share their successor's start and lose)
+        uint32_t queue = 0u;
+#pragma unroll
+        for (uint32_t step = kConnectQueues / 2u; step != 0u; step >>= 1) {
+            const uint32_t first = __shfl(before, static_cast<int>(queue + step), 64);
+            if (first <= idx) queue += step;
+        }
+        const uint32_t first = __shfl(before, static_cast<int>(queue), 64);
+        return queue * region + (idx - first);
+    }
+};
+
+// Busy lists (PathPool::busyIn) exist from the moment the work items run out; a launch walks the list instead of the slots once the
+// list is short enough to pay: k_extend as soon as half the slots are off it (a list entry costs one more dependent load, a dead
+// slot a wasted probe), k_shade only below a quarter (its slot state is 16 B words in nine arrays: out of slot order every word
+// costs a 64 B sector, so the list only wins once fewer than ~150/576 of the slots are busy).
+#ifndef PTR_BUSY_EXTEND_DIV
+#define PTR_BUSY_EXTEND_DIV 2
+#endif
+#ifndef PTR_BUSY_SHADE_DIV
+#define PTR_BUSY_SHADE_DIV 4
+#endif
 #ifndef PTR_LIGHT_PRETEST   // A/B switch of the light self-occlusion test in k_shade
 #define PTR_LIGHT_PRETEST 1
 #endif
@@ -475,8 +516,18 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
     const long long kernelStart = COUNT ? clock64() : 0ll;
 
     const SceneMem mem = sceneMem(sc);
+    // end of the frame (the ALIVE instantiation): the work is the busy list k_shade left, not the slots (PathPool::busyIn)
+    bool listed = ALIVE && pool.busyIn != nullptr;
+    SubLists lists{0u, pool.slots};
+    if (listed) {
+        lists.init(pool.busyCountIn, pool.connectRegion);
+        if (static_cast<uint64_t>(lists.total) * PTR_BUSY_EXTEND_DIV >= pool.slots) {   // still too full: walk the slots
+            listed = false;
+            lists.total = pool.slots;
+        }
+    }
     WaveFeeder feeder;
-    feeder.init(workCounter, pool.slots, feederChunk);
+    feeder.init(workCounter, lists.total, listed ? 256u : feederChunk);
     Trav t;
     t.cur = 0u;
     bool active = false;
@@ -486,7 +537,11 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
         if (nActive < kRefillBelow && !feeder.exhausted) {
             if (COUNT) ++refills;
             const long long refillStart = COUNT ? clock64() : 0ll;
-            const uint32_t idx = feeder.take(!active);
+            uint32_t idx = feeder.take(!active);
+            if (listed) {
+                const uint32_t entry = pool.busyIn[lists.position(idx != WaveFeeder::kNone ? idx : 0u, pool.connectRegion)];
+                if (idx != WaveFeeder::kNone) idx = (entry & kBusyAliveBit) ? (entry & ~kBusyAliveBit) : WaveFeeder::kNone;
+            }
             const uint32_t at = idx != WaveFeeder::kNone ? idx : 0u;
             const float4 r0 = pool.ray0[at], r1 = pool.ray1[at];   // both in flight before the liveness test
             const bool live = idx != WaveFeeder::kNone && (__float_as_uint(r1.w) & kFlagAlive);
@@ -828,12 +883,16 @@ struct ShadeCounts {
     uint32_t shadedHit = 0u, triHit = 0u, primary = 0u;   // counting build
 };
 
-// One visit of a path slot: what k_shade does for its thread's slot.  TAIL: the caller is the end-of-frame kernel (k_tail_run),
-// whose lanes hold arbitrary slots and diverge - nothing in here may then rely on the wave (no ballots, no wave-level
-// reservations of work items).
-template <bool COUNT, bool SSS, bool TAIL>
+// One visit of a path slot: what k_shade does for its thread's slot.  MODE kShadeDense: lane l of wave w holds slot 64 w + l.
+// kShadeListed: the lanes hold the slots of a busy list (end of the frame) - the wave is converged but its slots are arbitrary, so
+// work items are claimed lane by lane.  kShadeTail: the caller is the end-of-frame kernel (k_tail_run), whose lanes hold arbitrary
+// slots AND diverge - nothing in here may then rely on the wave (no ballots, no list appends).
+// `listWave`: which sub-list this wave appends to (wave-uniform; unused in kShadeTail).
+constexpr int kShadeDense = 0, kShadeListed = 1, kShadeTail = 2;
+template <bool COUNT, bool SSS, int MODE>
 __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const uint32_t slot, const bool inRange,
-                                          const bool drained, ShadeCounts& counts) {
+                                          const bool drained, const uint32_t listWave, ShadeCounts& counts) {
+    constexpr bool TAIL = MODE == kShadeTail;
     // Everything that depends only on the slot index is requested up front, and the record loads are pointed at a
     // zero word when the record is not pending, so the kernel has ~11 loads in flight per lane after ONE dependent
     // step (the state word) instead of walking a chain of ten load-wait pairs at 5 waves per SIMD.
@@ -1311,7 +1370,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
     }
 
     // ---- claim new work items ----
-    if (TAIL) {
+    if (MODE != kShadeDense) {
         // end of the frame: the range heads are dry; what can be left is the unused part of the last reservation of this slot's
         // 64-slot group (csrc/host/hip_backend.cpp hands a group to the tail kernel only after the heads ran dry)
         if (needItem) {
@@ -1418,12 +1477,26 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
         const bool queued = touched && pendingMask != 0u;
         const unsigned long long mask = __ballot(queued);
         if (mask != 0ull) {
-            const uint32_t queue = __builtin_amdgcn_readfirstlane(slot >> 6) & (kConnectQueues - 1u);
+            const uint32_t queue = __builtin_amdgcn_readfirstlane(listWave) & (kConnectQueues - 1u);
             uint32_t base = 0u;
             if (laneId() == 0u) base = atomicAdd(pool.connectCount + queue * kConnectCountStride, static_cast<uint32_t>(__popcll(mask)));
             base = __builtin_amdgcn_readfirstlane(base);
             const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << laneId()) - 1ull)));
             if (queued) pool.connectList[queue * pool.connectRegion + base + rank] = slot | (pendingMask << kConnectMaskShift);
+        }
+    }
+
+    if (!TAIL && pool.busyOut) {
+        // end of the frame: the slots the next iteration has to visit (same scheme)
+        const bool busy = touched && (stillAlive || pendingMask != 0u || flushNext);
+        const unsigned long long mask = __ballot(busy);
+        if (mask != 0ull) {
+            const uint32_t queue = __builtin_amdgcn_readfirstlane(listWave) & (kConnectQueues - 1u);
+            uint32_t base = 0u;
+            if (laneId() == 0u) base = atomicAdd(pool.busyCountOut + queue * kConnectCountStride, static_cast<uint32_t>(__popcll(mask)));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << laneId()) - 1ull)));
+            if (busy) pool.busyOut[queue * pool.connectRegion + base + rank] = slot | (stillAlive ? kBusyAliveBit : 0u);
         }
     }
 
@@ -1434,19 +1507,38 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
     }
 }
 
-template <bool COUNT, bool SSS>
+// LISTED: the launch walks pool.busyIn instead of the slots (end of the frame, see PathPool)
+template <bool COUNT, bool SSS, bool LISTED>
 __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(RenderParams rp, SceneView sc, PathPool pool, ShadeResets resets) {
-    const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x;
-    if (slot == 0u) {
+    const uint32_t index = blockIdx.x * kShadeBlock + threadIdx.x;
+    if (index == 0u) {
         // k_shade runs between this iteration's k_extend and k_connect: it clears the work heads they will claim from
         // next (and the live-slot counter of the next k_extend), which saves two fill dispatches per iteration
         if (resets.extendHead) *resets.extendHead = 0u;
         if (resets.connectHead) *resets.connectHead = 0u;
         if (resets.nextAlive) *resets.nextAlive = 0u;
     }
-    if (slot < kConnectQueues && pool.connectClear) pool.connectClear[slot * kConnectCountStride] = 0u;   // the next iteration's counters
+    if (index < kConnectQueues) {   // the next iteration's list counters
+        if (pool.connectClear) pool.connectClear[index * kConnectCountStride] = 0u;
+        if (pool.busyCountClear) pool.busyCountClear[index * kConnectCountStride] = 0u;
+    }
     ShadeCounts counts;
-    shadeSlot<COUNT, SSS, false>(rp, sc, pool, slot, slot < pool.slots, resets.drained != 0u, counts);
+    if (LISTED) {
+        SubLists lists;
+        lists.init(pool.busyCountIn, pool.connectRegion);
+        uint32_t slot = index;   // while the list is too long to beat a walk over the slots in order
+        bool inRange = index < pool.slots, drained = resets.drained != 0u;
+        if (static_cast<uint64_t>(lists.total) * PTR_BUSY_SHADE_DIV < pool.slots) {
+            if ((index & ~63u) >= lists.total) return;   // the whole wave lies beyond the list
+            inRange = index < lists.total;
+            drained = false;
+            const uint32_t at = lists.position(inRange ? index : 0u, pool.connectRegion);
+            slot = inRange ? (pool.busyIn[at] & ~kBusyAliveBit) : 0u;
+        }
+        shadeSlot<COUNT, SSS, kShadeListed>(rp, sc, pool, slot, inRange, drained, index >> 6, counts);
+    } else {
+        shadeSlot<COUNT, SSS, kShadeDense>(rp, sc, pool, index, index < pool.slots, resets.drained != 0u, index >> 6, counts);
+    }
     if (COUNT) {
         addCounter(pool.counters, kCntShadedHits, counts.shadedHit);
         addCounter(pool.counters, kCntTriangleHits, counts.triHit);
@@ -1574,21 +1666,10 @@ __global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_e
     // cross-lane reads.  Measured before: 3.5 slots probed per ray found on config 2 (a third of the slots queue a record), more as
     // the frame drains, and the probing passes were a third of the kernel's instructions.
     const bool listed = pool.connectList != nullptr;
-    uint32_t listBefore = 0u;   // lane l: entries in sub-lists 0..l-1
-    uint32_t listTotal = pool.slots;
-    if (listed) {
-        const uint32_t mine = min(pool.connectCount[laneId() * kConnectCountStride], pool.connectRegion);
-        uint32_t incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t up = __shfl_up(incl, off, 64);
-            if (static_cast<int>(laneId()) >= off) incl += up;
-        }
-        listBefore = incl - mine;
-        listTotal = __builtin_amdgcn_readlane(incl, 63);
-    }
+    SubLists lists{0u, pool.slots};
+    if (listed) lists.init(pool.connectCount, pool.connectRegion);
     WaveFeeder feeder;
-    feeder.init(workCounter, listTotal, listed ? 256u : feederChunk);
+    feeder.init(workCounter, lists.total, listed ? 256u : feederChunk);
     Trav t;
     t.cur = 0u;
     bool active = false;
@@ -1606,17 +1687,9 @@ __global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_e
             if (!feeder.exhausted) {
                 const uint32_t idx = feeder.take(!active && bits == 0u);
                 if (listed) {
-                    // largest sub-list whose first index is <= idx (empty sub-lists share their successor's start and lose)
-                    const uint32_t want = idx != WaveFeeder::kNone ? idx : 0u;
-                    uint32_t queue = 0u;
-#pragma unroll
-                    for (uint32_t step = kConnectQueues / 2u; step != 0u; step >>= 1) {
-                        const uint32_t before = __shfl(listBefore, static_cast<int>(queue + step), 64);
-                        if (before <= want) queue += step;
-                    }
-                    const uint32_t before = __shfl(listBefore, static_cast<int>(queue), 64);
+                    const uint32_t at = lists.position(idx != WaveFeeder::kNone ? idx : 0u, pool.connectRegion);
                     if (idx != WaveFeeder::kNone) {
-                        const uint32_t entry = pool.connectList[queue * pool.connectRegion + (want - before)];
+                        const uint32_t entry = pool.connectList[at];
                         mySlot = entry & ((1u << kConnectMaskShift) - 1u);
                         bits = entry >> kConnectMaskShift;
                     }
@@ -1893,7 +1966,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_tail_run(RenderParams rp, Scene
                     __threadfence();
                 }
                 // k_shade's part
-                shadeSlot<COUNT, SSS, true>(rp, sc, pool, slot, true, false, counts);
+                shadeSlot<COUNT, SSS, kShadeTail>(rp, sc, pool, slot, true, false, 0u, counts);
                 __threadfence();
                 // k_connect's part: the records this visit queued
                 uint32_t bits = pool.pending[slot] & kFlagPendingMask;
@@ -2198,10 +2271,13 @@ void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& po
     const uint32_t grid = ceilDiv(pool.slots, kShadeBlock);
     const bool sss = (rp.mediaMode & (PTR_METAL_SSS | PTR_METAL_PBR | PTR_METAL_CLAMPS)) != 0u;   // the instantiation that carries those Metal-only models
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, resets); };
+    const bool listed = pool.busyIn != nullptr;   // the grid still covers every slot: waves beyond the list leave at once
     if (count) {
-        if (sss) launch(k_shade<true, true>); else launch(k_shade<true, false>);
+        if (listed) { if (sss) launch(k_shade<true, true, true>); else launch(k_shade<true, false, true>); }
+        else if (sss) launch(k_shade<true, true, false>); else launch(k_shade<true, false, false>);
     } else {
-        if (sss) launch(k_shade<false, true>); else launch(k_shade<false, false>);
+        if (listed) { if (sss) launch(k_shade<false, true, true>); else launch(k_shade<false, false, true>); }
+        else if (sss) launch(k_shade<false, true, false>); else launch(k_shade<false, false, false>);
     }
 }
 
