@@ -151,6 +151,12 @@ def main():
 
     if rank == 0:
         ensure_assets()
+        # the large generated meshes a non-default scene names (file names ending in _<triangles>.ply; too big for the repository)
+        import re
+        from scenes.gen_assets import ensure_large_asset
+        with open(args.scene) as f:
+            for asset in re.findall(r"assets/(\w+_\d{6,}\.ply)", f.read()):
+                ensure_large_asset(asset)
     if world > 1:
         dist.barrier()
 

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <numeric>
 #include <thread>
 
@@ -18,7 +19,6 @@ namespace {
 
 constexpr int kBins = 16;
 constexpr uint32_t kDepthLimit = ptrk::kTraversalStackDepth - 2;   // leaves sit at depth <= kDepthLimit
-constexpr uint32_t kParallelThreshold = 1u << 16;
 
 struct Aabb {
     float lo[3], hi[3];
@@ -41,28 +41,58 @@ struct Aabb {
     }
 };
 
-struct TempNode {
+// Arrays of tens of millions of plain records: allocated WITHOUT being filled (a std::vector would write every element once on
+// the calling thread - seconds for a 29 M-triangle scene - and place all its pages next to that one core); whoever writes an
+// element first touches its page.
+template <typename T>
+struct RawArray {
+    std::unique_ptr<T[]> items;
+    void allocate(size_t n) { items.reset(new T[n]); }
+    void release() { items.reset(); }
+    T& operator[](size_t i) { return items[i]; }
+    const T& operator[](size_t i) const { return items[i]; }
+    T* data() { return items.get(); }
+};
+
+struct TempNode {   // no initialisers: see RawArray.  A leaf sets count (> 0) and the totals, an internal node everything but `first`.
     Aabb box;
-    uint32_t left = 0, right = 0;   // children (internal)
-    uint32_t first = 0, count = 0;  // range in `order` (leaf when count > 0)
-    uint32_t sphereLeaf = 0;
+    uint32_t left, right;   // children (internal)
+    uint32_t first, count;  // range in `order` (leaf when count > 0)
+    uint32_t sphereLeaf;
     // subtree totals, filled on the way back up: what the flattener needs to give every subtree its own slice of the node /
     // triangle / sphere arrays, so that subtrees can be laid out in parallel
-    uint32_t internalNodes = 0, triPrims = 0, spherePrims = 0;
+    uint32_t internalNodes, triPrims, spherePrims;
+};
+
+// The builder's working copy of a primitive: bounds + input index in one 32 B record.  The records of a node are one contiguous
+// run that is partitioned in place, so every pass over a node streams through memory; with an index array into the caller's
+// primitives every access below the top of a large tree was a cache miss (5.7 of the 7.5 s a 29 M-triangle build took).
+struct Rec {
+    float lo[3];
+    uint32_t id;
+    float hi[3];
+    uint32_t isSphere;
+    float centre(int axis) const { return 0.5f * (lo[axis] + hi[axis]); }
 };
 
 struct Builder {
-    const std::vector<BuildPrim>& prims;
-    std::vector<float> centers;       // 3 per prim
-    std::vector<uint32_t> order;
-    std::vector<TempNode> nodes;
+    RawArray<Rec> recs;
+    std::vector<uint32_t> order;      // recs[i].id once the tree stands (what the flattener reads)
+    RawArray<TempNode> nodes;
     std::atomic<uint32_t> nextNode{1};
-    std::atomic<int> freeThreads{0};
     uint32_t kLeafMax = 4;   // SAH may stop at <= kLeafMax primitives
 
-    explicit Builder(const std::vector<BuildPrim>& p) : prims(p) {}
-
-    uint32_t allocPair() { return nextNode.fetch_add(2); }
+    // Two nodes for the children of a split.  The subtrees of the task list take them from a block of their own (`cursor`): with one
+    // shared counter, neighbouring pairs belong to different threads and every write to a node drags its cache line across the
+    // machine (64 threads: 1 us per primitive and level instead of 70 ns).
+    uint32_t allocPair(uint32_t* cursor) {
+        if (cursor) {
+            const uint32_t at = *cursor;
+            *cursor += 2;
+            return at;
+        }
+        return nextNode.fetch_add(2);
+    }
 
     static uint32_t log2Ceil(uint32_t n) {
         uint32_t l = 0;
@@ -73,17 +103,15 @@ struct Builder {
     void makeLeaf(uint32_t node, uint32_t begin, uint32_t end) {
         nodes[node].first = begin;
         nodes[node].count = end - begin;
-        nodes[node].sphereLeaf = prims[order[begin]].isSphere;
+        nodes[node].sphereLeaf = recs[begin].isSphere;
         nodes[node].internalNodes = 0;
         nodes[node].triPrims = nodes[node].sphereLeaf ? 0u : end - begin;
         nodes[node].spherePrims = nodes[node].sphereLeaf ? end - begin : 0u;
     }
 
-    // Nodes above this size split their own loops over the host threads: the top five levels of a 29 M-triangle tree touch every
-    // primitive once per level, and before the subtrees fan out over the threads that was most of the build (6.9 s of it serial).
-    static constexpr uint32_t kWideNode = 1u << 20;
+    // passes over large nodes are cut into one chunk per 64 Ki primitives, at most wideThreads of them
     uint32_t wideThreads = 1;
-    std::vector<uint32_t> scratch;   // parallel partition of wide nodes
+    RawArray<Rec> scratch;   // parallel partition of wide nodes
 
     template <typename Fn>
     void forChunks(uint32_t begin, uint32_t end, Fn&& fn) const {   // fn(chunkIndex, chunkBegin, chunkEnd)
@@ -98,111 +126,137 @@ struct Builder {
         for (auto& th : pool) th.join();
     }
 
-    void build(uint32_t node, uint32_t begin, uint32_t end, uint32_t depth) {
+    // What a node knows about its range before it looks at a single primitive: the parent computed it while partitioning.
+    struct NodeInfo {
         Aabb box, cbox;
-        box.reset();
-        cbox.reset();
-        uint32_t sphereCount = 0;
-        const bool wide = (end - begin) >= kWideNode && wideThreads > 1;
-        if (wide) {
-            struct Part {
-                Aabb box, cbox;
-                uint32_t spheres;
-            };
-            std::vector<Part> parts(wideThreads);
-            for (Part& p : parts) {
-                p.box.reset();
-                p.cbox.reset();
-                p.spheres = 0;
+        uint32_t spheres = 0;
+        void reset() {
+            box.reset();
+            cbox.reset();
+            spheres = 0;
+        }
+        void add(const Rec& p) {
+            box.grow(p.lo, p.hi);
+            const float c[3] = {p.centre(0), p.centre(1), p.centre(2)};
+            cbox.growPoint(c);
+            spheres += p.isSphere;
+        }
+        void merge(const NodeInfo& o) {
+            if (o.box.lo[0] <= o.box.hi[0]) {
+                box.grow(o.box.lo, o.box.hi);
+                cbox.grow(o.cbox.lo, o.cbox.hi);
             }
+            spheres += o.spheres;
+        }
+    };
+
+    // bounds of a range by one pass over it (the root, and the rare splits that do not come out of the SAH partition)
+    NodeInfo measure(uint32_t begin, uint32_t end) {
+        NodeInfo info;
+        info.reset();
+        if ((end - begin) >= kTaskNode && wideThreads > 1) {
+            std::vector<NodeInfo> parts(wideThreads);
+            for (NodeInfo& p : parts) p.reset();
             forChunks(begin, end, [&](uint32_t k, uint32_t b, uint32_t e) {
-                Part& part = parts[k];
-                for (uint32_t i = b; i < e; ++i) {
-                    const BuildPrim& p = prims[order[i]];
-                    part.box.grow(p.lo, p.hi);
-                    part.cbox.growPoint(&centers[static_cast<size_t>(order[i]) * 3]);
-                    part.spheres += p.isSphere;
-                }
+                NodeInfo part;   // on the thread's own stack: neighbours in `parts` share cache lines
+                part.reset();
+                for (uint32_t i = b; i < e; ++i) part.add(recs[i]);
+                parts[k] = part;
             });
-            for (const Part& p : parts) {
-                if (p.box.lo[0] <= p.box.hi[0]) {
-                    box.grow(p.box.lo, p.box.hi);
-                    cbox.grow(p.cbox.lo, p.cbox.hi);
-                }
-                sphereCount += p.spheres;
-            }
+            for (const NodeInfo& p : parts) info.merge(p);
         } else {
-            for (uint32_t i = begin; i < end; ++i) {
-                const BuildPrim& p = prims[order[i]];
-                box.grow(p.lo, p.hi);
-                cbox.growPoint(&centers[static_cast<size_t>(order[i]) * 3]);
-                sphereCount += p.isSphere;
+            for (uint32_t i = begin; i < end; ++i) info.add(recs[i]);
+        }
+        return info;
+    }
+
+    struct Bins {
+        Aabb box[3][kBins];
+        uint32_t count[3][kBins];
+        void reset() {
+            for (int a = 0; a < 3; ++a) {
+                for (int b = 0; b < kBins; ++b) {
+                    box[a][b].reset();
+                    count[a][b] = 0;
+                }
             }
         }
+    };
+
+    // A node costs two passes over its primitives: one fills the bins of all three axes, one partitions the range and measures both
+    // halves on the way (the first version took five: bounds, one binning pass per axis, partition - 7.7 of the 11.6 s a
+    // 29 M-triangle scene took to prepare).
+    // Decides one node: a leaf (returns false), or the place `mid` where its range is cut, with the range partitioned and both
+    // halves measured.  `wide`: the passes are split over the host threads.
+    bool split(uint32_t node, uint32_t begin, uint32_t end, uint32_t depth, const NodeInfo& info, bool wide, uint32_t* cursor, uint32_t& mid,
+               NodeInfo& leftInfo, NodeInfo& rightInfo) {
+        const Aabb& box = info.box;
+        const Aabb& cbox = info.cbox;
+        const uint32_t sphereCount = info.spheres;
         nodes[node].box = box;
         const uint32_t count = end - begin;
         const bool mixed = sphereCount != 0 && sphereCount != count;
 
-        uint32_t mid = begin;
+        mid = begin;
         bool haveSplit = false;
         const bool forceBalanced = depth + log2Ceil(count) + 1 >= kDepthLimit;
 
         if (count == 1 || (count <= kLeafMax && !mixed && forceBalanced)) {
             makeLeaf(node, begin, end);
-            return;
+            return false;
         }
 
         if (!forceBalanced) {
-            // binned SAH over the three axes
-            int bestAxis = -1, bestBin = -1;
-            float bestCost = std::numeric_limits<float>::infinity();
+            // binned SAH over the three axes, all bins in one pass
+            float lo[3], scale[3];
+            bool usable[3];
             for (int axis = 0; axis < 3; ++axis) {
-                const float lo = cbox.lo[axis], hi = cbox.hi[axis];
-                if (!(hi > lo)) continue;
-                Aabb binBox[kBins];
-                uint32_t binCount[kBins];
-                for (int b = 0; b < kBins; ++b) {
-                    binBox[b].reset();
-                    binCount[b] = 0;
-                }
-                const float scale = static_cast<float>(kBins) / (hi - lo);
-                if (wide) {
-                    struct Bins {
-                        Aabb box[kBins];
-                        uint32_t count[kBins];
-                    };
-                    std::vector<Bins> parts(wideThreads);
-                    for (Bins& p : parts) {
-                        for (int b = 0; b < kBins; ++b) {
-                            p.box[b].reset();
-                            p.count[b] = 0;
-                        }
+                lo[axis] = cbox.lo[axis];
+                usable[axis] = cbox.hi[axis] > cbox.lo[axis];
+                scale[axis] = usable[axis] ? static_cast<float>(kBins) / (cbox.hi[axis] - cbox.lo[axis]) : 0.0f;
+            }
+            auto fill = [&](Bins& bins, uint32_t b, uint32_t e) {
+                for (uint32_t i = b; i < e; ++i) {
+                    const Rec& p = recs[i];
+                    for (int axis = 0; axis < 3; ++axis) {
+                        if (!usable[axis]) continue;
+                        const int bin = std::min(kBins - 1, static_cast<int>((p.centre(axis) - lo[axis]) * scale[axis]));
+                        bins.box[axis][bin].grow(p.lo, p.hi);
+                        ++bins.count[axis][bin];
                     }
-                    forChunks(begin, end, [&](uint32_t k, uint32_t cb, uint32_t ce) {
-                        Bins& part = parts[k];
-                        for (uint32_t i = cb; i < ce; ++i) {
-                            const uint32_t id = order[i];
-                            const int b = std::min(kBins - 1, static_cast<int>((centers[static_cast<size_t>(id) * 3 + axis] - lo) * scale));
-                            part.box[b].grow(prims[id].lo, prims[id].hi);
-                            ++part.count[b];
-                        }
-                    });
-                    for (const Bins& p : parts) {
+                }
+            };
+            Bins bins;
+            bins.reset();
+            std::vector<Bins> parts;   // wide nodes: the bins of every chunk (kept: the partition reads its counts from them)
+            if (wide) {
+                parts.resize(wideThreads);
+                for (Bins& p : parts) p.reset();   // chunks that do not exist stay empty
+                forChunks(begin, end, [&](uint32_t k, uint32_t cb, uint32_t ce) {
+                    Bins mine;
+                    mine.reset();
+                    fill(mine, cb, ce);
+                    parts[k] = mine;
+                });
+                for (const Bins& p : parts) {
+                    for (int axis = 0; axis < 3; ++axis) {
                         for (int b = 0; b < kBins; ++b) {
-                            if (p.count[b]) {
-                                binBox[b].grow(p.box[b].lo, p.box[b].hi);
-                                binCount[b] += p.count[b];
+                            if (p.count[axis][b]) {
+                                bins.box[axis][b].grow(p.box[axis][b].lo, p.box[axis][b].hi);
+                                bins.count[axis][b] += p.count[axis][b];
                             }
                         }
                     }
-                } else {
-                    for (uint32_t i = begin; i < end; ++i) {
-                        const uint32_t id = order[i];
-                        const int b = std::min(kBins - 1, static_cast<int>((centers[static_cast<size_t>(id) * 3 + axis] - lo) * scale));
-                        binBox[b].grow(prims[id].lo, prims[id].hi);
-                        ++binCount[b];
-                    }
                 }
+            } else {
+                fill(bins, begin, end);
+            }
+            int bestAxis = -1, bestBin = -1;
+            float bestCost = std::numeric_limits<float>::infinity();
+            for (int axis = 0; axis < 3; ++axis) {
+                if (!usable[axis]) continue;
+                const Aabb* binBox = bins.box[axis];
+                const uint32_t* binCount = bins.count[axis];
                 float rightArea[kBins];
                 uint32_t rightCount[kBins];
                 Aabb acc;
@@ -233,23 +287,26 @@ struct Builder {
                 const float splitCost = 1.0f + bestCost / parentArea;   // c_trav = c_int = 1 (tinybvh defaults)
                 if (count <= kLeafMax && !mixed && splitCost >= static_cast<float>(count)) {
                     makeLeaf(node, begin, end);
-                    return;
+                    return false;
                 }
-                const float lo = cbox.lo[bestAxis];
-                const float scale = static_cast<float>(kBins) / (cbox.hi[bestAxis] - lo);
-                auto goesLeft = [&](uint32_t id) {
-                    return std::min(kBins - 1, static_cast<int>((centers[static_cast<size_t>(id) * 3 + bestAxis] - lo) * scale)) <= bestBin;
+                const float splitLo = cbox.lo[bestAxis];
+                const float splitScale = static_cast<float>(kBins) / (cbox.hi[bestAxis] - splitLo);
+                auto goesLeft = [&](const Rec& p) {
+                    return std::min(kBins - 1, static_cast<int>((p.centre(bestAxis) - splitLo) * splitScale)) <= bestBin;
                 };
+                leftInfo.reset();
+                rightInfo.reset();
                 if (wide) {
                     // chunk-wise counts, prefix sums, stable scatter through the scratch array (which side a primitive lands on is all
-                    // that matters: the subtrees re-partition their ranges anyway)
+                    // that matters: the subtrees re-partition their ranges anyway); the scatter measures both halves
+                    // how many of a chunk go left is already in that chunk's bins (same chunks as the binning pass)
                     std::vector<uint32_t> lefts(wideThreads + 1u, 0u), sizes(wideThreads + 1u, 0u);
-                    forChunks(begin, end, [&](uint32_t k, uint32_t cb, uint32_t ce) {
-                        uint32_t n = 0;
-                        for (uint32_t i = cb; i < ce; ++i) n += goesLeft(order[i]) ? 1u : 0u;
-                        lefts[k + 1u] = n;
-                        sizes[k + 1u] = ce - cb;
-                    });
+                    for (uint32_t k = 0; k < wideThreads; ++k) {
+                        for (int b = 0; b < kBins; ++b) {
+                            sizes[k + 1u] += parts[k].count[bestAxis][b];
+                            if (b <= bestBin) lefts[k + 1u] += parts[k].count[bestAxis][b];
+                        }
+                    }
                     uint32_t totalLeft = 0;
                     for (uint32_t k = 1; k <= wideThreads; ++k) totalLeft += lefts[k];
                     std::vector<uint32_t> leftAt(wideThreads + 1u, 0u), rightAt(wideThreads + 1u, 0u);
@@ -257,18 +314,77 @@ struct Builder {
                         leftAt[k + 1u] = leftAt[k] + lefts[k + 1u];
                         rightAt[k + 1u] = rightAt[k] + (sizes[k + 1u] - lefts[k + 1u]);
                     }
+                    std::vector<NodeInfo> leftParts(wideThreads), rightParts(wideThreads);
+                    for (uint32_t k = 0; k < wideThreads; ++k) {
+                        leftParts[k].reset();
+                        rightParts[k].reset();
+                    }
                     forChunks(begin, end, [&](uint32_t k, uint32_t cb, uint32_t ce) {
                         uint32_t l = begin + leftAt[k], r = begin + totalLeft + rightAt[k];
+                        NodeInfo li, ri;
+                        li.reset();
+                        ri.reset();
                         for (uint32_t i = cb; i < ce; ++i) {
-                            const uint32_t id = order[i];
-                            if (goesLeft(id)) scratch[l++] = id; else scratch[r++] = id;
+                            const Rec& p = recs[i];
+                            if (goesLeft(p)) {
+                                scratch[l++] = p;
+                                li.add(p);
+                            } else {
+                                scratch[r++] = p;
+                                ri.add(p);
+                            }
                         }
+                        leftParts[k] = li;
+                        rightParts[k] = ri;
                     });
-                    forChunks(begin, end, [&](uint32_t, uint32_t cb, uint32_t ce) { std::memcpy(&order[cb], &scratch[cb], static_cast<size_t>(ce - cb) * 4u); });
+                    forChunks(begin, end, [&](uint32_t, uint32_t cb, uint32_t ce) { std::memcpy(&recs[cb], &scratch[cb], static_cast<size_t>(ce - cb) * sizeof(Rec)); });
+                    for (uint32_t k = 0; k < wideThreads; ++k) {
+                        leftInfo.merge(leftParts[k]);
+                        rightInfo.merge(rightParts[k]);
+                    }
                     mid = begin + totalLeft;
                 } else {
-                    auto it = std::partition(order.begin() + begin, order.begin() + end, goesLeft);
-                    mid = static_cast<uint32_t>(it - order.begin());
+                    // std::partition's two-ended walk (so the order inside the halves, and with it the order of the primitives in the
+                    // leaves, is what it always was), measuring both halves as the elements settle
+                    auto settleLeft = [&](const Rec& p) { leftInfo.add(p); };
+                    auto settleRight = [&](const Rec& p) { rightInfo.add(p); };
+                    uint32_t first = begin, last = end;
+                    while (true) {
+                        bool finished = false;
+                        while (true) {
+                            if (first == last) {
+                                finished = true;
+                                break;
+                            }
+                            if (goesLeft(recs[first])) {
+                                settleLeft(recs[first]);
+                                ++first;
+                            } else {
+                                break;
+                            }
+                        }
+                        if (finished) break;
+                        --last;   // order[first] goes right and has not been counted yet
+                        while (true) {
+                            if (first == last) {
+                                settleRight(recs[first]);
+                                finished = true;
+                                break;
+                            }
+                            if (!goesLeft(recs[last])) {
+                                settleRight(recs[last]);
+                                --last;
+                            } else {
+                                break;
+                            }
+                        }
+                        if (finished) break;
+                        std::swap(recs[first], recs[last]);
+                        settleLeft(recs[first]);
+                        settleRight(recs[last]);
+                        ++first;
+                    }
+                    mid = first;
                 }
                 haveSplit = mid != begin && mid != end;
             }
@@ -276,11 +392,11 @@ struct Builder {
         if (!haveSplit) {
             if (mixed) {
                 // never mix spheres and triangles in one leaf: separate the kinds first
-                auto it = std::partition(order.begin() + begin, order.begin() + end, [&](uint32_t id) { return prims[id].isSphere == 0; });
-                mid = static_cast<uint32_t>(it - order.begin());
+                Rec* const it = std::partition(recs.data() + begin, recs.data() + end, [&](const Rec& p) { return p.isSphere == 0; });
+                mid = static_cast<uint32_t>(it - recs.data());
             } else if (count <= kLeafMax && !forceBalanced) {
                 makeLeaf(node, begin, end);
-                return;
+                return false;
             } else {
                 // object median along the widest centroid axis (also the depth-bounding fallback)
                 int axis = 0;
@@ -293,32 +409,95 @@ struct Builder {
                     }
                 }
                 mid = begin + count / 2;
-                std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end, [&](uint32_t a, uint32_t b) {
-                    const float ca = centers[static_cast<size_t>(a) * 3 + axis], cb = centers[static_cast<size_t>(b) * 3 + axis];
-                    return ca < cb || (ca == cb && a < b);
+                std::nth_element(recs.data() + begin, recs.data() + mid, recs.data() + end, [&](const Rec& a, const Rec& b) {
+                    const float ca = a.centre(axis), cb = b.centre(axis);
+                    return ca < cb || (ca == cb && a.id < b.id);
                 });
             }
+            leftInfo = measure(begin, mid);
+            rightInfo = measure(mid, end);
         }
-
-        const uint32_t left = allocPair();
+        const uint32_t left = allocPair(cursor);
         nodes[node].left = left;
         nodes[node].right = left + 1;
         nodes[node].count = 0;
-        if (count >= kParallelThreshold && freeThreads.fetch_sub(1) > 0) {
-            std::thread t([this, left, begin, mid, depth]() { build(left, begin, mid, depth + 1); });
-            build(left + 1, mid, end, depth + 1);
-            t.join();
-            freeThreads.fetch_add(1);
-        } else {
-            if (count >= kParallelThreshold) freeThreads.fetch_add(1);
-            build(left, begin, mid, depth + 1);
-            build(left + 1, mid, end, depth + 1);
-        }
+        return true;
+    }
+
+    void sumChildren(uint32_t node) {
+        const uint32_t left = nodes[node].left;
         nodes[node].internalNodes = 1u + nodes[left].internalNodes + nodes[left + 1].internalNodes;
         nodes[node].triPrims = nodes[left].triPrims + nodes[left + 1].triPrims;
         nodes[node].spherePrims = nodes[left].spherePrims + nodes[left + 1].spherePrims;
     }
+
+    // one subtree, on the calling thread
+    void build(uint32_t node, uint32_t begin, uint32_t end, uint32_t depth, const NodeInfo& info, uint32_t* cursor) {
+        uint32_t mid;
+        NodeInfo leftInfo, rightInfo;
+        if (!split(node, begin, end, depth, info, false, cursor, mid, leftInfo, rightInfo)) return;
+        build(nodes[node].left, begin, mid, depth + 1, leftInfo, cursor);
+        build(nodes[node].right, mid, end, depth + 1, rightInfo, cursor);
+        sumChildren(node);
+    }
+
+    // The whole tree.  Nodes of kTaskNode primitives and more are split one after the other with every pass spread over the threads
+    // (the top eight levels of a 29 M-triangle tree touch every primitive once per level); the subtrees below them - a few hundred -
+    // are a task list that a pool of threads works through, largest first.  (The first scheme gave each large split a thread while
+    // any were free: a third of 32 threads busy on average.)
+    static constexpr uint32_t kTaskNode = 1u << 17;
+    struct Task {
+        uint32_t node, begin, end, depth;
+        NodeInfo info;
+        uint32_t firstNode = 0;
+    };
+    void buildTop(uint32_t node, uint32_t begin, uint32_t end, uint32_t depth, const NodeInfo& info, std::vector<Task>& tasks,
+                  std::vector<uint32_t>& topNodes) {
+        if (end - begin < kTaskNode || wideThreads <= 1) {
+            tasks.push_back({node, begin, end, depth, info, 0u});
+            return;
+        }
+        uint32_t mid;
+        NodeInfo leftInfo, rightInfo;
+        if (!split(node, begin, end, depth, info, true, nullptr, mid, leftInfo, rightInfo)) return;
+        buildTop(nodes[node].left, begin, mid, depth + 1, leftInfo, tasks, topNodes);
+        buildTop(nodes[node].right, mid, end, depth + 1, rightInfo, tasks, topNodes);
+        topNodes.push_back(node);   // children first
+    }
+    void buildAll(uint32_t count) {
+        std::vector<Task> tasks;
+        std::vector<uint32_t> topNodes;
+        const auto t0 = std::chrono::steady_clock::now();
+        buildTop(0, 0, count, 0, measure(0, count), tasks, topNodes);
+        if (std::getenv("PTR_BUILD_VERBOSE")) {
+            std::fprintf(stderr, "[bvh] top of the tree: %zu nodes, %zu subtrees left, %.2f s\n", topNodes.size(), tasks.size(),
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
+        std::sort(tasks.begin(), tasks.end(), [](const Task& a, const Task& b) { return (a.end - a.begin) > (b.end - b.begin); });
+        uint32_t firstFree = nextNode.load();
+        for (Task& t : tasks) {
+            t.firstNode = firstFree;
+            firstFree += 2u * (t.end - t.begin);
+        }
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            while (true) {
+                const size_t t = next.fetch_add(1);
+                if (t >= tasks.size()) break;
+                uint32_t cursor = tasks[t].firstNode;   // a subtree over n primitives has fewer than 2 n nodes
+                build(tasks[t].node, tasks[t].begin, tasks[t].end, tasks[t].depth, tasks[t].info, &cursor);
+            }
+        };
+        const uint32_t workers = static_cast<uint32_t>(std::min<size_t>(std::max(poolThreads, 1u), tasks.size()));
+        std::vector<std::thread> pool;
+        for (uint32_t w = 1; w < workers; ++w) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
+        for (uint32_t node : topNodes) sumChildren(node);
+    }
+    uint32_t poolThreads = 1;
 };
+
 
 struct Flattener {
     const Builder& b;
@@ -526,22 +705,38 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
         }
     }
 
-    Builder b(prims);
+    Builder b;
     b.kLeafMax = std::min(std::max(leafMax, 1u), ptrk::kMaxLeafPrims);
-    b.centers.resize(static_cast<size_t>(n) * 3);
-    for (uint32_t i = 0; i < n; ++i) {
-        for (int a = 0; a < 3; ++a) b.centers[static_cast<size_t>(i) * 3 + a] = 0.5f * (prims[i].lo[a] + prims[i].hi[a]);
-    }
-    b.order.reserve(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        if (!oversize[i]) b.order.push_back(i);
-    }
-    const uint32_t inTree = static_cast<uint32_t>(b.order.size());
-    b.nodes.resize(static_cast<size_t>(2) * inTree + 1);
     if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
-    b.freeThreads = static_cast<int>(std::min(threads, 32u)) - 1;
-    b.wideThreads = std::min(threads, 32u);
-    if (inTree >= Builder::kWideNode) b.scratch.resize(n);
+    b.wideThreads = std::min(threads, 64u);
+    b.poolThreads = std::min(threads, 64u);
+    const uint32_t inTree = n - oversizeCount;
+    b.recs.allocate(inTree);
+    {
+        // in input order, the oversize ones left out: chunk k starts at its first index minus the oversize primitives before it
+        std::vector<uint32_t> skipped(b.wideThreads + 1u, 0u);
+        b.forChunks(0, n, [&](uint32_t k, uint32_t cb, uint32_t ce) {
+            uint32_t s = 0;
+            for (uint32_t i = cb; i < ce; ++i) s += oversize[i];
+            skipped[k + 1u] = s;
+        });
+        for (uint32_t k = 0; k < b.wideThreads; ++k) skipped[k + 1u] += skipped[k];
+        b.forChunks(0, n, [&](uint32_t k, uint32_t cb, uint32_t ce) {
+            uint32_t at = cb - skipped[k];
+            for (uint32_t i = cb; i < ce; ++i) {
+                if (oversize[i]) continue;
+                Rec& r = b.recs[at++];
+                for (int a = 0; a < 3; ++a) {
+                    r.lo[a] = prims[i].lo[a];
+                    r.hi[a] = prims[i].hi[a];
+                }
+                r.id = i;
+                r.isSphere = prims[i].isSphere;
+            }
+        });
+    }
+    b.nodes.allocate(static_cast<size_t>(2) * inTree + 2u * (inTree >> 16) + 64u);   // 2 n - 1 nodes, and the slack of the per-subtree blocks
+    if (inTree >= Builder::kTaskNode && b.wideThreads > 1) b.scratch.allocate(inTree);
     const bool verbose = std::getenv("PTR_BUILD_VERBOSE") != nullptr;
     auto tick = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -550,7 +745,13 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
         tick = now;
     };
     lap("setup");
-    b.build(0, 0, inTree, 0);
+    b.buildAll(inTree);
+    b.scratch.release();
+    b.order.resize(inTree);
+    b.forChunks(0, inTree, [&](uint32_t, uint32_t cb, uint32_t ce) {
+        for (uint32_t i = cb; i < ce; ++i) b.order[i] = b.recs[i].id;
+    });
+    b.recs.release();
     lap("sah build");
 
     Flattener f{b, out, {}, {}};

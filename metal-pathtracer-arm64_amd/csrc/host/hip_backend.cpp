@@ -338,8 +338,19 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     ds.hasRandomWalkMaterial = ps.hasRandomWalkMaterial;
 
     HIP_CHECK(hipSetDevice(ds.device));
-    ds.nodes.upload(reinterpret_cast<const float4*>(bvh.nodes.data()), bvh.nodes.size() / 4);
-    ds.qnodes.upload(reinterpret_cast<const uint4*>(bvh.qnodes.data()), bvh.qnodes.size() / 4);
+    // 32 B quantised nodes halve the node fetches; use them unless the 16-bit grid is coarse next to the
+    // primitives (cell > 1/8 of the mean primitive extent would inflate leaf boxes noticeably).  Only the node array the
+    // kernels will read goes to the device (a 29 M-triangle scene: 0.5 GB instead of 1.5 GB of nodes).
+    const float maxCell = std::max(std::max(bvh.gridCell[0], bvh.gridCell[1]), bvh.gridCell[2]);
+    bool useQuantized = bvh.nodeCount > 0 && maxCell * 8.0f <= bvh.meanPrimExtent;
+    if (const char* e = std::getenv("PTR_QUANTIZED_NODES")) useQuantized = std::atoi(e) != 0;
+    if (useQuantized) {
+        ds.nodes.release();
+        ds.qnodes.upload(reinterpret_cast<const uint4*>(bvh.qnodes.data()), bvh.qnodes.size() / 4);
+    } else {
+        ds.qnodes.release();
+        ds.nodes.upload(reinterpret_cast<const float4*>(bvh.nodes.data()), bvh.nodes.size() / 4);
+    }
     ds.tris.upload(reinterpret_cast<const float4*>(geo.triData.data()), geo.triData.size() / 4);
     ds.triNormals.upload(reinterpret_cast<const float4*>(geo.triNormals.data()), geo.triNormals.size() / 4);
     ds.spheres.upload(reinterpret_cast<const float4*>(geo.sphereData.data()), geo.sphereData.size() / 4);
@@ -364,11 +375,7 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     std::memcpy(v.gridOrigin, bvh.gridOrigin, sizeof(v.gridOrigin));
     std::memcpy(v.gridCell, bvh.gridCell, sizeof(v.gridCell));
     for (int a = 0; a < 3; ++a) v.gridInvCell[a] = 1.0f / bvh.gridCell[a];
-    // 32 B quantised nodes halve the node fetches; use them unless the 16-bit grid is coarse next to the
-    // primitives (cell > 1/8 of the mean primitive extent would inflate leaf boxes noticeably)
-    const float maxCell = std::max(std::max(bvh.gridCell[0], bvh.gridCell[1]), bvh.gridCell[2]);
-    v.useQuantized = (bvh.nodeCount > 0 && maxCell * 8.0f <= bvh.meanPrimExtent) ? 1u : 0u;
-    if (const char* e = std::getenv("PTR_QUANTIZED_NODES")) v.useQuantized = std::atoi(e) != 0 ? 1u : 0u;
+    v.useQuantized = useQuantized ? 1u : 0u;
     const size_t nodeBytes = v.useQuantized ? bvh.qnodes.size() * 4u : bvh.nodes.size() * 4u;
     const size_t triBytes = geo.triData.size() * 4u;
     if (nodeBytes > 0xFFFFFFFFull || triBytes > 0xFFFFFFFFull) throw HipError{"scene exceeds the 4 GiB node/triangle array limit"};
@@ -469,7 +476,9 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     ds.zeros.ensure(16);
     HIP_CHECK(hipMemset(ds.zeros.ptr, 0, 16 * sizeof(uint32_t)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ds.pinnedAlive), sizeof(uint32_t) * (kPinnedHeadsOffset + kItemHeads), hipHostMallocDefault));
-    ds.uploadSeconds = ps.seconds + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const double copySeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ds.uploadSeconds = ps.seconds + copySeconds;
+    if (std::getenv("PTR_BUILD_VERBOSE")) std::fprintf(stderr, "[upload] prepare %.2f s, copies to the device %.2f s\n", ps.seconds, copySeconds);
 }
 
 void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {

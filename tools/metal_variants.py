@@ -18,9 +18,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 VARIANTS = {
-    "3_metal_pbr": dict(scene="helmet_env.scene", assets=[], semantics=63, gpu_spp=256, parity_spp=64, strip=128),
-    "4_absorbing_glass": dict(scene="knot_glass_absorbing.scene", assets=["torus_knot_871200.ply"], semantics=63, gpu_spp=256, parity_spp=64, strip=128),
-    "5_separable_sss": dict(scene="lucy_standin_sss.scene", assets=["lucy_standin_28005128.ply", "blob_1002528.ply"], semantics=63, gpu_spp=32,
+    "3_metal_pbr": dict(scene="helmet_env.scene", assets=[], semantics=127, gpu_spp=256, parity_spp=64, strip=128),
+    "4_absorbing_glass": dict(scene="knot_glass_absorbing.scene", assets=["torus_knot_871200.ply"], semantics=127, gpu_spp=256, parity_spp=64, strip=128),
+    "5_separable_sss": dict(scene="lucy_standin_sss.scene", assets=["lucy_standin_28005128.ply", "blob_1002528.ply"], semantics=127, gpu_spp=32,
                             parity_spp=16, strip=64),
 }
 
