@@ -20,6 +20,7 @@
 #include "bsdf.h"
 #include "device_types.h"
 #include "launch.h"
+#include <type_traits>
 #include "traverse.h"
 #include "texture.h"
 #include "traverse_dual.h"
@@ -889,7 +890,10 @@ struct ShadeCounts {
 // slots AND diverge - nothing in here may then rely on the wave (no ballots, no list appends).
 // `listWave`: which sub-list this wave appends to (wave-uniform; unused in kShadeTail).
 constexpr int kShadeDense = 0, kShadeListed = 1, kShadeTail = 2;
-template <bool COUNT, bool SSS, int MODE>
+// TEX (only with SSS): the scene has material textures - the per-hit texture lookups and the path's ray cone are compiled in.  A
+// separate instantiation because they cost registers whether or not a scene uses them: with the texture code in, the Metal-model
+// kernel drops to 3 waves/SIMD and untextured Metal-semantics scenes ran 19-25 % slower than in round 1.
+template <bool COUNT, bool SSS, bool TEX, int MODE>
 __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const uint32_t slot, const bool inRange,
                                           const bool drained, const uint32_t listWave, ShadeCounts& counts) {
     constexpr bool TAIL = MODE == kShadeTail;
@@ -1088,7 +1092,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                 bool passThrough = false;   // the alpha test of a textured material discarded the hit
                 PbrHit pbrHit;
                 if (SSS && cc.metalPbr && type == 7u) {
-                    if (sf.primType == 0u && sc.textureCount > 0u && sc.triUv != nullptr) {
+                    if (TEX && sf.primType == 0u && sc.textureCount > 0u && sc.triUv != nullptr) {
                         cone = pool.cone ? pool.cone[slot] : make_float2(0.0f, 0.0f);
                         haveCone = pool.cone != nullptr;
                         passThrough = applyPbrTextures(sc, sf, materialIndex, mat, wo, cone, hitv.x, rng, pbrHit);
@@ -1313,7 +1317,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                             lastDelta = bs.isDelta;
                             nextO = (SSS && bs.hasExit) ? sssExitOrigin(bs.exitPoint, n, bs.dir) : offsetOrigin(sf, bs.dir);
                             nextD = bs.dir;
-                            if (SSS && pool.cone) {
+                            if (TEX && pool.cone) {
                                 // the path's ray cone: width at this hit, spread widened by the sampled lobe (pathtrace.metal:7262-7267, 5703-5715)
                                 if (!haveCone) cone = pool.cone[slot];
                                 haveCone = true;
@@ -1469,7 +1473,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
             pool.thr[slot] = mk4(thr, __uint_as_float(rng));
         }
         if (COUNT && pool.signature) pool.signature[slot] = sig;
-        if (SSS && pool.cone && stillAlive && (haveCone || newSample)) pool.cone[slot] = newSample ? primaryCone(rp) : cone;
+        if (TEX && pool.cone && stillAlive && (haveCone || newSample)) pool.cone[slot] = newSample ? primaryCone(rp) : cone;
     }
 
     if (!TAIL && pool.connectList) {
@@ -1508,7 +1512,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
 }
 
 // LISTED: the launch walks pool.busyIn instead of the slots (end of the frame, see PathPool)
-template <bool COUNT, bool SSS, bool LISTED>
+template <bool COUNT, bool SSS, bool TEX, bool LISTED>
 __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(RenderParams rp, SceneView sc, PathPool pool, ShadeResets resets) {
     const uint32_t index = blockIdx.x * kShadeBlock + threadIdx.x;
     if (index == 0u) {
@@ -1535,9 +1539,9 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
             const uint32_t at = lists.position(inRange ? index : 0u, pool.connectRegion);
             slot = inRange ? (pool.busyIn[at] & ~kBusyAliveBit) : 0u;
         }
-        shadeSlot<COUNT, SSS, kShadeListed>(rp, sc, pool, slot, inRange, drained, index >> 6, counts);
+        shadeSlot<COUNT, SSS, TEX, kShadeListed>(rp, sc, pool, slot, inRange, drained, index >> 6, counts);
     } else {
-        shadeSlot<COUNT, SSS, kShadeDense>(rp, sc, pool, index, index < pool.slots, resets.drained != 0u, index >> 6, counts);
+        shadeSlot<COUNT, SSS, TEX, kShadeDense>(rp, sc, pool, index, index < pool.slots, resets.drained != 0u, index >> 6, counts);
     }
     if (COUNT) {
         addCounter(pool.counters, kCntShadedHits, counts.shadedHit);
@@ -1927,7 +1931,7 @@ __global__ void __launch_bounds__(256) k_tail_collect(PathPool pool, uint32_t* l
     if (have) flush();
 }
 
-template <bool COUNT, bool SSS>
+template <bool COUNT, bool SSS, bool TEX>
 __global__ void __launch_bounds__(kTraceBlock) k_tail_run(RenderParams rp, SceneView sc, PathPool pool, const uint32_t* list, const uint32_t* listCount,
                                                           uint32_t* listHead, uint32_t* spill, uint32_t spillStride) {
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
@@ -1966,7 +1970,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_tail_run(RenderParams rp, Scene
                     __threadfence();
                 }
                 // k_shade's part
-                shadeSlot<COUNT, SSS, kShadeTail>(rp, sc, pool, slot, true, false, 0u, counts);
+                shadeSlot<COUNT, SSS, TEX, kShadeTail>(rp, sc, pool, slot, true, false, 0u, counts);
                 __threadfence();
                 // k_connect's part: the records this visit queued
                 uint32_t bits = pool.pending[slot] & kFlagPendingMask;
@@ -2272,12 +2276,15 @@ void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& po
     const bool sss = (rp.mediaMode & (PTR_METAL_SSS | PTR_METAL_PBR | PTR_METAL_CLAMPS)) != 0u;   // the instantiation that carries those Metal-only models
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, resets); };
     const bool listed = pool.busyIn != nullptr;   // the grid still covers every slot: waves beyond the list leave at once
+    const bool tex = sss && sc.textureCount > 0u;   // the instantiation with the texture lookups and the ray cone
+    auto pick = [&](auto countTag, auto listedTag) {
+        constexpr bool C = decltype(countTag)::value, L = decltype(listedTag)::value;
+        if (tex) launch(k_shade<C, true, true, L>); else if (sss) launch(k_shade<C, true, false, L>); else launch(k_shade<C, false, false, L>);
+    };
     if (count) {
-        if (listed) { if (sss) launch(k_shade<true, true, true>); else launch(k_shade<true, false, true>); }
-        else if (sss) launch(k_shade<true, true, false>); else launch(k_shade<true, false, false>);
+        if (listed) pick(std::true_type{}, std::true_type{}); else pick(std::true_type{}, std::false_type{});
     } else {
-        if (listed) { if (sss) launch(k_shade<false, true, true>); else launch(k_shade<false, false, true>); }
-        else if (sss) launch(k_shade<false, true, false>); else launch(k_shade<false, false, false>);
+        if (listed) pick(std::false_type{}, std::true_type{}); else pick(std::false_type{}, std::false_type{});
     }
 }
 
@@ -2329,10 +2336,11 @@ void launchTail(const RenderParams& rp, const SceneView& sc, const PathPool& poo
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, dList, dListCount, dListHead, cfg.spill, stride);
     };
+    const bool tex = sss && sc.textureCount > 0u;
     if (count) {
-        if (sss) launch(k_tail_run<true, true>); else launch(k_tail_run<true, false>);
+        if (tex) launch(k_tail_run<true, true, true>); else if (sss) launch(k_tail_run<true, true, false>); else launch(k_tail_run<true, false, false>);
     } else {
-        if (sss) launch(k_tail_run<false, true>); else launch(k_tail_run<false, false>);
+        if (tex) launch(k_tail_run<false, true, true>); else if (sss) launch(k_tail_run<false, true, false>); else launch(k_tail_run<false, false, false>);
     }
 }
 

@@ -504,6 +504,34 @@ def test_partition_and_pool_size_invariance(cornell_small):
     assert np.array_equal(again, full)                                       # and run to run
 
 
+def test_scheduling_knobs_do_not_change_the_image():
+    # How the work is scheduled - pool groups, persistent grid, the connect list, the busy lists at the end of the frame, the
+    # end-of-frame kernels, the pool size - must not show in the result: same image bit for bit, same ray and hit counters.
+    # 1080p x 12 spp = 25 M work items: a 12 Mi-slot pool in 4 groups, large enough for every mechanism to engage.
+    host = pt.HostScene.load(os.path.join(SCENES, "cornell_mesh.scene"), SCENES)
+    s = host.settings_for(width=1920, height=1080, max_depth=8, seed=1337)
+
+    def render(env):
+        os.environ.update(env)       # the knobs are read when the scene is uploaded
+        try:
+            dev = pt.DeviceScene(host.desc, 0, keepalive=host)
+            image, _ = dev.render_image(s, 12)
+            _, stats = dev.render_image(s, 12, count=True)
+            dev.close()
+        finally:
+            for k in env:
+                del os.environ[k]
+        return image, (stats.extendRays, stats.shadowRays, stats.shadedHits, stats.extendNodesVisited, stats.samples)
+
+    base, base_counts = render({})
+    assert np.isfinite(base).all() and base.mean() > 0.01 and base_counts[4] == 1920 * 1080 * 12
+    for env in ({"PTR_CONNECT_LIST": "0"}, {"PTR_BUSY_LISTS": "0"}, {"PTR_POOL_GROUPS": "1"}, {"PTR_TRACE_BLOCKS_PER_CU": "8"},
+                {"PTR_TAIL_BELOW": "0"}, {"PTR_POOL_SLOTS": str(3 << 20), "PTR_REFILL_BELOW": "24"}):
+        image, counts = render(env)
+        assert np.array_equal(image, base), env
+        assert counts == base_counts, env
+
+
 def test_frames_rendered_in_several_passes(cornell_small):
     # a frame whose per-sample accumulators do not fit the memory budget is rendered in passes of equal sample counts that add up
     # in the output buffer; the sample streams do not depend on the split, so only the order of the float additions differs
