@@ -708,6 +708,7 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
     Builder b;
     b.kLeafMax = std::min(std::max(leafMax, 1u), ptrk::kMaxLeafPrims);
     if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+    if (const char* e = std::getenv("PTR_BUILD_THREADS")) threads = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 256));   // test / tuning knob
     b.wideThreads = std::min(threads, 64u);
     b.poolThreads = std::min(threads, 64u);
     const uint32_t inTree = n - oversizeCount;

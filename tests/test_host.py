@@ -370,6 +370,29 @@ def test_bvh_invariants_config2_mesh(leaf_max):
     assert g["sah_cost_milli"] < 60_000 * (1 if leaf_max >= 2 else 2)
 
 
+def test_bvh_of_a_large_mesh_does_not_depend_on_the_thread_count():
+    # 871 k triangles: above the size where the builder splits its passes over the threads and hands subtrees to a task pool
+    # (csrc/host/bvh_builder.cpp).  The tree must be the same tree however many threads build it.
+    from scenes.gen_assets import ensure_assets, ensure_large_asset
+    ensure_assets()
+    ensure_large_asset("torus_knot_871200.ply")
+    host = pt.HostScene.load(os.path.join(ROOT, "scenes", "knot_glass.scene"), os.path.join(ROOT, "scenes"))
+    keys = ("nodes", "leaves", "max_depth", "max_leaf_size", "sah_cost_milli", "oversize", "quantized_usable")
+    seen = []
+    for threads in ("1", "3", None):
+        if threads is None:
+            os.environ.pop("PTR_BUILD_THREADS", None)
+        else:
+            os.environ["PTR_BUILD_THREADS"] = threads
+        try:
+            g = pt.debug_scene_geometry(host.desc)
+        finally:
+            os.environ.pop("PTR_BUILD_THREADS", None)
+        _geometry_ok(g, 871200 + 2 * 6, 0)
+        seen.append(tuple(g[k] for k in keys))
+    assert seen[0] == seen[1] == seen[2]
+
+
 def test_bvh_invariants_mixed_and_degenerate_scenes(tmp_path):
     for name, tris, spheres in (("materials.scene", None, None), ("env_materials.scene", None, None)):
         host = pt.HostScene.load(os.path.join(ROOT, "tests", "golden", name), os.path.join(ROOT, "scenes"))
