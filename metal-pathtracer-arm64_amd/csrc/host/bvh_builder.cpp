@@ -11,6 +11,7 @@
 #include <memory>
 #include <numeric>
 #include <thread>
+#include <unordered_map>
 
 #include "../kernels/bvh_layout.h"
 
@@ -503,6 +504,9 @@ struct Flattener {
     const Builder& b;
     FlatBvh& out;
     std::vector<uint32_t> primToTri, primToSphere;  // input index -> n-th triangle / sphere
+    // PTR_BFS_TOP=<n> (experiment: the top of the tree staged in LDS): the n internal nodes nearest the root get device indices
+    // 0 .. n-1 in breadth-first order, the subtrees below them contiguous preorder blocks after that.  temp node -> device index.
+    std::unordered_map<uint32_t, uint32_t> placed;
 
     struct Stats {
         double sahCost = 0.0;
@@ -548,7 +552,14 @@ struct Flattener {
         const TempNode& l = b.nodes[n.left];
         const uint32_t kids[2] = {n.left, n.right};
         const uint32_t triBase[2] = {it.triBase, it.triBase + l.triPrims}, sphereBase[2] = {it.sphereBase, it.sphereBase + l.spherePrims};
-        const uint32_t device[2] = {it.device + 1u, it.device + 1u + l.internalNodes};
+        // preorder: the left subtree follows its parent, the right one follows the left subtree - unless the node was given a place
+        // of its own (breadth-first top of the tree, see run())
+        auto placeOf = [&](uint32_t temp, uint32_t preorder) {
+            if (placed.empty()) return preorder;
+            const auto found = placed.find(temp);
+            return found != placed.end() ? found->second : preorder;
+        };
+        const uint32_t device[2] = {placeOf(n.left, it.device + 1u), placeOf(n.right, it.device + 1u + l.internalNodes)};
         Item next[2];
         bool internal[2] = {false, false};
         for (int s = 0; s < 2; ++s) {
@@ -587,6 +598,32 @@ struct Flattener {
         }
         out.nodeCount = root.internalNodes;
         out.nodes.assign(static_cast<size_t>(out.nodeCount) * 16, 0.0f);
+        if (const char* e = std::getenv("PTR_BFS_TOP")) {
+            const uint32_t want = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 0), 1 << 16));
+            if (want > 1u && root.internalNodes > want) {
+                std::vector<uint32_t> top{0u};
+                placed[0u] = 0u;
+                for (size_t head = 0; head < top.size() && top.size() < want; ++head) {
+                    const TempNode& n = b.nodes[top[head]];
+                    for (uint32_t kid : {n.left, n.right}) {
+                        if (b.nodes[kid].count == 0 && top.size() < want) {
+                            placed[kid] = static_cast<uint32_t>(top.size());
+                            top.push_back(kid);
+                        }
+                    }
+                }
+                uint32_t next = static_cast<uint32_t>(top.size());
+                for (uint32_t t : top) {
+                    const TempNode& n = b.nodes[t];
+                    for (uint32_t kid : {n.left, n.right}) {
+                        if (b.nodes[kid].count == 0 && placed.find(kid) == placed.end()) {
+                            placed[kid] = next;
+                            next += b.nodes[kid].internalNodes;
+                        }
+                    }
+                }
+            }
+        }
         // the top of the tree serially (breadth first, until there are a few subtrees per thread), the subtrees in parallel
         std::vector<Item> tasks{{0u, 0u, 0u, 0u, 0u}};
         const size_t wanted = out.nodeCount >= (1u << 16) ? static_cast<size_t>(std::max(threads, 1u)) * 4u : 1u;

@@ -62,9 +62,15 @@ struct LaneStack {
 // address arithmetic, and returns zeros instead of faulting if an index were ever out of range.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// PTR_LDS_TOP=<n> (experiment, with the host's PTR_BFS_TOP=<n> layout): the n quantised nodes nearest the root are copied into
+// LDS by every block of k_extend / k_connect and fetched from there.
+#ifndef PTR_LDS_TOP
+#define PTR_LDS_TOP 0
+#endif
 struct SceneMem {
     __amdgpu_buffer_rsrc_t nodes;   // quantised or float nodes, whichever the scene uses
     __amdgpu_buffer_rsrc_t tris;
+    const uint4* top = nullptr;     // LDS copy of nodes 0 .. PTR_LDS_TOP-1 (two uint4 each), or null
 };
 
 __device__ __forceinline__ SceneMem sceneMem(const SceneView& sc) {
@@ -280,7 +286,14 @@ __device__ __forceinline__ bool travNodeStep(const SceneView& sc, const SceneMem
     // both halves of the node are fetched up front and both boxes tested without branching: a short-circuit
     // on the child reference made the compiler issue the second half as a dependent load
     if (NODES == 1 || (NODES < 0 && sc.useQuantized)) {
-        const uint4 q0 = load16u(mem.nodes, t.cur * 32u), q1 = load16u(mem.nodes, t.cur * 32u + 16u);
+        uint4 q0, q1;
+        if (PTR_LDS_TOP > 0 && NODES == 1 && mem.top != nullptr && t.cur < static_cast<uint32_t>(PTR_LDS_TOP)) {
+            q0 = mem.top[t.cur * 2u];
+            q1 = mem.top[t.cur * 2u + 1u];
+        } else {
+            q0 = load16u(mem.nodes, t.cur * 32u);
+            q1 = load16u(mem.nodes, t.cur * 32u + 16u);
+        }
         ref0 = q0.w;
         ref1 = q1.w;
         h0 = slabTest(gridLo(q0.x, q0.y), gridHi(q0.y, q0.z), t.oi, t.inv, t.tnear, t.hit.t, e0);

@@ -516,7 +516,15 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
     uint32_t activeLanes = 0u, leafLanes = 0u, voteIterations = 0u;   // counting build: occupancy of the vote iterations
     const long long kernelStart = COUNT ? clock64() : 0ll;
 
-    const SceneMem mem = sceneMem(sc);
+    SceneMem mem = sceneMem(sc);
+#if PTR_LDS_TOP > 0
+    __shared__ uint4 ldsTop[PTR_LDS_TOP * 2];
+    if (NODES == 1 && sc.nodeBytes >= PTR_LDS_TOP * 32u) {
+        for (uint32_t i = threadIdx.x; i < PTR_LDS_TOP * 2u; i += kTraceBlock) ldsTop[i] = sc.qnodes[i];
+        __syncthreads();
+        mem.top = ldsTop;
+    }
+#endif
     // end of the frame (the ALIVE instantiation): the work is the busy list k_shade left, not the slots (PathPool::busyIn)
     bool listed = ALIVE && pool.busyIn != nullptr;
     SubLists lists{0u, pool.slots};
@@ -1664,7 +1672,15 @@ __global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_e
 
     // The work list is the slot pool itself: a lane takes a slot, reads its pending mask and resolves that
     // slot's records one after another (no compaction queue -> no hot atomic counter in k_shade).
-    const SceneMem mem = sceneMem(sc);
+    SceneMem mem = sceneMem(sc);
+#if PTR_LDS_TOP > 0
+    __shared__ uint4 ldsTop[PTR_LDS_TOP * 2];
+    if (NODES == 1 && sc.nodeBytes >= PTR_LDS_TOP * 32u) {
+        for (uint32_t i = threadIdx.x; i < PTR_LDS_TOP * 2u; i += kTraceBlock) ldsTop[i] = sc.qnodes[i];
+        __syncthreads();
+        mem.top = ldsTop;
+    }
+#endif
     // With a connect list (PathPool::connectList) the work is the list's entries: lane l reads the counter of sub-list l, a wave
     // prefix sum gives every sub-list its place in one dense index space, and a lane finds the sub-list of an index with six
     // cross-lane reads.  Measured before: 3.5 slots probed per ray found on config 2 (a third of the slots queue a record), more as

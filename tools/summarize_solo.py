@@ -2,7 +2,8 @@
 """Turn one tools/measure_solo.sh directory into a per-kernel JSON record:
 durations from the --stats pass, HBM-side bytes from the FETCH_SIZE / WRITE_SIZE passes (FETCH doubled: on gfx950 the counter
 tallies the 128 B requests of wide reads at 64 B, MI355X_MICROARCH.md section HBM; both are reported in KB), VALU lane
-utilisation = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64), VALU issue = SQ_INSTS_VALU x 4 / (GRBM_GUI_ACTIVE x 128)."""
+utilisation = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64), VALU issue = SQ_INSTS_VALU x 4 / (GRBM_GUI_ACTIVE x 128),
+share of the waves' cycles spent waiting = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES."""
 import csv
 import glob
 import json
@@ -60,6 +61,12 @@ for k in sorted(set(dur) | set(tot)):
         if c.get("GRBM_GUI_ACTIVE", 0) > 0:
             r["valu_issue"] = round(c["SQ_INSTS_VALU"] / max(calls[k]["SQ_INSTS_VALU"], 1) * 4.0 /
                                     (c["GRBM_GUI_ACTIVE"] / max(calls[k]["GRBM_GUI_ACTIVE"], 1) * 128.0), 4)
+    if c.get("SQ_WAVE_CYCLES", 0) > 0:
+        # how the resident waves spend their cycles: waiting on any outstanding instruction (memory above all) against the
+        # share in which a vector-memory or LDS instruction is in flight for them
+        r["wave_cycles_waiting"] = round(c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"], 4)
+        r["wave_cycles_vmem_active"] = round(c.get("SQ_ACTIVE_INST_VMEM", 0) / c["SQ_WAVE_CYCLES"], 4)
+        r["wave_cycles_lds_active"] = round(c.get("SQ_ACTIVE_INST_LDS", 0) / c["SQ_WAVE_CYCLES"], 4)
     rec["kernels"][k] = r
 with open(out_path, "w") as f:
     json.dump(rec, f, indent=1)
