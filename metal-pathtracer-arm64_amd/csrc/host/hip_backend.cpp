@@ -1031,6 +1031,13 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
                 std::fprintf(stderr, "[steps] k_extend: %.3g vote iterations; lanes holding a ray %.1f / 64 on average, of which at a leaf %.1f\n", votes,
                              static_cast<double>(c[kCntExtendActiveLanes]) / std::max(votes, 1.0),
                              static_cast<double>(c[kCntExtendLeafLanes]) / std::max(votes, 1.0));
+                const double shadeLanes = std::max(static_cast<double>(c[kCntShadeWaves]), 1.0);
+                std::fprintf(stderr, "[steps] k_shade: %.3g wave visits; share of their lanes at each stage: ray traced %.3f, surface hit %.3f, of which a light "
+                                     "%.3f; light sample evaluated %.3f, tested against the light's own triangles %.3f, shadow ray queued %.3f; BSDF sampled "
+                                     "%.3f; new work item wanted %.3f\n",
+                             shadeLanes / 64.0, c[kCntShadeAlive] / shadeLanes, c[kCntShadeSurface] / shadeLanes, c[kCntShadeEmitter] / shadeLanes,
+                             c[kCntShadeLightEval] / shadeLanes, c[kCntShadeLightPretest] / shadeLanes, c[kCntShadeLightStored] / shadeLanes,
+                             c[kCntShadeBsdfSample] / shadeLanes, c[kCntShadeNeedItem] / shadeLanes);
                 std::fprintf(stderr, "[steps] k_extend: refill passes take %.1f %% of the waves' time in the kernel\n",
                              100.0 * static_cast<double>(c[kCntExtendRefillTicks]) / std::max(static_cast<double>(c[kCntExtendWaveTicks]), 1.0));
             }

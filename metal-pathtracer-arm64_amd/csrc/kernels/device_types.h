@@ -238,7 +238,17 @@ enum CounterSlot : uint32_t {
     kCntExtendActiveLanes = 17,     // sum over vote iterations of the lanes holding a ray
     kCntExtendLeafLanes = 18,       // ... of which at a leaf
     kCntExtendVoteIterations = 19,  // 64 x vote iterations
-    kCounterSlots = 24,
+    // k_shade, counting build (PTR_TRACE_STEPS): lanes that reach each stage of a visit, and 64 x the waves that ran a visit at all
+    kCntShadeWaves = 24,
+    kCntShadeAlive = 25,        // slots with a ray that was traced
+    kCntShadeSurface = 26,      // ... that hit a surface
+    kCntShadeEmitter = 27,      // ... which was a light (the path ends there)
+    kCntShadeLightEval = 28,    // rectangle-light samples that reach the BSDF evaluation
+    kCntShadeLightPretest = 29, // ... and the test against the light's own triangles
+    kCntShadeLightStored = 30,  // ... and queue a shadow ray
+    kCntShadeBsdfSample = 31,   // lanes that sample the BSDF
+    kCntShadeNeedItem = 32,     // lanes that ask for a new work item
+    kCounterSlots = 40,
 };
 
 }  // namespace ptrk

@@ -890,6 +890,7 @@ __device__ __forceinline__ bool applyPbrTextures(const SceneView& sc, const Surf
 // SSS: the instantiation with the Metal subsurface semantics (launched when PTR_METAL_SSS is set)
 struct ShadeCounts {
     uint32_t shadedHit = 0u, triHit = 0u, primary = 0u;   // counting build
+    uint32_t stage[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // kCntShadeWaves ... kCntShadeNeedItem
 };
 
 // One visit of a path slot: what k_shade does for its thread's slot.  MODE kShadeDense: lane l of wave w holds slot 64 w + l.
@@ -932,6 +933,10 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                  "v"(landed[3].x), "v"(landed[4].x));   // keep the loads here: the compiler would sink each one next to its use
     const bool active = inRange && (flagsIn & kFlagAlive);
     const bool touched = inRange && (active || pendingIn != 0u || (flagsIn & kFlagFlush));   // state/accum rewritten
+    if (COUNT) {
+        counts.stage[0] += 1u;   // every lane counts its wave: the sum is 64 x the waves
+        counts.stage[1] += active ? 1u : 0u;
+    }
 
     bool want[kRecSlots] = {false, false, false, false, false};
     bool stillAlive = false, needItem = false, walkFlag = false;
@@ -1071,6 +1076,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                 const Surface sf = reconstruct(sc, rayO, rayD, hitv.x, prim);
                 if (COUNT) {
                     shadedHit = 1u;
+                    if (COUNT) counts.stage[2] += 1u;
                     triHit = sf.primType == 0u ? 1u : 0u;
                     sig = (sig & 0xFFFFu) | (sigHashStep(sig >> 16, sf.primType, sf.geomIndex, sf.primIndex) << 16);
                 }
@@ -1127,6 +1133,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                     lastDelta = true;
                     specDepth += 1u;
                 } else if (type == 3u) {
+                    if (COUNT) counts.stage[3] += 1u;
                     // ---- emitter reached by a BSDF-sampled ray ----
                     const float4 em = mat.v(kMatEmission);
                     f3 emission = mk3(em) * rp.emissionScale;
@@ -1172,6 +1179,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                                 const f3 emission = mk3(L[4]) * rp.emissionScale;
                                 const float nDotL = smax(dot(n, ldir), 0.0f);
                                 if (pdf > 0.0f && isfinite(pdf) && (dot(emission, emission) > 0.0f) && nDotL > 0.0f) {
+                                    if (COUNT) counts.stage[4] += 1u;
                                     const BsdfEvalResult be = evalBsdf<SSS>(mat, sf.position, n, wo, ldir, cc);
                                     if (!be.isDelta && be.pdf > 0.0f) {
                                         const float w = pdf / (pdf + be.pdf);   // balance heuristic, unclamped
@@ -1193,12 +1201,14 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                                                 // registers are live, not with the rest of the record.
                                                 float tt, tu, tv;
                                                 bool occludedByLight = false;
+                                                if (COUNT) counts.stage[5] += 1u;
                                                 if (PTR_LIGHT_PRETEST != 0 && l3.w != 0.0f) {
                                                     occludedByLight = triangleTest(mk3(L[5]), mk3(L[6]), mk3(L[7]), shadowOrg, ldir, kEps, shadowMax, tt, tu, tv) ||
                                                                       triangleTest(mk3(L[8]), mk3(L[9]), mk3(L[10]), shadowOrg, ldir, kEps, shadowMax, tt, tu, tv);
                                                 }
                                                 if (!occludedByLight) {
                                                     // a.w: depth of this vertex, for the path signature of the counting build
+                                                    if (COUNT) counts.stage[6] += 1u;
                                                     storeRecord(pool, slot, 0u, 0u, shadowOrg, shadowMax, ldir, clamped, static_cast<float>(depth), mk3(0.0f));
                                                     want[0] = true;
                                                 }
@@ -1261,6 +1271,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                             wr.b[slot] = mk4(n, 0.0f);
                         }
                     }
+                    if (COUNT) counts.stage[7] += 1u;
                     if (!SSS || (!haveSample && !walking)) bs = sampleBsdf<SSS>(mat, sf.position, n, wo, incident, sf.frontFace, rng, cc);
                     if (SSS && walking) {
                         // nothing else this visit: the walk's first boundary query is the slot's next ray
@@ -1381,6 +1392,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
         }
     }
 
+    if (COUNT) counts.stage[8] += needItem ? 1u : 0u;
     // ---- claim new work items ----
     if (MODE != kShadeDense) {
         // end of the frame: the range heads are dry; what can be left is the unused part of the last reservation of this slot's
@@ -1555,6 +1567,8 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
         addCounter(pool.counters, kCntShadedHits, counts.shadedHit);
         addCounter(pool.counters, kCntTriangleHits, counts.triHit);
         addCounter(pool.counters, kCntPrimaryRays, counts.primary);
+#pragma unroll
+        for (uint32_t k = 0; k < 9u; ++k) addCounter(pool.counters, kCntShadeWaves + k, counts.stage[k]);
     }
 }
 
