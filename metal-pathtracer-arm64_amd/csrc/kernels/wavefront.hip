@@ -35,7 +35,10 @@ constexpr float kSpecNeePdfFloor = 1.0e-4f;
 constexpr float kSpecNeeInvPdfClamp = 1.0e4f;
 constexpr float kMisMin = 1.0e-4f;
 constexpr float kMisMax = 0.9999f;
-constexpr uint32_t kShadeBlock = 128u;
+#ifndef PTR_SHADE_BLOCK
+#define PTR_SHADE_BLOCK 128
+#endif
+constexpr uint32_t kShadeBlock = PTR_SHADE_BLOCK;
 
 __device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
