@@ -194,12 +194,16 @@ typedef struct PtrSettings {
      * (:4598-4948): specular, diffuse and transmission lobes picked by weight (KHR_materials_transmission factor in
      * pbrExtras.z, thickness tint :3295-3306), visible-normal sampling with the G1 pdf, energy compensation on the
      * specular lobe, rough refraction with the Walter et al. Jacobian, delta mirror / delta refraction at roughness
-     * <= 1e-3 (which then also counts as a delta surface, :4570-4586); factors only - textures are not covered.
+     * <= 1e-3 (which then also counts as a delta surface, :4570-4586), and the material textures of the glTF path
+     * (:5919-6400; PtrSceneDesc.textures, filtering rule in csrc/kernels/texture.h).
      * Bit 6 (PTR_METAL_CLAMPS): the Metal kernel's variants of the luminance clamps (shaders/pathtrace.metal:3550-3633; SURVEY.md
      * Appendix A rows 4-6): the firefly limit is raised to fireflyClampMaxContribution when that is positive (default 1000: far
      * looser than the Embree backend's max(32 lum(throughput), 4)); clamp_specular_tail is skipped while base and roughness
      * scale are both zero (the default - the Embree backend then still caps the lobe's luminance at the clamp floor);
-     * clamp_specular_pdf returns 0 for a non-finite or non-positive pdf and the pdf itself while minSpecularPdf <= 0. */
+     * clamp_specular_pdf returns 0 for a non-finite or non-positive pdf and the pdf itself while minSpecularPdf <= 0.  With
+     * them go the next-event-estimation weights of the Metal kernel (:6532-6552, 6624-6645; Appendix A row 13): a light or
+     * environment sample counts when the BSDF value is positive (not: when it has a density), its balance weight is clamped to
+     * [1e-4, 0.9999], and the weight is 1 where the BSDF reports no density. */
     uint32_t metalSemantics;
     uint32_t sssMode;   /* RenderSettings::SssMode: 0 off, 1 separable, 2 random walk; read only with PTR_METAL_SSS */
     uint32_t sssMaxSteps;   /* RenderSettings::sssMaxSteps (32): closest-hit queries per random walk, at least 1 */

@@ -65,6 +65,26 @@ __device__ __forceinline__ ClampCfg clampCfg(const RenderParams& rp) {
     return c;
 }
 
+// Next-event estimation: the Embree path counts a light sample when the BSDF has a density for its direction and weights it with the
+// unclamped balance heuristic (E:2753-2756, 2800-2802); the Metal kernel (PTR_METAL_CLAMPS, pathtrace.metal:6532-6552, 6624-6645) counts
+// it when the BSDF value is positive, clamps the weight to [1e-4, 0.9999] and uses 1 where the BSDF reports no density.
+template <bool METAL>
+__device__ __forceinline__ bool neeContributes(const BsdfEvalResult& be, const ClampCfg& cc) {
+    if (be.isDelta) return false;
+    if (METAL && cc.metalClamps) return smax(smax(be.value.x, be.value.y), be.value.z) > 0.0f;
+    return be.pdf > 0.0f;
+}
+template <bool METAL>
+__device__ __forceinline__ float neeWeight(float lightPdf, float bsdfPdf, const ClampCfg& cc) {
+    if (!(METAL && cc.metalClamps)) return lightPdf / (lightPdf + bsdfPdf);
+    float weight = 1.0f;
+    if (bsdfPdf > 0.0f) {
+        const float denom = lightPdf + bsdfPdf;
+        if (denom > 0.0f) weight = clampf(lightPdf / denom, kMisMin, kMisMax);
+    }
+    return weight;
+}
+
 // ---------------------------------------------------------------- wave helpers
 __device__ __forceinline__ uint32_t laneId() { return __lane_id(); }
 
@@ -1184,8 +1204,8 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                                 if (pdf > 0.0f && isfinite(pdf) && (dot(emission, emission) > 0.0f) && nDotL > 0.0f) {
                                     if (COUNT) counts.stage[4] += 1u;
                                     const BsdfEvalResult be = evalBsdf<SSS>(mat, sf.position, n, wo, ldir, cc);
-                                    if (!be.isDelta && be.pdf > 0.0f) {
-                                        const float w = pdf / (pdf + be.pdf);   // balance heuristic, unclamped
+                                    if (neeContributes<SSS>(be, cc)) {
+                                        const float w = neeWeight<SSS>(pdf, be.pdf, cc);
                                         f3 contrib = (emission * be.value) * nDotL;
                                         contrib *= w / pdf;
                                         if (finite3(contrib)) {
@@ -1235,8 +1255,8 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                         if (epdf > 0.0f && nDotL > 0.0f) {
                             const f3 envRadiance = envLookup(sc, edir, rp.envRotation, rp.envIntensity);
                             const BsdfEvalResult be = evalBsdf<SSS>(mat, sf.position, n, wo, edir, cc);
-                            if (!be.isDelta && be.pdf > 0.0f) {
-                                const float w = epdf / (epdf + be.pdf);
+                            if (neeContributes<SSS>(be, cc)) {
+                                const float w = neeWeight<SSS>(epdf, be.pdf, cc);
                                 f3 contrib = (envRadiance * be.value) * nDotL;
                                 contrib *= w / epdf;
                                 if (finite3(contrib)) {

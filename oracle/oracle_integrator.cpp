@@ -97,6 +97,24 @@ V3 schlickFresnel(V3 f0, float cosTheta) { return f0 + (V3(1.0f, 1.0f, 1.0f) - f
 // ---------------------------------------------------------------------------------------------
 // clamps                                                                              E:406-479
 // ---------------------------------------------------------------------------------------------
+// Next-event estimation, Embree path (E:2753-2756, 2800-2802): a light sample counts when the BSDF has a density for its direction,
+// with the unclamped balance weight.  Metal kernel (M:6532-6552, 6624-6645; PTR_METAL_CLAMPS, Appendix A row 13): it counts when the BSDF
+// value is positive; the weight is clamped to [1e-4, 0.9999], and 1 where the BSDF reports no density.
+static bool neeContributes(const BsdfEval& be, const ClampParams& p) {
+    if (be.isDelta) return false;
+    if (p.metalClamps) return std::max(std::max(be.value.x, be.value.y), be.value.z) > 0.0f;
+    return be.pdf > 0.0f;
+}
+static float neeWeight(float lightPdf, float bsdfPdf, const ClampParams& p) {
+    if (!p.metalClamps) return lightPdf / (lightPdf + bsdfPdf);
+    float weight = 1.0f;
+    if (bsdfPdf > 0.0f) {
+        const float denom = lightPdf + bsdfPdf;
+        if (denom > 0.0f) weight = clampf(lightPdf / denom, kMisWeightClampMin, kMisWeightClampMax);
+    }
+    return weight;
+}
+
 V3 clampFireflyContribution(V3 throughput, V3 contribution, const ClampParams& p) {
     V3 combined = throughput * contribution;
     if (!finite3(combined)) return V3();
@@ -2374,8 +2392,8 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
                             }
                             if (!occluded(offsetRayOrigin(hit, ls.direction), ls.direction, shadowMax)) {
                                 const BsdfEval be = evaluateBsdf(material, hit.position, shadingNormal, wo, ls.direction, cp);
-                                if (!be.isDelta && be.pdf > 0.0f) {
-                                    const float weight = ls.pdf / (ls.pdf + be.pdf);  // unclamped balance heuristic
+                                if (neeContributes(be, cp)) {
+                                    const float weight = neeWeight(ls.pdf, be.pdf, cp);
                                     V3 contribution = (ls.emission * be.value) * nDotL;
                                     contribution *= weight / ls.pdf;
                                     if (finite3(contribution)) {
@@ -2402,8 +2420,8 @@ void render(const Scene& scene, const PtrSceneDesc& desc, const PtrSettings& set
                         if (!occluded(offsetRayOrigin(hit, es.direction), es.direction, kInf)) {
                             const V3 envRadiance = sampleEnvironment(*env, es.direction, settings.environmentRotation, settings.environmentIntensity);
                             const BsdfEval be = evaluateBsdf(material, hit.position, shadingNormal, wo, es.direction, cp);
-                            if (!be.isDelta && be.pdf > 0.0f) {
-                                const float weight = es.pdf / (es.pdf + be.pdf);
+                            if (neeContributes(be, cp)) {
+                                const float weight = neeWeight(es.pdf, be.pdf, cp);
                                 V3 contribution = (envRadiance * be.value) * nDotL;
                                 contribution *= weight / es.pdf;
                                 if (finite3(contribution)) radiance += clampFireflyContribution(throughput, contribution, cp);
