@@ -19,7 +19,7 @@ namespace ptr {
 namespace {
 
 constexpr int kBins = 16;
-constexpr uint32_t kDepthLimit = ptrk::kTraversalStackDepth - 2;   // leaves sit at depth <= kDepthLimit
+constexpr uint32_t kDepthLimit = ptrk::kMaxTreeDepth - 2;   // leaves sit at depth <= kDepthLimit
 
 struct Aabb {
     float lo[3], hi[3];

@@ -8,7 +8,7 @@
 //   * 64 B nodes hold both child boxes + child references (one fetch decides both children),
 //   * leaves are folded into the parent's child reference (no leaf node fetch),
 //   * primitives are re-ordered into leaf order so a leaf is one contiguous run,
-//   * tree depth is bounded (< kTraversalStackDepth) so the traversal stack can never overflow.
+//   * tree depth is bounded (< kMaxTreeDepth) so the traversal stack can never overflow.
 #pragma once
 
 #include <cstdint>

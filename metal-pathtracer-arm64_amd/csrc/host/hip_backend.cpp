@@ -110,6 +110,7 @@ float bitsToFloat(uint32_t u) {
 struct PtrDeviceScene {
     int device = 0;
     DeviceBuffer<uint4> qnodes;
+    DeviceBuffer<uint4> wnodes;   // PTR_WIDE_NODES=1: four-wide nodes (SceneView::wnodes)
     DeviceBuffer<float4> nodes, tris, triNormals, spheres, materials, rects, rectLights, envRgba;
     DeviceBuffer<uint2> sphereInfo;
     DeviceBuffer<int32_t> lightIndexByRect;
@@ -376,6 +377,52 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     std::memcpy(v.gridCell, bvh.gridCell, sizeof(v.gridCell));
     for (int a = 0; a < 3; ++a) v.gridInvCell[a] = 1.0f / bvh.gridCell[a];
     v.useQuantized = useQuantized ? 1u : 0u;
+    bool useWide = useQuantized && static_cast<uint64_t>(bvh.nodeCount) * 64u <= 0xFFFFFFFFull;
+    if (const char* e = std::getenv("PTR_WIDE_NODES")) useWide = useWide && std::atoi(e) != 0;   // A/B knob
+    if (useWide) {
+        // Four-wide nodes for the persistent traversal kernels: every second level of the binary tree is collapsed.  Wide node j =
+        // the 16 B child records of binary node j's children's children (a child that is a leaf keeps its own record), stored at
+        // index j so that the child references stay valid - half the wide nodes are never visited, which costs memory (64 B per binary
+        // node beside the 32 B binary array that the cold kernels and the counting build keep walking) but no renumbering.
+        std::unique_ptr<uint32_t[]> wide(new uint32_t[static_cast<size_t>(bvh.nodeCount) * 16u]);
+        const uint32_t* q = bvh.qnodes.data();
+        const uint32_t nodeCount = bvh.nodeCount;
+        const uint32_t workers = nodeCount >= (1u << 16) ? std::min(32u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        auto collapse = [&](uint32_t begin, uint32_t end) {
+            for (uint32_t j = begin; j < end; ++j) {
+                uint32_t* w = wide.get() + static_cast<size_t>(j) * 16u;
+                uint32_t filled = 0;
+                for (uint32_t side = 0; side < 2u; ++side) {
+                    const uint32_t* rec = q + static_cast<size_t>(j) * 8u + side * 4u;
+                    const uint32_t ref = rec[3];
+                    if (ref == ptrk::kRefEmpty) continue;
+                    if (ref & ptrk::kRefLeafBit) {
+                        std::memcpy(w + 4u * filled++, rec, 16);
+                    } else {
+                        for (uint32_t g = 0; g < 2u; ++g) {
+                            const uint32_t* grand = q + static_cast<size_t>(ref) * 8u + g * 4u;
+                            if (grand[3] != ptrk::kRefEmpty) std::memcpy(w + 4u * filled++, grand, 16);
+                        }
+                    }
+                }
+                for (; filled < 4u; ++filled) {
+                    for (uint32_t k = 0; k < 4u; ++k) w[4u * filled + k] = ptrk::kRefEmpty;
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        const uint32_t chunk = (nodeCount + workers - 1u) / workers;
+        for (uint32_t k = 1; k < workers; ++k) {
+            const uint32_t b = std::min(nodeCount, chunk * k), e2 = std::min(nodeCount, chunk * (k + 1u));
+            if (b < e2) pool.emplace_back(collapse, b, e2);
+        }
+        collapse(0u, std::min(nodeCount, chunk));
+        for (auto& th : pool) th.join();
+        ds.wnodes.upload(reinterpret_cast<const uint4*>(wide.get()), static_cast<size_t>(nodeCount) * 4u);
+        v.wnodes = ds.wnodes.ptr;
+        v.wideBytes = static_cast<uint32_t>(static_cast<size_t>(nodeCount) * 64u);
+        v.useWide = 1u;
+    }
     const size_t nodeBytes = v.useQuantized ? bvh.qnodes.size() * 4u : bvh.nodes.size() * 4u;
     const size_t triBytes = geo.triData.size() * 4u;
     if (nodeBytes > 0xFFFFFFFFull || triBytes > 0xFFFFFFFFull) throw HipError{"scene exceeds the 4 GiB node/triangle array limit"};

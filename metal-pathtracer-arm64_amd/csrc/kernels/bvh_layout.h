@@ -15,7 +15,10 @@ constexpr uint32_t kRefSphereBit = 0x40000000u;
 constexpr uint32_t kRefCountShift = 26u;
 constexpr uint32_t kRefOffsetMask = 0x03FFFFFFu;
 constexpr uint32_t kMaxLeafPrims = 8u;
-constexpr uint32_t kTraversalStackDepth = 48u;   // builder bounds tree depth below this
+constexpr uint32_t kMaxTreeDepth = 48u;          // the builder bounds the depth of the binary tree below this
+// Entries a traversal stack can hold.  The binary walk pushes at most one entry per level (< kMaxTreeDepth); the four-wide walk
+// (two binary levels per step) up to three per step: 3 x kMaxTreeDepth / 2 = 72, plus the root beside the oversize leaf.
+constexpr uint32_t kTraversalStackDepth = 76u;
 constexpr uint32_t kLdsStackLevels = 16u;        // stack levels kept in LDS; deeper levels spill to HBM
 #ifndef PTR_TRACE_BLOCK   // 64, 128 or 256
 #define PTR_TRACE_BLOCK 256

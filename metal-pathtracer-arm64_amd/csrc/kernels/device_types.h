@@ -50,6 +50,12 @@ struct SceneView {
     uint32_t nodeBytes;            // size of the node array in use (qnodes or nodes): buffer-descriptor range
     uint32_t triBytes;             // size of the triangle array
     uint32_t oversizeRef;          // leaf reference of the triangles kept out of the tree (kRefEmpty: none): every ray tests them first
+    // PTR_WIDE_NODES=1 (experiment): 64 B four-wide quantised nodes for k_extend / k_connect.  wnodes[j] holds, for binary node j, the
+    // 16 B child records of its grandchildren (a child that is a leaf keeps its own record; unused places are kRefEmpty), indexed
+    // like the binary nodes so the child references stay valid; every second level of the binary tree is never visited.
+    const uint4* wnodes;
+    uint32_t wideBytes;
+    uint32_t useWide;
     // ---- material textures (PTR_METAL_PBR only; all null / 0 when the scene has none) - kernels/texture.h
     const float4* triUv;           // 4 float4 per triangle, leaf order: (uv0, uv1) of the three vertices, then (uvPerWorld0, uvPerWorld1, 0, 0)
     const float4* triTangent;      // 3 float4 per triangle, leaf order: world-space vertex tangents, w = handedness (0: none)

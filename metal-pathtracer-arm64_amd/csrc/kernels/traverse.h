@@ -46,7 +46,7 @@ struct LaneStack {
         } else if (sp < kTraversalStackDepth) {
             *spillSlot(sp) = v;
         } else {
-            return;  // cannot happen: the builder bounds tree depth below kTraversalStackDepth
+            return;  // cannot happen: the builder bounds the tree depth (bvh_layout.h)
         }
         ++sp;
     }
@@ -71,6 +71,7 @@ struct SceneMem {
     __amdgpu_buffer_rsrc_t nodes;   // quantised or float nodes, whichever the scene uses
     __amdgpu_buffer_rsrc_t tris;
     const uint4* top = nullptr;     // LDS copy of nodes 0 .. PTR_LDS_TOP-1 (two uint4 each), or null
+    __amdgpu_buffer_rsrc_t wide;    // four-wide nodes (NODES == 2 instantiations only)
 };
 
 __device__ __forceinline__ SceneMem sceneMem(const SceneView& sc) {
@@ -78,6 +79,7 @@ __device__ __forceinline__ SceneMem sceneMem(const SceneView& sc) {
     const void* nodes = sc.useQuantized ? static_cast<const void*>(sc.qnodes) : static_cast<const void*>(sc.nodes);
     m.nodes = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(nodes), 0, sc.nodeBytes, 0x00020000);
     m.tris = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(sc.tris), 0, sc.triBytes, 0x00020000);
+    m.wide = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(sc.wnodes), 0, sc.wideBytes, 0x00020000);
     return m;
 }
 
@@ -212,7 +214,7 @@ __device__ __forceinline__ bool travBegin(const SceneView& sc, Trav& t, f3 org, 
     // and padded boxes; the reported hit comes from the exact primitive tests on t.org / t.dir
     t.inv = mk3(fminf(fmaxf(__builtin_amdgcn_rcpf(dir.x), -kInvMax), kInvMax), fminf(fmaxf(__builtin_amdgcn_rcpf(dir.y), -kInvMax), kInvMax),
                 fminf(fmaxf(__builtin_amdgcn_rcpf(dir.z), -kInvMax), kInvMax));
-    if (NODES == 1 || (NODES < 0 && sc.useQuantized)) {
+    if (NODES >= 1 || (NODES < 0 && sc.useQuantized)) {
         const f3 cell = mk3(sc.gridCell[0], sc.gridCell[1], sc.gridCell[2]);
         const f3 invCell = mk3(sc.gridInvCell[0], sc.gridInvCell[1], sc.gridInvCell[2]);
         const f3 orgQ = (org - mk3(sc.gridOrigin[0], sc.gridOrigin[1], sc.gridOrigin[2])) * invCell;
@@ -277,9 +279,52 @@ __device__ __forceinline__ f3 gridHi(uint32_t w1, uint32_t w2) {
     return mk3(static_cast<float>(w1 >> 16), static_cast<float>(w2 & 0xFFFFu), static_cast<float>(w2 >> 16));
 }
 
+// Node step over a four-wide node (NODES == 2, SceneView::wnodes): four boxes, the hit children in order of entry distance (a
+// five-exchange sorting network on (distance, reference) pairs), the nearest is walked next, the others are pushed far to near.
+template <bool COUNT>
+__device__ __forceinline__ bool travWideStep(const SceneMem& mem, Trav& t, LaneStack& stack, TraceCounters& cnt) {
+    const uint32_t at = t.cur * 64u;
+    const uint4 c0 = load16u(mem.wide, at), c1 = load16u(mem.wide, at + 16u), c2 = load16u(mem.wide, at + 32u), c3 = load16u(mem.wide, at + 48u);
+    float k0, k1, k2, k3;
+    const bool h0 = slabTest(gridLo(c0.x, c0.y), gridHi(c0.y, c0.z), t.oi, t.inv, t.tnear, t.hit.t, k0) & (c0.w != kRefEmpty);
+    const bool h1 = slabTest(gridLo(c1.x, c1.y), gridHi(c1.y, c1.z), t.oi, t.inv, t.tnear, t.hit.t, k1) & (c1.w != kRefEmpty);
+    const bool h2 = slabTest(gridLo(c2.x, c2.y), gridHi(c2.y, c2.z), t.oi, t.inv, t.tnear, t.hit.t, k2) & (c2.w != kRefEmpty);
+    const bool h3 = slabTest(gridLo(c3.x, c3.y), gridHi(c3.y, c3.z), t.oi, t.inv, t.tnear, t.hit.t, k3) & (c3.w != kRefEmpty);
+    k0 = h0 ? k0 : INFINITY;
+    k1 = h1 ? k1 : INFINITY;
+    k2 = h2 ? k2 : INFINITY;
+    k3 = h3 ? k3 : INFINITY;
+    uint32_t r0 = c0.w, r1 = c1.w, r2 = c2.w, r3 = c3.w;
+    if (COUNT) ++cnt.nodes;
+    t.leafPos = 0u;
+    auto exchange = [](float& ka, uint32_t& ra, float& kb, uint32_t& rb) {
+        const bool swap = kb < ka;
+        const float kLo = swap ? kb : ka, kHi = swap ? ka : kb;
+        const uint32_t rLo = swap ? rb : ra, rHi = swap ? ra : rb;
+        ka = kLo;
+        kb = kHi;
+        ra = rLo;
+        rb = rHi;
+    };
+    exchange(k0, r0, k1, r1);
+    exchange(k2, r2, k3, r3);
+    exchange(k0, r0, k2, r2);
+    exchange(k1, r1, k3, r3);
+    exchange(k1, r1, k2, r2);
+    if (k3 < INFINITY) stack.push(r3);
+    if (k2 < INFINITY) stack.push(r2);
+    if (k1 < INFINITY) stack.push(r1);
+    if (k0 < INFINITY) {
+        t.cur = r0;
+        return true;
+    }
+    return travPop(t, stack);
+}
+
 // Node step (t.cur is an internal node).  Returns false once the ray is finished.
 template <bool COUNT, int NODES = -1>
 __device__ __forceinline__ bool travNodeStep(const SceneView& sc, const SceneMem& mem, Trav& t, LaneStack& stack, TraceCounters& cnt) {
+    if (NODES == 2) return travWideStep<COUNT>(mem, t, stack, cnt);
     uint32_t ref0, ref1;
     float e0, e1;
     bool h0, h1;

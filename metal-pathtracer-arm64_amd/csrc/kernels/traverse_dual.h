@@ -57,7 +57,7 @@ __device__ __forceinline__ void swapRays(RayRegs& a, RayRegs& b) {
 }
 
 // Stack of the ray being stepped: lds[(level * 2 + column) * kTraceBlock + lane]; levels >= kDualLdsLevels live in a
-// lane-interleaved HBM area (the builder bounds tree depth below kTraversalStackDepth, so it cannot overflow).
+// lane-interleaved HBM area (the builder bounds the tree depth, so it cannot overflow).
 struct DualStack {
     LdsWord* lds;         // &ldsStack[threadIdx.x]
     uint32_t* spill;      // spill area of this launch

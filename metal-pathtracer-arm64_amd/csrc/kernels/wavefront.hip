@@ -521,7 +521,10 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams rp, PathPool pool
 // =====================================================================================================
 // 8 waves/SIMD: the step loop with its repeated steps wants 66-68 VGPRs; holding it at 64 costs no spill in the loop
 // and is 4 % faster than 7 waves
-#define PTR_EXTEND_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#ifndef PTR_TRAV_WAVES   // waves per SIMD the traversal kernels are compiled for (8: at most 64 VGPRs)
+#define PTR_TRAV_WAVES 8
+#endif
+#define PTR_EXTEND_ATTR __attribute__((amdgpu_waves_per_eu(PTR_TRAV_WAVES, PTR_TRAV_WAVES)))
 template <bool COUNT, bool ALIVE, int NODES>
 __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride, uint32_t* workCounter,
                                                          int kRefillBelow, uint32_t feederChunk, uint32_t* aliveOut) {
@@ -1695,7 +1698,7 @@ __device__ f3 mneeChain(const RenderParams& rp, const SceneView& sc, const Clamp
 }  // namespace
 
 template <bool COUNT, int NODES>
-__global__ void __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) k_connect(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride,
+__global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_connect(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride,
                                                           uint32_t* workCounter, int kRefillBelow, uint32_t feederChunk) {
     __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
     LaneStack stack;
@@ -2316,6 +2319,8 @@ void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig&
     // counting build keeps the run-time flag
     if (count) {
         if (aliveOut) launch(k_extend<true, true, -1>); else launch(k_extend<true, false, -1>);
+    } else if (sc.useQuantized && sc.useWide) {
+        if (aliveOut) launch(k_extend<false, true, 2>); else launch(k_extend<false, false, 2>);
     } else if (sc.useQuantized) {
         if (aliveOut) launch(k_extend<false, true, 1>); else launch(k_extend<false, false, 1>);
     } else {
@@ -2362,6 +2367,8 @@ void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& 
         };
         if (count) {
             launch(k_connect<true, -1>);
+        } else if (sc.useQuantized && sc.useWide) {
+            launch(k_connect<false, 2>);
         } else if (sc.useQuantized) {
             launch(k_connect<false, 1>);
         } else {

@@ -526,7 +526,8 @@ def test_scheduling_knobs_do_not_change_the_image():
     base, base_counts = render({})
     assert np.isfinite(base).all() and base.mean() > 0.01 and base_counts[4] == 1920 * 1080 * 12
     for env in ({"PTR_CONNECT_LIST": "0"}, {"PTR_BUSY_LISTS": "0"}, {"PTR_POOL_GROUPS": "1"}, {"PTR_TRACE_BLOCKS_PER_CU": "8"},
-                {"PTR_TAIL_BELOW": "0"}, {"PTR_POOL_SLOTS": str(3 << 20), "PTR_REFILL_BELOW": "24"}):
+                {"PTR_TAIL_BELOW": "0"}, {"PTR_POOL_SLOTS": str(3 << 20), "PTR_REFILL_BELOW": "24"},
+                {"PTR_WIDE_NODES": "0"}):   # the binary walk instead of the four-wide nodes (same tree, one level at a time)
         image, counts = render(env)
         assert np.array_equal(image, base), env
         assert counts == base_counts, env
