@@ -136,7 +136,7 @@ struct PtrDeviceScene {
     // end of the frame: once the item queue is dry and at most this many slots are still alive, the remaining paths are finished by
     // k_tail_run (one lane per path, no launches between bounces) instead of further extend / shade / connect rounds; 0 = never
     uint64_t tailBelow = 512ull << 10;
-    uint64_t poolSlots = 16ull << 20;
+    uint64_t poolSlots = 32ull << 20;        // resident path slots at most (PTR_POOL_SLOTS)
     uint32_t poolGroups = 4;   // the pool is split into this many independent groups, one HIP stream each
     uint32_t feederChunk = 256, feederChunkSparse = 0;   // slots per work-head claim: full pool / mostly dead pool (0: slots per resident wave)
     std::vector<hipStream_t> groupStreams;   // streams of groups 1.. (group 0 runs on the caller's stream)
@@ -694,6 +694,9 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
     rp.itemCount = static_cast<uint32_t>(itemCount64);
     // enough to keep every CU's wave slots full several times over - but never more than half the work items: a pool as
     // large as the frame is all ramp-up and drain (config 1, 16.8 M samples: 16 Mi slots 16.2 ms, 8 Mi slots 10.0 ms)
+    // (32 Mi slots at most: a larger pool gives every launch more rays before its tail - config 2 +4.5 %, config 4 +2 %, config 5 +8 %
+    // against 16 Mi - and since the lists made the end of the frame cheap it costs the partitions of a multi-GPU frame nothing:
+    // one rank of eight 38.2 ms at 16 Mi, 38.4 ms at 32 Mi; profiles/r2_ab_grid_pool_knobs.txt)
     const uint64_t targetSlots = std::min<uint64_t>(ds.poolSlots, std::max<uint64_t>(1ull << 20, itemCount64 / 2u));
     uint32_t slots = static_cast<uint32_t>(std::min<uint64_t>(targetSlots, itemCount64));
     if (slots < itemCount64) slots &= ~255u;   // item ranges start right after the pre-assigned items: keep them 64-aligned
