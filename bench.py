@@ -265,11 +265,12 @@ def main():
                               "no PMC record for this command line",
             "avg_launch_ms": solo["avg_launch_ms"] if solo else None,
             "peak_measured": round(stream_gbs, 1),
-            "note": "HBM is NOT what bounds this kernel on this workload: the 9 MB scene is served by L1 / L2 / Infinity Cache and HBM only "
-                    "carries the ray-state stream; the binding resource is VALU issue at partial lane occupancy (`valu`).  `algorithmic` "
-                    "is SURVEY.md section 8(d)'s reference-layout figure (64 B per node visit, 68 B per primitive test) over the same "
-                    "launches - an effective, cache-served rate that can exceed the HBM peak; `hbm_resident_scene` is the same kernel "
-                    "on BASELINE configs[4], whose 0.5 GB of nodes and 1.4 GB of triangles do come from HBM.",
+            "note": "HBM is NOT what bounds this kernel on this workload: the scene (a few MB of four-wide nodes and triangles) is served by "
+                    "L1 / L2 / Infinity Cache and HBM only carries the ray-state stream; the binding resource is VALU issue at partial lane "
+                    "occupancy (`valu`).  `algorithmic` is SURVEY.md section 8(d)'s reference-layout figure (64 B per binary node visit, "
+                    "68 B per primitive test, counted by the counting build on the binary tree) over the same launches - an effective, "
+                    "cache-served rate that can exceed the HBM peak; `hbm_resident_scene` is the same kernel on BASELINE configs[4], whose "
+                    "1 GB of four-wide nodes and 1.4 GB of triangles do come from HBM.",
             "algorithmic": {
                 "bytes_per_launch": solo["alg_bytes_per_launch"] if solo else None,
                 "achieved": solo["achieved"] if solo else None,
