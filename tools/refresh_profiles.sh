@@ -30,7 +30,7 @@ configs)
   tail -5 gpurun_out/full_configs_$TAG.log
   ;;
 rest)
-  POOLS=16777216 timeout -k 10 200 python tools/strong_scaling_probe.py 2>&1 | grep pool > gpurun_out/strong_probe_$TAG.log
+  POOLS=0 timeout -k 10 200 python tools/strong_scaling_probe.py 2>&1 | grep pool > gpurun_out/strong_probe_$TAG.log
   cat gpurun_out/strong_probe_$TAG.log
   python3 -c "
 from scenes.gen_assets import ensure_assets, ensure_large_asset
