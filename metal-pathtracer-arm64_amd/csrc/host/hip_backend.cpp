@@ -377,23 +377,41 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     std::memcpy(v.gridCell, bvh.gridCell, sizeof(v.gridCell));
     for (int a = 0; a < 3; ++a) v.gridInvCell[a] = 1.0f / bvh.gridCell[a];
     v.useQuantized = useQuantized ? 1u : 0u;
-    bool useWide = useQuantized && static_cast<uint64_t>(bvh.nodeCount) * 64u <= 0xFFFFFFFFull;
+    bool useWide = useQuantized && bvh.nodeCount > 0;
     if (const char* e = std::getenv("PTR_WIDE_NODES")) useWide = useWide && std::atoi(e) != 0;   // A/B knob
     if (useWide) {
-        // Four-wide nodes for the persistent traversal kernels: every second level of the binary tree is collapsed.  Wide node j =
-        // the 16 B child records of binary node j's children's children (a child that is a leaf keeps its own record), stored at
-        // index j so that the child references stay valid - half the wide nodes are never visited, which costs memory (64 B per binary
-        // node beside the 32 B binary array that the cold kernels and the counting build keep walking) but no renumbering.
-        std::unique_ptr<uint32_t[]> wide(new uint32_t[static_cast<size_t>(bvh.nodeCount) * 16u]);
+        // Four-wide nodes for the persistent traversal kernels: every second level of the binary tree is collapsed.  A wide node holds
+        // the 16 B child records of a binary node's children's children (a child that is a leaf keeps its own record).  Only the
+        // binary nodes at even depth become wide nodes; they are numbered in the order of their binary (preorder) indices, so the
+        // wide array is half as long as the binary one, its nodes lie back to back (a 128 B cache line holds two nodes that are
+        // both walked) and subtrees stay contiguous.  The binary array stays for the cold kernels and the counting build.
         const uint32_t* q = bvh.qnodes.data();
         const uint32_t nodeCount = bvh.nodeCount;
+        constexpr uint32_t kNotWide = 0xFFFFFFFFu;
+        // depth parity: a parent precedes its children in preorder, so one forward pass settles it
+        std::unique_ptr<uint32_t[]> wideIndex(new uint32_t[nodeCount]);
+        std::vector<uint8_t> odd(nodeCount, 0);
+        for (uint32_t n = 0; n < nodeCount; ++n) {
+            for (uint32_t side = 0; side < 2u; ++side) {
+                const uint32_t ref = q[static_cast<size_t>(n) * 8u + side * 4u + 3u];
+                if (ref != ptrk::kRefEmpty && !(ref & ptrk::kRefLeafBit) && ref < nodeCount) odd[ref] = odd[n] ^ 1u;
+            }
+        }
+        if (const char* e = std::getenv("PTR_WIDE_COMPACT")) {   // A/B knob: 0 = a wide node for every binary node, at the same index
+            if (std::atoi(e) == 0) std::fill(odd.begin(), odd.end(), static_cast<uint8_t>(0));
+        }
+        uint32_t wideCount = 0;
+        for (uint32_t n = 0; n < nodeCount; ++n) wideIndex[n] = odd[n] ? kNotWide : wideCount++;
+        if (static_cast<uint64_t>(wideCount) * 64u > 0xFFFFFFFFull) throw HipError{"scene exceeds the 4 GiB node array limit"};
+        std::unique_ptr<uint32_t[]> wide(new uint32_t[static_cast<size_t>(wideCount) * 16u]);
         const uint32_t workers = nodeCount >= (1u << 16) ? std::min(32u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
         auto collapse = [&](uint32_t begin, uint32_t end) {
-            for (uint32_t j = begin; j < end; ++j) {
-                uint32_t* w = wide.get() + static_cast<size_t>(j) * 16u;
+            for (uint32_t n = begin; n < end; ++n) {
+                if (wideIndex[n] == kNotWide) continue;
+                uint32_t* w = wide.get() + static_cast<size_t>(wideIndex[n]) * 16u;
                 uint32_t filled = 0;
                 for (uint32_t side = 0; side < 2u; ++side) {
-                    const uint32_t* rec = q + static_cast<size_t>(j) * 8u + side * 4u;
+                    const uint32_t* rec = q + static_cast<size_t>(n) * 8u + side * 4u;
                     const uint32_t ref = rec[3];
                     if (ref == ptrk::kRefEmpty) continue;
                     if (ref & ptrk::kRefLeafBit) {
@@ -401,7 +419,10 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
                     } else {
                         for (uint32_t g = 0; g < 2u; ++g) {
                             const uint32_t* grand = q + static_cast<size_t>(ref) * 8u + g * 4u;
-                            if (grand[3] != ptrk::kRefEmpty) std::memcpy(w + 4u * filled++, grand, 16);
+                            if (grand[3] == ptrk::kRefEmpty) continue;
+                            uint32_t* dst = w + 4u * filled++;
+                            std::memcpy(dst, grand, 16);
+                            if (!(grand[3] & ptrk::kRefLeafBit)) dst[3] = wideIndex[grand[3]];   // an internal grandchild: its wide node
                         }
                     }
                 }
@@ -418,9 +439,9 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
         }
         collapse(0u, std::min(nodeCount, chunk));
         for (auto& th : pool) th.join();
-        ds.wnodes.upload(reinterpret_cast<const uint4*>(wide.get()), static_cast<size_t>(nodeCount) * 4u);
+        ds.wnodes.upload(reinterpret_cast<const uint4*>(wide.get()), static_cast<size_t>(wideCount) * 4u);
         v.wnodes = ds.wnodes.ptr;
-        v.wideBytes = static_cast<uint32_t>(static_cast<size_t>(nodeCount) * 64u);
+        v.wideBytes = static_cast<uint32_t>(static_cast<size_t>(wideCount) * 64u);
         v.useWide = 1u;
     }
     const size_t nodeBytes = v.useQuantized ? bvh.qnodes.size() * 4u : bvh.nodes.size() * 4u;
