@@ -51,7 +51,8 @@ int ptr_debug_env_distribution(const float* rgba, uint32_t w, uint32_t h, float*
  * out[0..15]: nodes, leaves, triangles referenced, spheres referenced, max depth, max leaf size, unreferenced
  * primitives, multiply referenced primitives, box containment violations, quantised-box violations, bad child
  * references, triangle count, sphere count, SAH cost * 1000, build milliseconds (gather+build+flatten), quantised
- * nodes usable (grid fine enough; bits 8..: triangles kept out of the tree so that it is).  leaf_max = 0 uses the default.  Returns non-zero with a message on bad input. */
+ * nodes usable (grid fine enough; bits 8..15: triangles kept out of the tree so that it is; bits 16..47: four-wide nodes of the
+ * persistent kernels; bit 63: those nodes have a bad reference or do not reach every primitive exactly once).  leaf_max = 0 uses the default.  Returns non-zero with a message on bad input. */
 int ptr_debug_scene_geometry(const PtrSceneDesc* scene, uint32_t leaf_max, uint64_t out[16], char* err, size_t err_cap);
 
 #ifdef __cplusplus

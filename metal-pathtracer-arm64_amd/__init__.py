@@ -605,6 +605,9 @@ def debug_scene_geometry(desc: PtrSceneDesc, leaf_max: int = 0) -> dict:
     err = _err_buf()
     _check(load_library().ptr_debug_scene_geometry(C.byref(desc), leaf_max, out, err, len(err)), err)
     g = dict(zip(GEOMETRY_FIELDS, [int(v) for v in out]))
-    g["oversize"] = g["quantized_usable"] >> 8          # triangles kept out of the tree (tested first by every ray)
-    g["quantized_usable"] &= 0xFF
+    word = g["quantized_usable"]
+    g["oversize"] = (word >> 8) & 0xFF                   # triangles kept out of the tree (tested first by every ray)
+    g["wide_nodes"] = (word >> 16) & 0xFFFFFFFF          # four-wide nodes of the persistent traversal kernels
+    g["wide_problems"] = word >> 63                      # bad references / primitives not reached exactly once through them
+    g["quantized_usable"] = word & 0xFF
     return g

@@ -871,4 +871,61 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
     lap("quantise");
 }
 
+uint32_t BuildWideNodes(const FlatBvh& bvh, bool compact, std::unique_ptr<uint32_t[]>& wide) {
+    const uint32_t* q = bvh.qnodes.data();
+    const uint32_t nodeCount = bvh.nodeCount;
+    constexpr uint32_t kNotWide = 0xFFFFFFFFu;
+    if (nodeCount == 0 || bvh.qnodes.size() < static_cast<size_t>(nodeCount) * 8u) return 0;
+    // depth parity: a parent precedes its children in preorder, so one forward pass settles it
+    std::unique_ptr<uint32_t[]> wideIndex(new uint32_t[nodeCount]);
+    std::vector<uint8_t> odd(nodeCount, 0);
+    if (compact) {
+        for (uint32_t n = 0; n < nodeCount; ++n) {
+            for (uint32_t side = 0; side < 2u; ++side) {
+                const uint32_t ref = q[static_cast<size_t>(n) * 8u + side * 4u + 3u];
+                if (ref != ptrk::kRefEmpty && !(ref & ptrk::kRefLeafBit) && ref < nodeCount) odd[ref] = odd[n] ^ 1u;
+            }
+        }
+    }
+    uint32_t wideCount = 0;
+    for (uint32_t n = 0; n < nodeCount; ++n) wideIndex[n] = odd[n] ? kNotWide : wideCount++;
+    wide.reset(new uint32_t[static_cast<size_t>(wideCount) * 16u]);
+    const uint32_t workers = nodeCount >= (1u << 16) ? std::min(32u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    auto collapse = [&](uint32_t begin, uint32_t end) {
+        for (uint32_t n = begin; n < end; ++n) {
+            if (wideIndex[n] == kNotWide) continue;
+            uint32_t* w = wide.get() + static_cast<size_t>(wideIndex[n]) * 16u;
+            uint32_t filled = 0;
+            for (uint32_t side = 0; side < 2u; ++side) {
+                const uint32_t* rec = q + static_cast<size_t>(n) * 8u + side * 4u;
+                const uint32_t ref = rec[3];
+                if (ref == ptrk::kRefEmpty) continue;
+                if ((ref & ptrk::kRefLeafBit) || ref >= nodeCount) {
+                    std::memcpy(w + 4u * filled++, rec, 16);
+                } else {
+                    for (uint32_t g = 0; g < 2u; ++g) {
+                        const uint32_t* grand = q + static_cast<size_t>(ref) * 8u + g * 4u;
+                        if (grand[3] == ptrk::kRefEmpty) continue;
+                        uint32_t* dst = w + 4u * filled++;
+                        std::memcpy(dst, grand, 16);
+                        if (!(grand[3] & ptrk::kRefLeafBit) && grand[3] < nodeCount) dst[3] = wideIndex[grand[3]];   // its wide node
+                    }
+                }
+            }
+            for (; filled < 4u; ++filled) {
+                for (uint32_t k = 0; k < 4u; ++k) w[4u * filled + k] = ptrk::kRefEmpty;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    const uint32_t chunk = (nodeCount + workers - 1u) / workers;
+    for (uint32_t k = 1; k < workers; ++k) {
+        const uint32_t b = std::min(nodeCount, chunk * k), e = std::min(nodeCount, chunk * (k + 1u));
+        if (b < e) pool.emplace_back(collapse, b, e);
+    }
+    collapse(0u, std::min(nodeCount, chunk));
+    for (auto& th : pool) th.join();
+    return wideCount;
+}
+
 }  // namespace ptr

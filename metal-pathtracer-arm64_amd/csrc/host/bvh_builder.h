@@ -12,6 +12,7 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 namespace ptr {
@@ -41,5 +42,12 @@ struct FlatBvh {
 // prims: triangles and spheres mixed (isSphere flag); indices in triOrder/sphereOrder refer to the n-th
 // triangle / n-th sphere of the input in input order.
 void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t threads = 0, uint32_t leafMax = 4);
+
+// Four-wide nodes for the persistent traversal kernels (kernels/traverse.h travWideStep): every second level of the binary tree is
+// collapsed.  A wide node is 16 words: the 16 B child records (quantised box + reference, as in FlatBvh::qnodes) of a binary node's
+// children's children - a child that is a leaf keeps its own record, unused places are kRefEmpty.  compact: only the binary nodes at
+// even depth become wide nodes, numbered in the order of their binary (preorder) indices, internal references renumbered to match;
+// otherwise every binary node gets a wide node at its own index.  Returns the number of wide nodes.
+uint32_t BuildWideNodes(const FlatBvh& bvh, bool compact, std::unique_ptr<uint32_t[]>& wide);
 
 }  // namespace ptr

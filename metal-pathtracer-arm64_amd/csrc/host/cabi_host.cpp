@@ -251,7 +251,8 @@ int ptr_debug_scene_geometry(const PtrSceneDesc* scene, uint32_t leaf_max, uint6
                                    c.unreferenced, c.multiplyReferenced, c.boxViolations, c.quantViolations, c.badRefs,
                                    geo.triCount, geo.sphereCount, static_cast<uint64_t>(geo.bvh.sahCost * 1000.0),
                                    static_cast<uint64_t>((geo.gatherSeconds + geo.buildSeconds + geo.flattenSeconds) * 1000.0),
-                                   ((geo.bvh.nodeCount > 0 && maxCell * 8.0f <= geo.bvh.meanPrimExtent) ? 1u : 0u) | (c.oversize << 8)};
+                                   ((geo.bvh.nodeCount > 0 && maxCell * 8.0f <= geo.bvh.meanPrimExtent) ? 1u : 0u) | (c.oversize << 8) |
+                                       (std::min<uint64_t>(c.wideNodes, 0xFFFFFFFFull) << 16) | (c.wideProblems ? 1ull << 63 : 0ull)};
         std::memcpy(out, vals, sizeof(vals));
         return 0;
     });

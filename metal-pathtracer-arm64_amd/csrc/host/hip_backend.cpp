@@ -380,65 +380,13 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     bool useWide = useQuantized && bvh.nodeCount > 0;
     if (const char* e = std::getenv("PTR_WIDE_NODES")) useWide = useWide && std::atoi(e) != 0;   // A/B knob
     if (useWide) {
-        // Four-wide nodes for the persistent traversal kernels: every second level of the binary tree is collapsed.  A wide node holds
-        // the 16 B child records of a binary node's children's children (a child that is a leaf keeps its own record).  Only the
-        // binary nodes at even depth become wide nodes; they are numbered in the order of their binary (preorder) indices, so the
-        // wide array is half as long as the binary one, its nodes lie back to back (a 128 B cache line holds two nodes that are
-        // both walked) and subtrees stay contiguous.  The binary array stays for the cold kernels and the counting build.
-        const uint32_t* q = bvh.qnodes.data();
-        const uint32_t nodeCount = bvh.nodeCount;
-        constexpr uint32_t kNotWide = 0xFFFFFFFFu;
-        // depth parity: a parent precedes its children in preorder, so one forward pass settles it
-        std::unique_ptr<uint32_t[]> wideIndex(new uint32_t[nodeCount]);
-        std::vector<uint8_t> odd(nodeCount, 0);
-        for (uint32_t n = 0; n < nodeCount; ++n) {
-            for (uint32_t side = 0; side < 2u; ++side) {
-                const uint32_t ref = q[static_cast<size_t>(n) * 8u + side * 4u + 3u];
-                if (ref != ptrk::kRefEmpty && !(ref & ptrk::kRefLeafBit) && ref < nodeCount) odd[ref] = odd[n] ^ 1u;
-            }
-        }
-        if (const char* e = std::getenv("PTR_WIDE_COMPACT")) {   // A/B knob: 0 = a wide node for every binary node, at the same index
-            if (std::atoi(e) == 0) std::fill(odd.begin(), odd.end(), static_cast<uint8_t>(0));
-        }
-        uint32_t wideCount = 0;
-        for (uint32_t n = 0; n < nodeCount; ++n) wideIndex[n] = odd[n] ? kNotWide : wideCount++;
+        // four-wide nodes for the persistent traversal kernels (bvh_builder.h BuildWideNodes); the binary array stays for the cold
+        // kernels and the counting build
+        bool compact = true;
+        if (const char* e = std::getenv("PTR_WIDE_COMPACT")) compact = std::atoi(e) != 0;   // A/B knob
+        std::unique_ptr<uint32_t[]> wide;
+        const uint32_t wideCount = ptr::BuildWideNodes(bvh, compact, wide);
         if (static_cast<uint64_t>(wideCount) * 64u > 0xFFFFFFFFull) throw HipError{"scene exceeds the 4 GiB node array limit"};
-        std::unique_ptr<uint32_t[]> wide(new uint32_t[static_cast<size_t>(wideCount) * 16u]);
-        const uint32_t workers = nodeCount >= (1u << 16) ? std::min(32u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-        auto collapse = [&](uint32_t begin, uint32_t end) {
-            for (uint32_t n = begin; n < end; ++n) {
-                if (wideIndex[n] == kNotWide) continue;
-                uint32_t* w = wide.get() + static_cast<size_t>(wideIndex[n]) * 16u;
-                uint32_t filled = 0;
-                for (uint32_t side = 0; side < 2u; ++side) {
-                    const uint32_t* rec = q + static_cast<size_t>(n) * 8u + side * 4u;
-                    const uint32_t ref = rec[3];
-                    if (ref == ptrk::kRefEmpty) continue;
-                    if (ref & ptrk::kRefLeafBit) {
-                        std::memcpy(w + 4u * filled++, rec, 16);
-                    } else {
-                        for (uint32_t g = 0; g < 2u; ++g) {
-                            const uint32_t* grand = q + static_cast<size_t>(ref) * 8u + g * 4u;
-                            if (grand[3] == ptrk::kRefEmpty) continue;
-                            uint32_t* dst = w + 4u * filled++;
-                            std::memcpy(dst, grand, 16);
-                            if (!(grand[3] & ptrk::kRefLeafBit)) dst[3] = wideIndex[grand[3]];   // an internal grandchild: its wide node
-                        }
-                    }
-                }
-                for (; filled < 4u; ++filled) {
-                    for (uint32_t k = 0; k < 4u; ++k) w[4u * filled + k] = ptrk::kRefEmpty;
-                }
-            }
-        };
-        std::vector<std::thread> pool;
-        const uint32_t chunk = (nodeCount + workers - 1u) / workers;
-        for (uint32_t k = 1; k < workers; ++k) {
-            const uint32_t b = std::min(nodeCount, chunk * k), e2 = std::min(nodeCount, chunk * (k + 1u));
-            if (b < e2) pool.emplace_back(collapse, b, e2);
-        }
-        collapse(0u, std::min(nodeCount, chunk));
-        for (auto& th : pool) th.join();
         ds.wnodes.upload(reinterpret_cast<const uint4*>(wide.get()), static_cast<size_t>(wideCount) * 4u);
         v.wnodes = ds.wnodes.ptr;
         v.wideBytes = static_cast<uint32_t>(static_cast<size_t>(wideCount) * 64u);

@@ -439,6 +439,42 @@ void ValidateSceneGeometry(const SceneGeometry& g, GeometryCheck& out) {
     }
     for (uint8_t s : triSeen) out.unreferenced += (s == 0);
     for (uint8_t s : sphSeen) out.unreferenced += (s == 0);
+
+    // the four-wide nodes of the persistent kernels: walked from the root, every primitive of the tree must turn up exactly once
+    if (nodeCount > 0 && !bvh.qnodes.empty()) {
+        std::unique_ptr<uint32_t[]> wide;
+        const uint32_t wideCount = BuildWideNodes(bvh, true, wide);
+        out.wideNodes = wideCount;
+        std::vector<uint8_t> triWide(g.triCount, 0), sphWide(g.sphereCount, 0), visited(wideCount, 0);
+        std::vector<uint32_t> stack{0u};
+        while (!stack.empty()) {
+            const uint32_t n = stack.back();
+            stack.pop_back();
+            if (n >= wideCount || visited[n]++) {
+                out.wideProblems += 1;
+                continue;
+            }
+            for (uint32_t c = 0; c < 4u; ++c) {
+                const uint32_t ref = wide[static_cast<size_t>(n) * 16u + c * 4u + 3u];
+                if (ref == ptrk::kRefEmpty) continue;
+                if (!(ref & ptrk::kRefLeafBit)) {
+                    stack.push_back(ref);
+                    continue;
+                }
+                const uint32_t first = ref & ptrk::kRefOffsetMask, count = ((ref >> ptrk::kRefCountShift) & 0xFu) + 1u;
+                std::vector<uint8_t>& seen = (ref & ptrk::kRefSphereBit) ? sphWide : triWide;
+                for (uint32_t i = first; i < first + count; ++i) {
+                    if (i >= seen.size() || seen[i]++) out.wideProblems += 1;
+                }
+            }
+        }
+        for (uint32_t n = 0; n < wideCount; ++n) out.wideProblems += (visited[n] == 0);
+        const uint32_t outside = bvh.oversizeRef != ptrk::kRefEmpty ? ((bvh.oversizeRef >> ptrk::kRefCountShift) & 0xFu) + 1u : 0u;
+        uint64_t missed = 0;
+        for (uint8_t s : triWide) missed += (s == 0);
+        for (uint8_t s : sphWide) missed += (s == 0);
+        if (missed != outside) out.wideProblems += 1 + (missed > outside ? missed - outside : outside - missed);
+    }
 }
 
 }  // namespace ptr

@@ -42,6 +42,8 @@ struct GeometryCheck {
     uint64_t quantViolations = 0;     // float child boxes sticking out of their quantised twin
     uint64_t badRefs = 0;             // child references pointing outside the arrays / cycles
     uint64_t oversize = 0;            // triangles kept out of the tree (FlatBvh::oversizeRef)
+    uint64_t wideNodes = 0;           // four-wide nodes (BuildWideNodes, compact)
+    uint64_t wideProblems = 0;        // bad references in them + primitives not reached exactly once through them
 };
 
 // Walks the flattened tree from the root and checks the invariants the device traversal relies on.

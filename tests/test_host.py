@@ -356,7 +356,10 @@ def _geometry_ok(g, tris, spheres):
     assert g["triangles_referenced"] == tris and g["spheres_referenced"] == spheres
     assert g["unreferenced"] == 0 and g["multiply_referenced"] == 0 and g["bad_refs"] == 0
     assert g["box_violations"] == 0 and g["quant_violations"] == 0
-    assert g["max_depth"] < 48          # kTraversalStackDepth: the traversal stack can never overflow
+    assert g["max_depth"] < 48          # kMaxTreeDepth: the traversal stacks (76 entries) can never overflow
+    # the four-wide nodes of the persistent kernels: every second level collapsed, every primitive reached exactly once
+    assert g["wide_problems"] == 0
+    assert g["wide_nodes"] <= g["nodes"] and (g["nodes"] == 0 or g["wide_nodes"] >= 1)
 
 
 @pytest.mark.parametrize("leaf_max", [1, 2, 4, 8])
