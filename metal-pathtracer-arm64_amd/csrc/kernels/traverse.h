@@ -196,8 +196,8 @@ struct Trav {
 #ifndef PTR_POSTPONE_LEAVES
 #define PTR_POSTPONE_LEAVES 0
 #endif
-// (binary node steps only: build the variant with PTR_WIDE_NODES=0 in the environment.  On top of the four-wide nodes it measured +1 %
-// on config 2 and nothing elsewhere, profiles/r2_ab_postponed_leaves.txt, and was not kept.)
+// (binary node steps only: a build with this switch launches the two-box kernels.  On top of the four-wide nodes it measured +1 % on
+// config 2 and nothing elsewhere, profiles/r2_ab_postponed_leaves.txt, and was not kept.)
 
 // NODES: 1 = 32 B quantised nodes, 0 = 64 B float nodes (compile-time choice of the persistent kernels), -1 = decided by the scene's
 // flag at run time (the cold kernels: ray-batch queries, feature buffers, chains, the end-of-frame kernel)

@@ -2319,7 +2319,7 @@ void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig&
     // counting build keeps the run-time flag
     if (count) {
         if (aliveOut) launch(k_extend<true, true, -1>); else launch(k_extend<true, false, -1>);
-    } else if (sc.useQuantized && sc.useWide) {
+    } else if (sc.useQuantized && sc.useWide && !PTR_POSTPONE_LEAVES) {   // (the postponed-leaf variant knows the binary step only)
         if (aliveOut) launch(k_extend<false, true, 2>); else launch(k_extend<false, false, 2>);
     } else if (sc.useQuantized) {
         if (aliveOut) launch(k_extend<false, true, 1>); else launch(k_extend<false, false, 1>);
@@ -2367,7 +2367,7 @@ void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& 
         };
         if (count) {
             launch(k_connect<true, -1>);
-        } else if (sc.useQuantized && sc.useWide) {
+        } else if (sc.useQuantized && sc.useWide && !PTR_POSTPONE_LEAVES) {
             launch(k_connect<false, 2>);
         } else if (sc.useQuantized) {
             launch(k_connect<false, 1>);
