@@ -11,9 +11,11 @@
 #include <memory>
 #include <numeric>
 #include <thread>
-#include <unordered_map>
+#include <stdexcept>
 
 #include "../kernels/bvh_layout.h"
+#include "knobs.h"
+#include "parallel.h"
 
 namespace ptr {
 namespace {
@@ -48,8 +50,15 @@ struct Aabb {
 template <typename T>
 struct RawArray {
     std::unique_ptr<T[]> items;
-    void allocate(size_t n) { items.reset(new T[n]); }
-    void release() { items.reset(); }
+    size_t capacity = 0;
+    void allocate(size_t n) {
+        items.reset(new T[n]);
+        capacity = n;
+    }
+    void release() {
+        items.reset();
+        capacity = 0;
+    }
     T& operator[](size_t i) { return items[i]; }
     const T& operator[](size_t i) const { return items[i]; }
     T* data() { return items.get(); }
@@ -118,13 +127,10 @@ struct Builder {
     void forChunks(uint32_t begin, uint32_t end, Fn&& fn) const {   // fn(chunkIndex, chunkBegin, chunkEnd)
         const uint32_t t = std::max(1u, std::min(wideThreads, (end - begin) >> 16));
         const uint32_t chunk = (end - begin + t - 1) / t;
-        std::vector<std::thread> pool;
-        for (uint32_t k = 1; k < t; ++k) {
+        runOnThreads(t, [&](uint32_t k) {
             const uint32_t b = std::min(end, begin + chunk * k), e = std::min(end, begin + chunk * (k + 1));
-            if (b < e) pool.emplace_back([&fn, k, b, e]() { fn(k, b, e); });
-        }
-        fn(0u, begin, std::min(end, begin + chunk));
-        for (auto& th : pool) th.join();
+            if (b < e || k == 0u) fn(k, b, e);
+        });
     }
 
     // What a node knows about its range before it looks at a single primitive: the parent computed it while partitioning.
@@ -470,33 +476,34 @@ struct Builder {
         std::vector<uint32_t> topNodes;
         const auto t0 = std::chrono::steady_clock::now();
         buildTop(0, 0, count, 0, measure(0, count), tasks, topNodes);
-        if (std::getenv("PTR_BUILD_VERBOSE")) {
+        if (verbose) {
             std::fprintf(stderr, "[bvh] top of the tree: %zu nodes, %zu subtrees left, %.2f s\n", topNodes.size(), tasks.size(),
                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         }
         std::sort(tasks.begin(), tasks.end(), [](const Task& a, const Task& b) { return (a.end - a.begin) > (b.end - b.begin); });
-        uint32_t firstFree = nextNode.load();
+        // A subtree over c primitives has at most 2 c - 1 nodes and its root already exists (its parent allocated it): it takes
+        // exactly 2 c - 2 from a block of its own.  With T serial top splits (1 + 2 T nodes, T + 1 subtrees) the whole tree is
+        // 1 + 2 T + 2 n - 2 (T + 1) = 2 n - 1 nodes whatever the shape of the top.
+        uint64_t firstFree = nextNode.load();
         for (Task& t : tasks) {
-            t.firstNode = firstFree;
-            firstFree += 2u * (t.end - t.begin);
+            t.firstNode = static_cast<uint32_t>(firstFree);
+            firstFree += 2ull * (t.end - t.begin) - 2ull;
         }
+        if (firstFree > nodes.capacity) throw std::runtime_error("BVH builder: node pool too small for the task blocks");
         std::atomic<size_t> next{0};
-        auto worker = [&]() {
+        const uint32_t workers = static_cast<uint32_t>(std::min<size_t>(std::max(poolThreads, 1u), tasks.size()));
+        runOnThreads(workers, [&](uint32_t) {
             while (true) {
                 const size_t t = next.fetch_add(1);
                 if (t >= tasks.size()) break;
-                uint32_t cursor = tasks[t].firstNode;   // a subtree over n primitives has fewer than 2 n nodes
+                uint32_t cursor = tasks[t].firstNode;
                 build(tasks[t].node, tasks[t].begin, tasks[t].end, tasks[t].depth, tasks[t].info, &cursor);
             }
-        };
-        const uint32_t workers = static_cast<uint32_t>(std::min<size_t>(std::max(poolThreads, 1u), tasks.size()));
-        std::vector<std::thread> pool;
-        for (uint32_t w = 1; w < workers; ++w) pool.emplace_back(worker);
-        worker();
-        for (auto& th : pool) th.join();
+        });
         for (uint32_t node : topNodes) sumChildren(node);
     }
     uint32_t poolThreads = 1;
+    bool verbose = false;
 };
 
 
@@ -504,9 +511,6 @@ struct Flattener {
     const Builder& b;
     FlatBvh& out;
     std::vector<uint32_t> primToTri, primToSphere;  // input index -> n-th triangle / sphere
-    // PTR_BFS_TOP=<n> (experiment: the top of the tree staged in LDS): the n internal nodes nearest the root get device indices
-    // 0 .. n-1 in breadth-first order, the subtrees below them contiguous preorder blocks after that.  temp node -> device index.
-    std::unordered_map<uint32_t, uint32_t> placed;
 
     struct Stats {
         double sahCost = 0.0;
@@ -552,14 +556,7 @@ struct Flattener {
         const TempNode& l = b.nodes[n.left];
         const uint32_t kids[2] = {n.left, n.right};
         const uint32_t triBase[2] = {it.triBase, it.triBase + l.triPrims}, sphereBase[2] = {it.sphereBase, it.sphereBase + l.spherePrims};
-        // preorder: the left subtree follows its parent, the right one follows the left subtree - unless the node was given a place
-        // of its own (breadth-first top of the tree, see run())
-        auto placeOf = [&](uint32_t temp, uint32_t preorder) {
-            if (placed.empty()) return preorder;
-            const auto found = placed.find(temp);
-            return found != placed.end() ? found->second : preorder;
-        };
-        const uint32_t device[2] = {placeOf(n.left, it.device + 1u), placeOf(n.right, it.device + 1u + l.internalNodes)};
+        const uint32_t device[2] = {it.device + 1u, it.device + 1u + l.internalNodes};
         Item next[2];
         bool internal[2] = {false, false};
         for (int s = 0; s < 2; ++s) {
@@ -598,32 +595,6 @@ struct Flattener {
         }
         out.nodeCount = root.internalNodes;
         out.nodes.assign(static_cast<size_t>(out.nodeCount) * 16, 0.0f);
-        if (const char* e = std::getenv("PTR_BFS_TOP")) {
-            const uint32_t want = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 0), 1 << 16));
-            if (want > 1u && root.internalNodes > want) {
-                std::vector<uint32_t> top{0u};
-                placed[0u] = 0u;
-                for (size_t head = 0; head < top.size() && top.size() < want; ++head) {
-                    const TempNode& n = b.nodes[top[head]];
-                    for (uint32_t kid : {n.left, n.right}) {
-                        if (b.nodes[kid].count == 0 && top.size() < want) {
-                            placed[kid] = static_cast<uint32_t>(top.size());
-                            top.push_back(kid);
-                        }
-                    }
-                }
-                uint32_t next = static_cast<uint32_t>(top.size());
-                for (uint32_t t : top) {
-                    const TempNode& n = b.nodes[t];
-                    for (uint32_t kid : {n.left, n.right}) {
-                        if (b.nodes[kid].count == 0 && placed.find(kid) == placed.end()) {
-                            placed[kid] = next;
-                            next += b.nodes[kid].internalNodes;
-                        }
-                    }
-                }
-            }
-        }
         // the top of the tree serially (breadth first, until there are a few subtrees per thread), the subtrees in parallel
         std::vector<Item> tasks{{0u, 0u, 0u, 0u, 0u}};
         const size_t wanted = out.nodeCount >= (1u << 16) ? static_cast<size_t>(std::max(threads, 1u)) * 4u : 1u;
@@ -640,7 +611,8 @@ struct Flattener {
         }
         std::vector<Stats> partial(tasks.size());
         std::atomic<size_t> nextTask{0};
-        auto worker = [&]() {
+        const uint32_t workers = tasks.size() > 1 ? std::min<uint32_t>(std::max(threads, 1u), static_cast<uint32_t>(tasks.size())) : 1u;
+        runOnThreads(workers, [&](uint32_t) {
             std::vector<Item> stack;
             while (true) {
                 const size_t t = nextTask.fetch_add(1);
@@ -652,12 +624,7 @@ struct Flattener {
                     emit(it, rootArea, partial[t], stack);
                 }
             }
-        };
-        const uint32_t workers = tasks.size() > 1 ? std::min<uint32_t>(std::max(threads, 1u), static_cast<uint32_t>(tasks.size())) : 1u;
-        std::vector<std::thread> pool;
-        for (uint32_t w = 1; w < workers; ++w) pool.emplace_back(worker);
-        worker();
-        for (auto& th : pool) th.join();
+        });
         for (const Stats& p : partial) {   // in task order: the floating-point sum does not depend on the thread schedule
             total.sahCost += p.sahCost;
             total.leafCount += p.leafCount;
@@ -688,7 +655,8 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
     constexpr uint32_t kMaxOversize = 16u;   // one leaf reference holds up to 16 primitives
     std::vector<uint8_t> oversize(n, 0);
     uint32_t oversizeCount = 0;
-    if (n > 64u && std::getenv("PTR_NO_OVERSIZE") == nullptr) {
+    const Knobs knobs = readKnobs();
+    if (n > 64u && !knobs.noOversize) {
         auto extentOf = [&](uint32_t i) { return std::max(std::max(prims[i].hi[0] - prims[i].lo[0], prims[i].hi[1] - prims[i].lo[1]), prims[i].hi[2] - prims[i].lo[2]); };
         // candidates: the kMaxOversize largest triangles, largest first
         std::vector<uint32_t> tris;
@@ -745,7 +713,7 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
     Builder b;
     b.kLeafMax = std::min(std::max(leafMax, 1u), ptrk::kMaxLeafPrims);
     if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
-    if (const char* e = std::getenv("PTR_BUILD_THREADS")) threads = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 256));   // test / tuning knob
+    if (knobs.buildThreads != 0u) threads = knobs.buildThreads;   // test knob
     b.wideThreads = std::min(threads, 64u);
     b.poolThreads = std::min(threads, 64u);
     const uint32_t inTree = n - oversizeCount;
@@ -773,9 +741,10 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
             }
         });
     }
-    b.nodes.allocate(static_cast<size_t>(2) * inTree + 2u * (inTree >> 16) + 64u);   // 2 n - 1 nodes, and the slack of the per-subtree blocks
+    b.nodes.allocate(static_cast<size_t>(2) * inTree + 2u);   // 2 n - 1 nodes exactly (see buildAll)
     if (inTree >= Builder::kTaskNode && b.wideThreads > 1) b.scratch.allocate(inTree);
-    const bool verbose = std::getenv("PTR_BUILD_VERBOSE") != nullptr;
+    const bool verbose = knobs.verboseBuild;
+    b.verbose = verbose;
     auto tick = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         const auto now = std::chrono::steady_clock::now();
@@ -854,13 +823,10 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
     {
         const uint32_t workers = out.nodeCount >= (1u << 16) ? std::min(threads, 32u) : 1u;
         const uint32_t chunk = (out.nodeCount + workers - 1) / workers;
-        std::vector<std::thread> pool;
-        for (uint32_t t = 1; t < workers; ++t) {
+        runOnThreads(workers, [&](uint32_t t) {
             const uint32_t lo = std::min(out.nodeCount, chunk * t), hi = std::min(out.nodeCount, chunk * (t + 1));
-            if (lo < hi) pool.emplace_back(quantiseRange, lo, hi);
-        }
-        quantiseRange(0, std::min(out.nodeCount, chunk));
-        for (auto& th : pool) th.join();
+            if (lo < hi) quantiseRange(lo, hi);
+        });
     }
     double extentSum = 0.0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -917,14 +883,11 @@ uint32_t BuildWideNodes(const FlatBvh& bvh, bool compact, std::unique_ptr<uint32
             }
         }
     };
-    std::vector<std::thread> pool;
     const uint32_t chunk = (nodeCount + workers - 1u) / workers;
-    for (uint32_t k = 1; k < workers; ++k) {
+    runOnThreads(workers, [&](uint32_t k) {
         const uint32_t b = std::min(nodeCount, chunk * k), e = std::min(nodeCount, chunk * (k + 1u));
-        if (b < e) pool.emplace_back(collapse, b, e);
-    }
-    collapse(0u, std::min(nodeCount, chunk));
-    for (auto& th : pool) th.join();
+        if (b < e) collapse(b, e);
+    });
     return wideCount;
 }
 

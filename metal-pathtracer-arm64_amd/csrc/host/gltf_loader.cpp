@@ -849,7 +849,7 @@ bool LoadGltfScene(const std::string& path, SceneResources& resources, std::stri
             size_t size = 0;
             if (images[im].view >= 0 && images[im].view < static_cast<int>(doc.views.size())) {
                 const BufferView& v = doc.views[static_cast<size_t>(images[im].view)];
-                if (v.buffer >= 0 && v.buffer < static_cast<int>(doc.buffers.size()) && v.offset + v.length <= doc.buffers[static_cast<size_t>(v.buffer)].size()) {
+                if (v.buffer >= 0 && v.buffer < static_cast<int>(doc.buffers.size()) && v.length <= doc.buffers[static_cast<size_t>(v.buffer)].size() && v.offset <= doc.buffers[static_cast<size_t>(v.buffer)].size() - v.length) {
                     data = doc.buffers[static_cast<size_t>(v.buffer)].data() + v.offset;
                     size = v.length;
                 }

@@ -23,6 +23,8 @@
 #include "../kernels/launch.h"
 #include "bvh_builder.h"
 #include "env_importance_sampler.h"
+#include "knobs.h"
+#include "parallel.h"
 #include "ptr_abi.h"
 #include "ptr_debug.h"
 #include "scene_geometry.h"
@@ -131,23 +133,17 @@ struct PtrDeviceScene {
     DeviceBuffer<uint32_t> flushItem, signature, tailList, tailWords;
     DeviceBuffer<uint32_t> connectList, connectCounts;   // PathPool::connectList: per group a list and two sets of sub-list counters
     DeviceBuffer<uint32_t> busyLists, busyCounts;        // PathPool::busyIn / busyOut: per group two lists and three sets of counters
-    uint32_t busyBelow = 1;                              // PTR_BUSY_LISTS=0: no busy lists at the end of the frame (A/B knob)
-    bool connectLists = true;                            // PTR_CONNECT_LIST=0: k_connect probes the slots (A/B knob)
     // end of the frame: once the item queue is dry and at most this many slots are still alive, the remaining paths are finished by
     // k_tail_run (one lane per path, no launches between bounces) instead of further extend / shade / connect rounds; 0 = never
     uint64_t tailBelow = 512ull << 10;
     uint64_t poolSlots = 32ull << 20;        // resident path slots at most (PTR_POOL_SLOTS)
     uint32_t poolGroups = 4;   // the pool is split into this many independent groups, one HIP stream each
-    uint32_t feederChunk = 256, feederChunkSparse = 0;   // slots per work-head claim: full pool / mostly dead pool (0: slots per resident wave)
+    bool shadeSort = true;     // k_shade sorts the slots of a block by shading key before it shades them (PTR_SHADE_SORT=0: A/B)
+    uint32_t feederChunk = 256;   // slots per work-head claim while the pool is full (it grows as the pool drains)
     std::vector<hipStream_t> groupStreams;   // streams of groups 1.. (group 0 runs on the caller's stream)
     std::vector<hipEvent_t> groupEvents;
     int refillBelow = 40;
-    // two rays per lane in k_extend / k_connect (kernels/traverse_dual.h).  Off: it fills the node steps better (0.71 of the lanes
-    // against 0.51) but needs 93 VGPRs (5 waves per SIMD instead of 8) and a vote + exchange every step, and measured 0.75x the
-    // frame rate of the one-ray loop (profiles/r2_dual_vs_classic.txt).  PTR_TRAVERSAL=dual selects it for A/B runs.
-    bool dualTraversal = false;
-    uint32_t dualGrid = 0;
-    int dualRefillAt = 32;
+    uint32_t spillLevels = 0;   // stack levels beyond the LDS part that the scene's tree can need (sizes the spill area)
     DeviceBuffer<uint4> medium;
     DeviceBuffer<uint32_t> scalars, pixelOfLocal, spill;
     DeviceBuffer<uint2> itemReserve;
@@ -181,13 +177,10 @@ constexpr uint32_t kMaxPoolGroups = 8;        // one block of scalars / one spil
 constexpr uint32_t kPinnedHeadsOffset = 16;
 constexpr uint32_t kTexInfoWords = 20;   // kernels/texture.h kTexInfoVec4 uint4 per texture   // pinned staging: [0..15] per-group live-slot counts, then kItemHeads range heads
 
-// Stack spill area of one pool group: the larger of the one-ray layout (levels beyond kLdsStackLevels, one column per thread of
-// the persistent grid) and the two-ray layout (levels beyond kDualLdsLevels, two columns per thread).
-size_t spillWordsPerGroup(const PtrDeviceScene& ds) {
-    const size_t classic = static_cast<size_t>(kTraversalStackDepth - kLdsStackLevels) * ds.traceGrid * kTraceGridUnit;
-    const size_t dual = static_cast<size_t>(kDualSpillLevels) * ds.dualGrid * kTraceGridUnit * 2u;
-    return std::max(classic, dual);
-}
+// Stack spill area of one pool group: the stack levels beyond kLdsStackLevels, one column per thread of the persistent grid.  The
+// four-wide walk pushes at most three entries per step (two binary levels), plus the root beside an oversize leaf: a tree of binary
+// depth d needs 3 ceil(d / 2) + 2 entries, not the worst case kTraversalStackDepth (1 GB of HBM per scene for 8 groups).
+size_t spillWordsPerGroup(const PtrDeviceScene& ds) { return static_cast<size_t>(ds.spillLevels) * ds.traceGrid * kTraceGridUnit; }
 
 // 576 B MaterialData -> the 13 float4 the integrator reads (kernels/device_types.h MaterialSlot).
 void compactMaterial(const PtrMaterial& m, std::vector<float>& out) {
@@ -218,6 +211,11 @@ struct PreparedScene {
     std::vector<float> texels;
     std::vector<uint32_t> texInfo;
     std::vector<float> materialTex;
+    // node format of the persistent kernels, decided once for all devices: 32 B quantised nodes unless the 16-bit grid is coarse next
+    // to the primitives, and the four-wide array derived from them (bvh_builder.h BuildWideNodes)
+    bool useQuantized = false;
+    std::unique_ptr<uint32_t[]> wide;
+    uint32_t wideCount = 0;
     double seconds = 0.0;
 };
 
@@ -261,8 +259,22 @@ void appendTextureWithMips(const PtrTexture& t, std::vector<float>& texels, std:
 
 void prepareScene(const PtrSceneDesc& desc, PreparedScene& ps) {
     const auto t0 = std::chrono::steady_clock::now();
+    const ptr::Knobs knobs = ptr::readKnobs();
     std::string geoError;
     if (!ptr::BuildSceneGeometry(desc, 0, ps.geo, geoError)) throw HipError{geoError};
+    {
+        // 32 B quantised nodes halve the node fetches; use them unless the 16-bit grid is coarse next to the primitives (cell > 1/8 of
+        // the mean primitive extent would inflate leaf boxes noticeably)
+        const ptr::FlatBvh& bvh = ps.geo.bvh;
+        const float maxCell = std::max(std::max(bvh.gridCell[0], bvh.gridCell[1]), bvh.gridCell[2]);
+        ps.useQuantized = bvh.nodeCount > 0 && maxCell * 8.0f <= bvh.meanPrimExtent;
+        if (knobs.quantizedNodes >= 0) ps.useQuantized = bvh.nodeCount > 0 && knobs.quantizedNodes != 0;
+        // four-wide nodes for the persistent traversal kernels; the binary array stays for the cold kernels and the counting build
+        if (ps.useQuantized && knobs.wideNodes != 0) {
+            ps.wideCount = ptr::BuildWideNodes(bvh, true, ps.wide);
+            if (static_cast<uint64_t>(ps.wideCount) * 64u > 0xFFFFFFFFull) throw HipError{"scene exceeds the 4 GiB node array limit"};
+        }
+    }
 
     // compact materials
     ps.mats.reserve(static_cast<size_t>(desc.materialCount) * kMaterialVec4 * 4);
@@ -339,12 +351,9 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     ds.hasRandomWalkMaterial = ps.hasRandomWalkMaterial;
 
     HIP_CHECK(hipSetDevice(ds.device));
-    // 32 B quantised nodes halve the node fetches; use them unless the 16-bit grid is coarse next to the
-    // primitives (cell > 1/8 of the mean primitive extent would inflate leaf boxes noticeably).  Only the node array the
-    // kernels will read goes to the device (a 29 M-triangle scene: 0.5 GB instead of 1.5 GB of nodes).
-    const float maxCell = std::max(std::max(bvh.gridCell[0], bvh.gridCell[1]), bvh.gridCell[2]);
-    bool useQuantized = bvh.nodeCount > 0 && maxCell * 8.0f <= bvh.meanPrimExtent;
-    if (const char* e = std::getenv("PTR_QUANTIZED_NODES")) useQuantized = std::atoi(e) != 0;
+    // only the node array the kernels will read goes to the device (a 29 M-triangle scene: 0.5 GB instead of 1.5 GB of nodes)
+    const ptr::Knobs knobs = ptr::readKnobs();
+    const bool useQuantized = ps.useQuantized;
     if (useQuantized) {
         ds.nodes.release();
         ds.qnodes.upload(reinterpret_cast<const uint4*>(bvh.qnodes.data()), bvh.qnodes.size() / 4);
@@ -377,19 +386,10 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     std::memcpy(v.gridCell, bvh.gridCell, sizeof(v.gridCell));
     for (int a = 0; a < 3; ++a) v.gridInvCell[a] = 1.0f / bvh.gridCell[a];
     v.useQuantized = useQuantized ? 1u : 0u;
-    bool useWide = useQuantized && bvh.nodeCount > 0;
-    if (const char* e = std::getenv("PTR_WIDE_NODES")) useWide = useWide && std::atoi(e) != 0;   // A/B knob
-    if (useWide) {
-        // four-wide nodes for the persistent traversal kernels (bvh_builder.h BuildWideNodes); the binary array stays for the cold
-        // kernels and the counting build
-        bool compact = true;
-        if (const char* e = std::getenv("PTR_WIDE_COMPACT")) compact = std::atoi(e) != 0;   // A/B knob
-        std::unique_ptr<uint32_t[]> wide;
-        const uint32_t wideCount = ptr::BuildWideNodes(bvh, compact, wide);
-        if (static_cast<uint64_t>(wideCount) * 64u > 0xFFFFFFFFull) throw HipError{"scene exceeds the 4 GiB node array limit"};
-        ds.wnodes.upload(reinterpret_cast<const uint4*>(wide.get()), static_cast<size_t>(wideCount) * 4u);
+    if (ps.wideCount > 0u) {
+        ds.wnodes.upload(reinterpret_cast<const uint4*>(ps.wide.get()), static_cast<size_t>(ps.wideCount) * 4u);
         v.wnodes = ds.wnodes.ptr;
-        v.wideBytes = static_cast<uint32_t>(static_cast<size_t>(wideCount) * 64u);
+        v.wideBytes = static_cast<uint32_t>(static_cast<size_t>(ps.wideCount) * 64u);
         v.useWide = 1u;
     }
     const size_t nodeBytes = v.useQuantized ? bvh.qnodes.size() * 4u : bvh.nodes.size() * 4u;
@@ -450,43 +450,22 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     ds.deviceTotalBytes = prop.totalGlobalMem;
     const uint32_t cus = prop.multiProcessorCount > 0 ? static_cast<uint32_t>(prop.multiProcessorCount) : 256u;
     ds.traceGrid = cus * 8u;   // 8 blocks of 256 threads per CU: fills the wave slots, grid-stride the rest
-    if (const char* e = std::getenv("PTR_REFILL_BELOW")) {   // tuning knob
-        const int v = std::atoi(e);
-        if (v >= 1 && v <= 64) ds.refillBelow = v;
-    }
+    if (knobs.refillBelow > 0) ds.refillBelow = knobs.refillBelow;
     // Half the wave slots when the pool runs as several groups of large launches: the kernels of the other groups (k_shade above all,
     // which needs 128 VGPRs a wave) then always find room beside a traversal kernel instead of queueing behind its last waves, and each
     // persistent wave sees twice as many rays before its own tail.  Measured on configs 2 / 3 / 4: +3.5 / +1.5 / +1.5 %, one rank of
     // eight 47.7 -> 44.5 ms; frames of a few milliseconds (config 1) lose 10 % and keep the full grid (profiles/r2_ab_grid_pool_knobs.txt).
     ds.traceGridHalf = cus * 4u;
-    if (const char* e = std::getenv("PTR_TRACE_BLOCKS_PER_CU")) {   // tuning knob
-        const int v = std::atoi(e);
-        if (v >= 1 && v <= 8) ds.traceGridHalf = ds.traceGrid = cus * static_cast<uint32_t>(v);
-    }
-    ds.dualGrid = cus * 5u;      // PTR_DUAL_WAVES blocks of 256 threads per CU (kernels/wavefront.hip)
-    if (const char* e = std::getenv("PTR_TRAVERSAL")) ds.dualTraversal = std::string(e) == "dual";   // A/B knob
-    if (const char* e = std::getenv("PTR_DUAL_BLOCKS_PER_CU")) {   // tuning knob
-        const int v = std::atoi(e);
-        if (v >= 1 && v <= 16) ds.dualGrid = cus * static_cast<uint32_t>(v);
-    }
-    if (const char* e = std::getenv("PTR_DUAL_REFILL_AT")) {   // tuning knob
-        const int v = std::atoi(e);
-        if (v >= 1 && v <= 128) ds.dualRefillAt = v;
-    }
-    if (const char* e = std::getenv("PTR_BUSY_LISTS")) ds.busyBelow = std::atoi(e) != 0 ? 1u : 0u;   // A/B knob
-    if (const char* e = std::getenv("PTR_CONNECT_LIST")) ds.connectLists = std::atoi(e) != 0;   // A/B knob
-    if (const char* e = std::getenv("PTR_TAIL_BELOW")) ds.tailBelow = std::strtoull(e, nullptr, 10);   // tuning knob (0 = off)
-    if (const char* e = std::getenv("PTR_POOL_SLOTS")) {   // tuning knob: resident path slots
-        const unsigned long long v = std::strtoull(e, nullptr, 10);
-        if (v >= 1024) ds.poolSlots = v;
-    }
-    if (const char* e = std::getenv("PTR_FEEDER_CHUNK")) ds.feederChunk = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 64), 1 << 16));
-    if (const char* e = std::getenv("PTR_FEEDER_CHUNK_SPARSE")) ds.feederChunkSparse = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 64), 1 << 16));
-    if (const char* e = std::getenv("PTR_POOL_GROUPS")) {   // tuning knob: concurrent pool groups (1 = single stream)
-        const int v = std::atoi(e);
-        if (v >= 1 && v <= static_cast<int>(kMaxPoolGroups)) ds.poolGroups = static_cast<uint32_t>(v);
-    }
-    ds.spill.ensure(spillWordsPerGroup(ds) * kMaxPoolGroups);
+    if (knobs.tailBelow >= 0) ds.tailBelow = static_cast<uint64_t>(knobs.tailBelow);
+    if (knobs.poolSlots != 0) ds.poolSlots = knobs.poolSlots;
+    if (knobs.poolGroups != 0) ds.poolGroups = knobs.poolGroups;
+    ds.shadeSort = knobs.shadeSort != 0;
+    // stack entries a ray of this tree can need: one per binary level for the two-box walk, three per pair of levels for the
+    // four-wide walk, the root beside an oversize leaf, and a margin
+    const uint32_t stackNeed = std::min<uint32_t>(kTraversalStackDepth, 3u * ((static_cast<uint32_t>(bvh.maxDepth) + 1u) / 2u) + 4u);
+    v.stackLimit = std::max(stackNeed, kLdsStackLevels);
+    ds.spillLevels = v.stackLimit - kLdsStackLevels;
+    ds.spill.ensure(std::max<size_t>(spillWordsPerGroup(ds) * ds.poolGroups, 1u));
     ds.scalars.ensure(static_cast<size_t>(kScalarCount) * kMaxPoolGroups);
     ds.counters.ensure(kCounterSlots);
     ds.zeros.ensure(16);
@@ -494,7 +473,7 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ds.pinnedAlive), sizeof(uint32_t) * (kPinnedHeadsOffset + kItemHeads), hipHostMallocDefault));
     const double copySeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ds.uploadSeconds = ps.seconds + copySeconds;
-    if (std::getenv("PTR_BUILD_VERBOSE")) std::fprintf(stderr, "[upload] prepare %.2f s, copies to the device %.2f s\n", ps.seconds, copySeconds);
+    if (knobs.verboseBuild) std::fprintf(stderr, "[upload] prepare %.2f s, copies to the device %.2f s\n", ps.seconds, copySeconds);
 }
 
 void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
@@ -760,16 +739,11 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
     const uint32_t connectRegion = ((groupSlots + 63u) / 64u + kConnectQueues - 1u) / kConnectQueues * 64u;
     const size_t connectListWords = static_cast<size_t>(connectRegion) * kConnectQueues;
     const size_t connectCountWords = static_cast<size_t>(kConnectQueues) * kConnectCountStride;   // one set
-    const bool connectLists = ds.connectLists && !ds.dualTraversal && slots < (1u << kConnectMaskShift);
-    if (connectLists) {
-        ds.connectList.ensure(connectListWords * groupCount);
-        ds.connectCounts.ensure(connectCountWords * 2u * kMaxPoolGroups);
-    }
-    const bool busyLists = connectLists && ds.busyBelow > 0u;
-    if (busyLists) {
-        ds.busyLists.ensure(connectListWords * 2u * groupCount);
-        ds.busyCounts.ensure(connectCountWords * 3u * kMaxPoolGroups);
-    }
+    if (slots >= (1u << kConnectMaskShift)) throw HipError{"path-slot pool too large for the connect lists"};   // (the pool is capped at 64 Mi slots)
+    ds.connectList.ensure(connectListWords * groupCount);
+    ds.connectCounts.ensure(connectCountWords * 2u * kMaxPoolGroups);
+    ds.busyLists.ensure(connectListWords * 2u * groupCount);
+    ds.busyCounts.ensure(connectCountWords * 3u * kMaxPoolGroups);
     std::vector<Group> groups(groupCount);
     for (uint32_t g = 0; g < groupCount; ++g) {
         Group& gr = groups[g];
@@ -793,21 +767,14 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         }
         gr.pool.itemReserve += first / 64u;
         gr.pool.slots = std::min(groupSlots, slots - first);
-        if (connectLists) {
-            gr.pool.connectList = ds.connectList.ptr + connectListWords * g;
-            gr.pool.connectRegion = connectRegion;
-            gr.connectCounts = ds.connectCounts.ptr + connectCountWords * 2u * g;
-        }
-        if (busyLists) {
-            gr.busyLists = ds.busyLists.ptr + connectListWords * 2u * g;
-            gr.busyCounts = ds.busyCounts.ptr + connectCountWords * 3u * g;
-        }
+        gr.pool.connectList = ds.connectList.ptr + connectListWords * g;
+        gr.pool.connectRegion = connectRegion;
+        gr.connectCounts = ds.connectCounts.ptr + connectCountWords * 2u * g;
+        gr.busyLists = ds.busyLists.ptr + connectListWords * 2u * g;
+        gr.busyCounts = ds.busyCounts.ptr + connectCountWords * 3u * g;
         gr.scalars = ds.scalars.ptr + static_cast<size_t>(g) * kScalarCount;
         const bool sideBySide = groupCount > 1 && gr.pool.slots >= kHalfGridGroupSlots;
         gr.cfg = LaunchConfig{sideBySide ? ds.traceGridHalf : ds.traceGrid, ds.spill.ptr + g * spillWords, gr.scalars + 1, ds.refillBelow};
-        gr.cfg.dual = ds.dualTraversal;
-        gr.cfg.dualGrid = ds.dualGrid;
-        gr.cfg.dualRefillAt = ds.dualRefillAt;
         gr.stream = g == 0 ? stream : ds.groupStreams[g - 1];
         gr.done = false;
         gr.feederChunk = ds.feederChunk;
@@ -835,8 +802,8 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
 
     if (count && (passFlags & 1u)) HIP_CHECK(hipMemsetAsync(ds.counters.ptr, 0, sizeof(uint64_t) * kCounterSlots, stream));   // counters add up over the passes
     HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * kScalarCount * kMaxPoolGroups, stream));
-    if (connectLists) HIP_CHECK(hipMemsetAsync(ds.connectCounts.ptr, 0, sizeof(uint32_t) * connectCountWords * 2u * kMaxPoolGroups, stream));
-    if (busyLists) HIP_CHECK(hipMemsetAsync(ds.busyCounts.ptr, 0, sizeof(uint32_t) * connectCountWords * 3u * kMaxPoolGroups, stream));
+    HIP_CHECK(hipMemsetAsync(ds.connectCounts.ptr, 0, sizeof(uint32_t) * connectCountWords * 2u * kMaxPoolGroups, stream));
+    HIP_CHECK(hipMemsetAsync(ds.busyCounts.ptr, 0, sizeof(uint32_t) * connectCountWords * 3u * kMaxPoolGroups, stream));
     {
         uint32_t* heads = ds.pinnedAlive + kPinnedHeadsOffset;
         for (uint32_t k = 0; k < kItemHeads; ++k) {
@@ -867,11 +834,10 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
     // slots it traced: one atomic per persistent wave).  A poll joins all streams, which
     // costs the overlap between groups once; polling every 4 iterations throughout was 5 % slower.  (Polling through
     // events without joining was tried: the host then runs up to a dozen empty iterations past the end - no gain.)
-    uint64_t kPollEvery = 4;
-    if (const char* e = std::getenv("PTR_POLL_EVERY")) kPollEvery = static_cast<uint64_t>(std::min(std::max(std::atoi(e), 1), 64));   // tuning knob
-    uint64_t kPollDry = 2;   // once the queue is dry: how often the live slots are counted (the hand-over to the tail kernels hangs on it)
-    if (const char* e = std::getenv("PTR_POLL_DRY")) kPollDry = static_cast<uint64_t>(std::min(std::max(std::atoi(e), 1), 64));   // tuning knob
-    const bool tracePolls = std::getenv("PTR_TRACE_ITERATIONS") != nullptr;   // debugging aid: live slots per poll
+    constexpr uint64_t kPollEvery = 4;
+    constexpr uint64_t kPollDry = 2;   // once the queue is dry: how often the live slots are counted (the hand-over to the tail kernels hangs on it)
+    const ptr::Knobs knobs = ptr::readKnobs();
+    const bool tracePolls = knobs.verbosePolls;   // debugging aid: live slots per poll
     uint64_t nextCheck = kPollEvery;
     bool queueDry = false;
     bool runTail = false;   // the last paths are handed to the tail kernels
@@ -884,11 +850,11 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
             // work heads and the next live-slot counter are cleared by k_shade (all zero at the start of the frame)
             const ShadeResets resets{gr.scalars + 1, gr.scalars + 2, gr.scalars + kAliveBase + (ring + 1u) % kAliveRing,
                                      (queueDry && gr.feederChunk > ds.feederChunk) ? 1u : 0u};
-            if (gr.connectCounts) {   // this iteration's counters, and the set k_shade clears for the next one
+            {   // this iteration's counters, and the set k_shade clears for the next one
                 gr.pool.connectCount = gr.connectCounts + connectCountWords * (iterations & 1u);
                 gr.pool.connectClear = gr.connectCounts + connectCountWords * ((iterations + 1u) & 1u);
             }
-            if (queueDry && gr.busyLists && gr.busyStage == 0u) gr.busyStage = 1u;   // the kernels decide per launch whether a list pays
+            if (queueDry && gr.busyStage == 0u) gr.busyStage = 1u;   // the kernels decide per launch whether a list pays
             if (gr.busyStage != 0u) {
                 // k_shade fills list `busyTurn` (counter set busyTurn % 3) and clears the set after it; in stage 2 this iteration's
                 // k_extend and k_shade walk the list the previous iteration filled
@@ -944,9 +910,9 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
                     // up to the point where the static first chunks of the resident waves cover the whole list and
                     // the head is not touched at all
                     const uint32_t thin = gr.pool.slots / std::max(ds.pinnedAlive[g], 1u);
-                    const uint32_t waves = std::max((gr.cfg.dual ? gr.cfg.dualGrid : gr.cfg.traceGrid) * (kTraceGridUnit / 64u), 1u);
+                    const uint32_t waves = std::max(gr.cfg.traceGrid * (kTraceGridUnit / 64u), 1u);
                     const uint32_t perWave = ((gr.pool.slots + waves - 1u) / waves + 63u) / 64u * 64u;
-                    const uint32_t cap = ds.feederChunkSparse ? ds.feederChunkSparse : std::max(perWave, ds.feederChunk);
+                    const uint32_t cap = std::max(perWave, ds.feederChunk);
                     gr.feederChunk = std::min(cap, ds.feederChunk * std::max(thin, 1u));
                     gr.shadeListed = static_cast<uint64_t>(ds.pinnedAlive[g]) * 5u < static_cast<uint64_t>(gr.pool.slots) * 2u;   // < 40 % live
                 }
@@ -1004,7 +970,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         stats->avgMsPerSample = seconds * 1000.0 / rp.spp;
         stats->uploadSeconds = ds.uploadSeconds;
         stats->samples = static_cast<uint64_t>(localPixels) * rp.spp;
-        if (std::getenv("PTR_TRACE_ITERATIONS") && !spans.empty()) {   // debugging aid: when each launch ran (ms from the first)
+        if (knobs.verboseLaunches && !spans.empty()) {   // debugging aid: when each launch ran (ms from the first)
             for (const Span& s : spans) {
                 float t0 = 0.0f, t1 = 0.0f;
                 HIP_CHECK(hipEventElapsedTime(&t0, spans.front().a, s.a));
@@ -1039,7 +1005,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
             stats->shadedHits = c[kCntShadedHits];
             stats->triangleHits = c[kCntTriangleHits];
             stats->shadowEarlyExits = c[kCntShadowEarlyExit];
-            if (std::getenv("PTR_TRACE_STEPS")) {   // lane utilisation of k_extend's step loop (counting build)
+            if (knobs.verboseSteps) {   // lane utilisation of k_extend's step loop (counting build)
                 const double nodeLanes = static_cast<double>(c[kCntExtendNodes] - c[kCntExtendLeaves]), primLanes = static_cast<double>(c[kCntExtendPrims]);
                 const double nodeSlots = static_cast<double>(c[kCntExtendWaveNodeSteps]), primSlots = static_cast<double>(c[kCntExtendWavePrimSteps]);
                 std::fprintf(stderr, "[steps] k_extend: %.3g rays; node steps %.3g lane / %.3g slots = %.3f; prim steps %.3g lane / %.3g slots = %.3f; "
@@ -1078,7 +1044,7 @@ void renderBands(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, 
     {
         const uint64_t budget = itemBudgetBytes(ds);
         uint64_t maxItems = std::min<uint64_t>(budget / sizeof(float4), 0xFFFFFFF0ull);
-        if (const char* e = std::getenv("PTR_MAX_ITEMS")) maxItems = std::max<uint64_t>(1024u, std::strtoull(e, nullptr, 10));   // test knob
+        if (const uint64_t forced = ptr::readKnobs().maxItems) maxItems = forced;   // test knob
         // counted on the whole frame, not on this partition: every partition then splits the samples the same way and the image
         // stays bit-identical whatever the number of partitions
         const uint64_t pixels = static_cast<uint64_t>(settings.width) * settings.height;
@@ -1306,12 +1272,7 @@ static int renderMulti(const PtrSceneDesc* scene, const PtrSettings* settings, u
                 errors[p] = "unknown exception";
             }
         };
-        {
-            std::vector<std::thread> threads;
-            for (uint32_t p = 1; p < parts; ++p) threads.emplace_back(worker, p);
-            worker(0u);
-            for (std::thread& t : threads) t.join();
-        }
+        ptr::runOnThreads(parts, worker);
         for (uint32_t p = 0; p < parts; ++p) {
             if (!errors[p].empty()) throw HipError{"device " + std::to_string(device_ids[p]) + ": " + errors[p]};
         }
@@ -1336,6 +1297,7 @@ static int renderMulti(const PtrSceneDesc* scene, const PtrSettings* settings, u
                 stats->traceKernelMs += partStats[p].traceKernelMs;
                 stats->shadeKernelMs += partStats[p].shadeKernelMs;
                 stats->shadowKernelMs += partStats[p].shadowKernelMs;
+                stats->tailKernelMs += partStats[p].tailKernelMs;
                 stats->traceLaunches += partStats[p].traceLaunches;
             }
         }

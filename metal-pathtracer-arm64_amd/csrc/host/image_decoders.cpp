@@ -82,11 +82,12 @@ const uint16_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 
 const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
 const uint16_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 
-bool inflateBlockData(BitReader& br, const Huffman& lit, const Huffman& dist, std::vector<uint8_t>& out) {
+bool inflateBlockData(BitReader& br, const Huffman& lit, const Huffman& dist, std::vector<uint8_t>& out, size_t cap) {
     while (true) {
         const int sym = lit.decode(br);
         if (sym < 0) return false;
         if (sym < 256) {
+            if (out.size() >= cap) return false;
             out.push_back(static_cast<uint8_t>(sym));
         } else if (sym == 256) {
             return true;
@@ -97,14 +98,15 @@ bool inflateBlockData(BitReader& br, const Huffman& lit, const Huffman& dist, st
             const int ds = dist.decode(br);
             if (ds < 0 || ds >= 30) return false;
             const uint32_t distance = kDistBase[ds] + br.get(kDistExtra[ds]);
-            if (br.bad || distance > out.size()) return false;
+            if (br.bad || distance > out.size() || out.size() + length > cap) return false;
             size_t from = out.size() - distance;
             for (uint32_t i = 0; i < length; ++i) out.push_back(out[from++]);
         }
     }
 }
 
-bool inflateRaw(BitReader& br, std::vector<uint8_t>& out) {
+// cap: the most output the caller can use; a stream that expands beyond it is rejected (a few KB of deflate can expand ~1000:1)
+bool inflateRaw(BitReader& br, std::vector<uint8_t>& out, size_t cap) {
     bool last = false;
     while (!last) {
         last = br.get(1) != 0;
@@ -115,7 +117,7 @@ bool inflateRaw(BitReader& br, std::vector<uint8_t>& out) {
             if (br.at + 4 > br.n) return false;
             const uint32_t len = br.p[br.at] | (br.p[br.at + 1] << 8), nlen = br.p[br.at + 2] | (br.p[br.at + 3] << 8);
             br.at += 4;
-            if ((len ^ 0xFFFFu) != nlen || br.at + len > br.n) return false;
+            if ((len ^ 0xFFFFu) != nlen || br.at + len > br.n || out.size() + len > cap) return false;
             out.insert(out.end(), br.p + br.at, br.p + br.at + len);
             br.at += len;
         } else if (type == 1) {
@@ -129,7 +131,7 @@ bool inflateRaw(BitReader& br, std::vector<uint8_t>& out) {
             uint8_t dl[30];
             for (int i = 0; i < 30; ++i) dl[i] = 5;
             dist.build(dl, 30);
-            if (!inflateBlockData(br, lit, dist, out)) return false;
+            if (!inflateBlockData(br, lit, dist, out, cap)) return false;
         } else if (type == 2) {
             const int nlen = static_cast<int>(br.get(5)) + 257, ndist = static_cast<int>(br.get(5)) + 1, ncode = static_cast<int>(br.get(4)) + 4;
             if (br.bad || nlen > 286 || ndist > 30) return false;
@@ -164,7 +166,7 @@ bool inflateRaw(BitReader& br, std::vector<uint8_t>& out) {
             Huffman lit, dist;
             if (!lit.build(ll, nlen)) return false;
             dist.build(ll + nlen, ndist);   // an incomplete distance code is legal (a single distance)
-            if (!inflateBlockData(br, lit, dist, out)) return false;
+            if (!inflateBlockData(br, lit, dist, out, cap)) return false;
         } else {
             return false;
         }
@@ -177,12 +179,12 @@ uint32_t be32(const uint8_t* p) { return (static_cast<uint32_t>(p[0]) << 24) | (
 
 }  // namespace
 
-bool InflateZlib(const uint8_t* data, size_t size, std::vector<uint8_t>& out, std::string* error) {
+bool InflateZlib(const uint8_t* data, size_t size, std::vector<uint8_t>& out, std::string* error, size_t maxOutput) {
     out.clear();
     if (size < 6) return fail(error, "zlib stream too short");
     if ((data[0] & 0x0F) != 8 || ((data[0] << 8) | data[1]) % 31 != 0 || (data[1] & 0x20)) return fail(error, "bad zlib header");
     BitReader br{data + 2, size - 2};
-    if (!inflateRaw(br, out)) return fail(error, "corrupt deflate stream");
+    if (!inflateRaw(br, out, maxOutput)) return fail(error, "corrupt deflate stream (or output beyond the expected size)");
     // adler32 of the output follows (after alignment); verify when present
     br.alignByte();
     if (br.at + 4 <= br.n) {
@@ -247,7 +249,7 @@ bool DecodePng(const uint8_t* data, size_t size, DecodedImage& out, std::string*
     const size_t bpp = std::max<size_t>(1, static_cast<size_t>(channels) * depth / 8);             // filter unit
     const size_t rowBytes = (static_cast<size_t>(width) * channels * depth + 7) / 8;
     std::vector<uint8_t> raw;
-    if (!InflateZlib(idat.data(), idat.size(), raw, error)) return false;
+    if (!InflateZlib(idat.data(), idat.size(), raw, error, (rowBytes + 1) * height)) return false;
     if (raw.size() < (rowBytes + 1) * height) return fail(error, "PNG pixel data too short");
 
     // undo the scanline filters in place
@@ -505,6 +507,7 @@ bool DecodeJpeg(const uint8_t* data, size_t size, DecodedImage& out, std::string
             if (segLen >= 2) restartInterval = (seg[0] << 8) | seg[1];
         } else if (marker == 0xDA) {
             if (!haveFrame || width == 0 || height == 0 || width > 16384 || height > 16384) return fail(error, "JPEG scan before frame header");
+            if (segLen < 1) return fail(error, "truncated JPEG scan header");
             const int ns = seg[0];
             if (ns != ncomp || segLen < 1 + static_cast<size_t>(ns) * 2 + 3) return fail(error, "unsupported JPEG scan layout");
             for (int i = 0; i < ns; ++i) {

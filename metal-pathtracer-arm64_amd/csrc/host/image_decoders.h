@@ -27,6 +27,7 @@ bool DecodeJpeg(const uint8_t* data, size_t size, DecodedImage& out, std::string
 // Picks the decoder from the magic bytes.
 bool DecodeImage(const uint8_t* data, size_t size, DecodedImage& out, std::string* error = nullptr);
 // zlib stream -> bytes (exposed for tests).
-bool InflateZlib(const uint8_t* data, size_t size, std::vector<uint8_t>& out, std::string* error = nullptr);
+// maxOutput: a stream that would expand beyond this many bytes is rejected
+bool InflateZlib(const uint8_t* data, size_t size, std::vector<uint8_t>& out, std::string* error = nullptr, size_t maxOutput = static_cast<size_t>(1) << 31);
 
 }  // namespace ptr

@@ -11,6 +11,8 @@
 #include <thread>
 
 #include "../kernels/bvh_layout.h"
+#include "knobs.h"
+#include "parallel.h"
 #include "vecmath.h"
 
 namespace ptr {
@@ -88,12 +90,10 @@ void parallelFor(size_t n, const std::function<void(size_t, size_t)>& body) {
         return;
     }
     const size_t chunk = (n + threads - 1) / threads;
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < threads; ++t) {
+    runOnThreads(threads, [&](uint32_t t) {
         const size_t b = std::min(n, chunk * t), e = std::min(n, chunk * (t + 1));
-        if (b < e) pool.emplace_back(body, b, e);
-    }
-    for (auto& th : pool) th.join();
+        if (b < e) body(b, e);
+    });
 }
 
 // Writes one triangle (input order) into the 12-float records and its padded bounds.
@@ -273,7 +273,6 @@ bool BuildSceneGeometry(const PtrSceneDesc& desc, uint32_t leafMax, SceneGeometr
     t0 = std::chrono::steady_clock::now();
     if (leafMax == 0) {
         leafMax = 4;
-        if (const char* e = std::getenv("PTR_LEAF_MAX")) leafMax = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 8));
     }
     BuildFlatBvh(prims, out.bvh, 0, leafMax);
     out.buildSeconds = secondsSince(t0);
@@ -316,7 +315,7 @@ bool BuildSceneGeometry(const PtrSceneDesc& desc, uint32_t leafMax, SceneGeometr
         out.sphereInfo.push_back(s.materialIndex[0]);
     }
     out.flattenSeconds = secondsSince(t0);
-    if (std::getenv("PTR_BUILD_VERBOSE")) {
+    if (readKnobs().verboseBuild) {
         std::fprintf(stderr, "[geometry] gather %.2f s, bvh %.2f s, leaf-order %.2f s (%u triangles, %u spheres)\n", out.gatherSeconds,
                      out.buildSeconds, out.flattenSeconds, out.triCount, out.sphereCount);
     }

@@ -30,7 +30,7 @@ struct SceneGeometry {
     double gatherSeconds = 0.0, buildSeconds = 0.0, flattenSeconds = 0.0;
 };
 
-// leafMax = 0 picks the default (4, or PTR_LEAF_MAX).  Returns false with a message on malformed input.
+// leafMax = 0 picks the default (4).  Returns false with a message on malformed input.
 bool BuildSceneGeometry(const PtrSceneDesc& desc, uint32_t leafMax, SceneGeometry& out, std::string& error);
 
 struct GeometryCheck {

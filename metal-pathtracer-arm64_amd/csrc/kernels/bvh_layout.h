@@ -25,14 +25,6 @@ constexpr uint32_t kLdsStackLevels = 16u;        // stack levels kept in LDS; de
 #endif
 constexpr uint32_t kTraceBlock = PTR_TRACE_BLOCK;   // threads per block of the traversal kernels
 constexpr uint32_t kTraceGridUnit = 256u;           // the host sizes traversal grids (and the spill area) in units of this many threads
-// two-rays-per-lane kernels (traverse_dual.h): stack levels per ray kept in LDS - 2 rays x 14 levels x 256 lanes x 4 B = 28 KB per
-// block, 140 KB for the 5 blocks a CU holds (the kernels need 93-96 VGPRs: 5 waves per SIMD)
-#ifndef PTR_DUAL_LDS_LEVELS
-#define PTR_DUAL_LDS_LEVELS 14
-#endif
-constexpr uint32_t kDualLdsLevels = PTR_DUAL_LDS_LEVELS;
-constexpr uint32_t kDualLdsWords = kDualLdsLevels * 2u * kTraceBlock;
-constexpr uint32_t kDualSpillLevels = kTraversalStackDepth - kDualLdsLevels;   // per ray column, in HBM
 constexpr uint32_t kHitMiss = 0xFFFFFFFFu;
 constexpr uint32_t kHitSphereBit = 0x80000000u;
 

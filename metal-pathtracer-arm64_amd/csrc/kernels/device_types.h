@@ -63,7 +63,7 @@ struct SceneView {
     const uint4* texInfo;          // kTexInfoVec4 uint4 per texture
     const float4* materialTex;     // kMaterialTexVec4 float4 per material: texture transforms, indices, uv sets, pbr params
     uint32_t textureCount;
-    uint32_t pad2;
+    uint32_t stackLimit;           // traversal stack entries a ray of this scene can need at most (<= kTraversalStackDepth): LDS levels + spill levels
 };
 
 // per-material texture record (materialTex): [0..11] KHR_texture_transform rows of the six slots (base colour, metallic-roughness,
@@ -235,7 +235,7 @@ enum CounterSlot : uint32_t {
     kCntPrimaryRays = 8,
     kCntShadowEarlyExit = 9,
     kCntStackOverflow = 10,
-    kCntExtendLeaves = 11,          // k_extend only, counting build: lane-utilisation bookkeeping (PTR_TRACE_STEPS)
+    kCntExtendLeaves = 11,          // k_extend only, counting build: lane-utilisation bookkeeping (PTR_VERBOSE=steps)
     kCntExtendWaveNodeSteps = 12,   // 64 x node steps executed by waves
     kCntExtendWavePrimSteps = 13,   // 64 x primitive steps executed by waves
     kCntExtendRefillPasses = 14,    // 64 x refill passes
@@ -244,7 +244,7 @@ enum CounterSlot : uint32_t {
     kCntExtendActiveLanes = 17,     // sum over vote iterations of the lanes holding a ray
     kCntExtendLeafLanes = 18,       // ... of which at a leaf
     kCntExtendVoteIterations = 19,  // 64 x vote iterations
-    // k_shade, counting build (PTR_TRACE_STEPS): lanes that reach each stage of a visit, and 64 x the waves that ran a visit at all
+    // k_shade, counting build (PTR_VERBOSE=steps): lanes that reach each stage of a visit, and 64 x the waves that ran a visit at all
     kCntShadeWaves = 24,
     kCntShadeAlive = 25,        // slots with a ray that was traced
     kCntShadeSurface = 26,      // ... that hit a surface

@@ -14,10 +14,6 @@ struct LaunchConfig {
     uint32_t* workCounters;  // [2] work-queue heads of k_extend / k_connect, zeroed by the host before each launch
     int refillBelow;         // persistent waves hand out new rays once fewer than this many lanes are traversing
     uint32_t feederChunk = 256;   // slots a wave claims per atomic on the work head
-    // two-rays-per-lane traversal kernels (traverse_dual.h)
-    bool dual = false;
-    uint32_t dualGrid = 0;        // blocks: resident waves per SIMD x CUs
-    int dualRefillAt = 32;        // a refill pass runs once this many of a wave's 128 ray register sets are empty
 };
 
 void launchGenerate(const RenderParams& rp, const PathPool& pool, hipStream_t stream);

@@ -34,6 +34,7 @@ struct LaneStack {
     LdsWord* lds;         // &ldsStack[threadIdx.x]; stride kTraceBlock
     uint32_t* spill;      // spill area of this launch (wave-uniform: stays in SGPRs); lane column = global thread id
     uint32_t spillStride;
+    uint32_t limit;       // entries the stack can hold: kLdsStackLevels + the spill levels the host allocated for this scene's tree (SceneView::stackLimit)
     uint32_t sp;
     // the lane's column is recomputed on the (rare) spill path instead of keeping a 64-bit pointer alive per lane
     __device__ __forceinline__ uint32_t* spillSlot(uint32_t level) const {
@@ -43,10 +44,10 @@ struct LaneStack {
     __device__ __forceinline__ void push(uint32_t v) {
         if (sp < kLdsStackLevels) {
             lds[sp * kTraceBlock] = v;
-        } else if (sp < kTraversalStackDepth) {
+        } else if (sp < limit) {
             *spillSlot(sp) = v;
         } else {
-            return;  // cannot happen: the builder bounds the tree depth (bvh_layout.h)
+            return;  // cannot happen: the host sizes the spill area from the depth of the tree it built (hip_backend.cpp)
         }
         ++sp;
     }
@@ -62,15 +63,9 @@ struct LaneStack {
 // address arithmetic, and returns zeros instead of faulting if an index were ever out of range.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// PTR_LDS_TOP=<n> (experiment, with the host's PTR_BFS_TOP=<n> layout): the n quantised nodes nearest the root are copied into
-// LDS by every block of k_extend / k_connect and fetched from there.
-#ifndef PTR_LDS_TOP
-#define PTR_LDS_TOP 0
-#endif
 struct SceneMem {
     __amdgpu_buffer_rsrc_t nodes;   // quantised or float nodes, whichever the scene uses
     __amdgpu_buffer_rsrc_t tris;
-    const uint4* top = nullptr;     // LDS copy of nodes 0 .. PTR_LDS_TOP-1 (two uint4 each), or null
     __amdgpu_buffer_rsrc_t wide;    // four-wide nodes (NODES == 2 instantiations only)
 };
 
@@ -184,20 +179,10 @@ struct Trav {
     f3 oi;               // org*inv in the space of the node boxes (world, or grid cells for quantised nodes)
     float tnear;
     TraceHit hit;
-    uint32_t cur;        // internal node index, or leaf reference while primitives remain (postponing build: kRefEmpty = nothing left to walk)
-    uint32_t leafPos;    // next primitive inside the current leaf (postponing build: the postponed leaf's reference, advanced in place)
+    uint32_t cur;        // internal node index, or leaf reference while primitives remain
+    uint32_t leafPos;    // next primitive inside the current leaf
     bool anyHit;
 };
-
-// PTR_POSTPONE_LEAVES: a lane that reaches a leaf parks it (one leaf per lane) and keeps walking; primitive steps then serve the
-// parked leaves of many lanes at once (Aila & Laine's speculative traversal, adapted to the wave vote).  The walk after a parked
-// leaf uses the ray's old extent, so it may fetch nodes the leaf's hit would have culled - work a waiting lane would not have done
-// at all, so it costs no wave step.  Every leaf whose box passes the test is still tested: results are unchanged.
-#ifndef PTR_POSTPONE_LEAVES
-#define PTR_POSTPONE_LEAVES 0
-#endif
-// (binary node steps only: a build with this switch launches the two-box kernels.  On top of the four-wide nodes it measured +1 % on
-// config 2 and nothing elsewhere, profiles/r2_ab_postponed_leaves.txt, and was not kept.)
 
 // NODES: 1 = 32 B quantised nodes, 0 = 64 B float nodes (compile-time choice of the persistent kernels), -1 = decided by the scene's
 // flag at run time (the cold kernels: ray-batch queries, feature buffers, chains, the end-of-frame kernel)
@@ -230,48 +215,24 @@ __device__ __forceinline__ bool travBegin(const SceneView& sc, Trav& t, f3 org, 
     t.hit.prim = kHitMiss;
     t.anyHit = anyHit;
     t.cur = sc.rootRef;
-    t.leafPos = PTR_POSTPONE_LEAVES ? kRefEmpty : 0u;
+    t.leafPos = 0u;
     stack.sp = 0;
     if (sc.oversizeRef != kRefEmpty) {
         // the few triangles kept out of the tree (bvh_builder.cpp) come first: their hits shorten the ray before the walk
-        if (PTR_POSTPONE_LEAVES) {
-            t.leafPos = sc.oversizeRef;   // parked from the start; the walk begins at the root beside it
-            return true;
-        }
         if (sc.rootRef != kRefEmpty) stack.push(sc.rootRef);
         t.cur = sc.oversizeRef;
         return true;
-    }
-    if (PTR_POSTPONE_LEAVES && sc.rootRef != kRefEmpty && (sc.rootRef & kRefLeafBit)) {   // a scene of one leaf
-        t.leafPos = sc.rootRef;
-        t.cur = kRefEmpty;
     }
     return sc.rootRef != kRefEmpty;
 }
 
 __device__ __forceinline__ bool travAtLeaf(const Trav& t) { return (t.cur & kRefLeafBit) != 0u; }
-// postponing build: the lane can take a node step / has a parked leaf
-__device__ __forceinline__ bool travCanWalk(const Trav& t) { return (t.cur & kRefLeafBit) == 0u; }
-__device__ __forceinline__ bool travHasParked(const Trav& t) { return t.leafPos != kRefEmpty; }
-
 // pops the next subtree; false when the traversal is complete
 __device__ __forceinline__ bool travPop(Trav& t, LaneStack& stack) {
     if (stack.sp == 0) return false;
     t.cur = stack.pop();
     t.leafPos = 0u;
     return true;
-}
-
-// postponing build: next subtree or kRefEmpty
-__device__ __forceinline__ uint32_t travPopOrNone(LaneStack& stack) { return stack.sp == 0 ? kRefEmpty : stack.pop(); }
-// postponing build: a leaf in `cur` moves to the parking place when that is free, and the walk goes on below it
-template <bool COUNT>
-__device__ __forceinline__ void travPark(Trav& t, LaneStack& stack, TraceCounters& cnt) {
-    if (t.leafPos == kRefEmpty && t.cur != kRefEmpty && (t.cur & kRefLeafBit)) {
-        t.leafPos = t.cur;
-        t.cur = travPopOrNone(stack);
-        if (COUNT) { ++cnt.nodes; ++cnt.leaves; }
-    }
 }
 
 __device__ __forceinline__ f3 gridLo(uint32_t w0, uint32_t w1) {
@@ -333,14 +294,7 @@ __device__ __forceinline__ bool travNodeStep(const SceneView& sc, const SceneMem
     // both halves of the node are fetched up front and both boxes tested without branching: a short-circuit
     // on the child reference made the compiler issue the second half as a dependent load
     if (NODES == 1 || (NODES < 0 && sc.useQuantized)) {
-        uint4 q0, q1;
-        if (PTR_LDS_TOP > 0 && NODES == 1 && mem.top != nullptr && t.cur < static_cast<uint32_t>(PTR_LDS_TOP)) {
-            q0 = mem.top[t.cur * 2u];
-            q1 = mem.top[t.cur * 2u + 1u];
-        } else {
-            q0 = load16u(mem.nodes, t.cur * 32u);
-            q1 = load16u(mem.nodes, t.cur * 32u + 16u);
-        }
+        const uint4 q0 = load16u(mem.nodes, t.cur * 32u), q1 = load16u(mem.nodes, t.cur * 32u + 16u);
         ref0 = q0.w;
         ref1 = q1.w;
         h0 = slabTest(gridLo(q0.x, q0.y), gridHi(q0.y, q0.z), t.oi, t.inv, t.tnear, t.hit.t, e0);
@@ -360,22 +314,6 @@ __device__ __forceinline__ bool travNodeStep(const SceneView& sc, const SceneMem
     const bool firstIs0 = e0 <= e1;
     const uint32_t nearRef = (h0 & (firstIs0 | !h1)) ? ref0 : ref1;
     const uint32_t farRef = firstIs0 ? ref1 : ref0;
-#if PTR_POSTPONE_LEAVES
-    uint32_t next = (h0 | h1) ? nearRef : kRefEmpty;
-    uint32_t other = (h0 & h1) ? farRef : kRefEmpty;
-    if ((next & kRefLeafBit) && next != kRefEmpty && t.leafPos == kRefEmpty) {
-        // a near leaf is parked and the walk continues with the far child (instead of pushing it)
-        t.leafPos = next;
-        next = other;
-        other = kRefEmpty;
-        if (COUNT) { ++cnt.nodes; ++cnt.leaves; }
-    }
-    if (other != kRefEmpty) stack.push(other);
-    if (next == kRefEmpty) next = travPopOrNone(stack);
-    t.cur = next;
-    travPark<COUNT>(t, stack, cnt);   // a popped leaf, parking place free: park it and pop once more
-    return t.cur != kRefEmpty || t.leafPos != kRefEmpty;
-#else
     t.leafPos = 0u;
     if (h0 & h1) stack.push(farRef);
     if (h0 | h1) {
@@ -383,25 +321,16 @@ __device__ __forceinline__ bool travNodeStep(const SceneView& sc, const SceneMem
         return true;
     }
     return travPop(t, stack);
-#endif
 }
 
 // Primitive step (t.cur is a leaf): tests primitive number t.leafPos of the leaf.  Returns false once finished.
 template <bool COUNT>
 __device__ __forceinline__ bool travPrimStep(const SceneView& sc, const SceneMem& mem, Trav& t, LaneStack& stack, TraceCounters& cnt) {
-#if PTR_POSTPONE_LEAVES
-    // the parked leaf: its reference is advanced in place (first primitive + 1, count - 1)
-    const uint32_t cur = t.leafPos;
-    const uint32_t index = cur & kRefOffsetMask;
-    const bool last = ((cur >> kRefCountShift) & 0xFu) == 0u;
-    if (COUNT) ++cnt.prims;
-#else
     const uint32_t cur = t.cur;
     const uint32_t first = cur & kRefOffsetMask;
     const uint32_t count = ((cur >> kRefCountShift) & 0xFu) + 1u;
     const uint32_t index = first + t.leafPos;
     if (COUNT) { ++cnt.prims; if (t.leafPos == 0u) { ++cnt.nodes; ++cnt.leaves; } }
-#endif
     if (cur & kRefSphereBit) {
         float tt;
         if (sphereTest(sc.spheres[index], t.org, t.dir, t.tnear, t.hit.t, tt)) {
@@ -419,18 +348,8 @@ __device__ __forceinline__ bool travPrimStep(const SceneView& sc, const SceneMem
             if (t.anyHit) return false;
         }
     }
-#if PTR_POSTPONE_LEAVES
-    if (!last) {
-        t.leafPos = cur + 1u - (1u << kRefCountShift);
-        return true;
-    }
-    t.leafPos = kRefEmpty;
-    travPark<COUNT>(t, stack, cnt);   // a leaf that was waiting in `cur` takes the place
-    return t.cur != kRefEmpty || t.leafPos != kRefEmpty;
-#else
     if (++t.leafPos < count) return true;
     return travPop(t, stack);
-#endif
 }
 
 #ifndef PTR_EXTRA_NODE_STEPS
@@ -449,44 +368,6 @@ __device__ __forceinline__ bool travPrimStep(const SceneView& sc, const SceneMem
 
 // One wave iteration for all traversing lanes: majority vote between node steps and primitive steps.
 // Returns (per lane) false when that lane's ray has just finished.  Lanes not voted for return true unchanged.
-#if PTR_POSTPONE_LEAVES
-#ifndef PTR_PARK_PRIM_AT   // a primitive step is also taken once this many lanes have a leaf parked
-#define PTR_PARK_PRIM_AT 48
-#endif
-template <bool COUNT, int NODES = -1>
-__device__ __forceinline__ bool travVote(const SceneView& sc, const SceneMem& mem, Trav& t, bool active, LaneStack& stack,
-                                         TraceCounters& cnt) {
-    const bool canWalk = active && travCanWalk(t);
-    const bool stuck = active && !travCanWalk(t);   // nothing to walk before a primitive step: a second leaf, or only the parked one
-    const bool parked = active && travHasParked(t);
-    const int nWalk = __popcll(__ballot(canWalk));
-    const int nStuck = __popcll(__ballot(stuck));
-    const int nParked = __popcll(__ballot(parked));
-    bool more = true;
-    if (nWalk >= nStuck * PTR_PRIM_BIAS && nParked < PTR_PARK_PRIM_AT) {
-        if (COUNT) ++cnt.waveNodeSteps;
-        if (canWalk) more = travNodeStep<COUNT, NODES>(sc, mem, t, stack, cnt);
-#pragma unroll
-        for (int extra = 0; extra < PTR_EXTRA_NODE_STEPS; ++extra) {
-            const bool again = canWalk && more && travCanWalk(t);
-            if (static_cast<int>(__popcll(__ballot(again))) * PTR_REPEAT_DEN < nWalk * PTR_REPEAT_NUM) break;
-            if (COUNT) ++cnt.waveNodeSteps;
-            if (again) more = travNodeStep<COUNT, NODES>(sc, mem, t, stack, cnt);
-        }
-    } else {
-        if (COUNT) ++cnt.wavePrimSteps;
-        if (parked) more = travPrimStep<COUNT>(sc, mem, t, stack, cnt);
-#pragma unroll
-        for (int extra = 0; extra < PTR_EXTRA_PRIM_STEPS; ++extra) {
-            const bool again = parked && more && travHasParked(t);
-            if (static_cast<int>(__popcll(__ballot(again))) * PTR_REPEAT_DEN < nParked * PTR_REPEAT_NUM) break;
-            if (COUNT) ++cnt.wavePrimSteps;
-            if (again) more = travPrimStep<COUNT>(sc, mem, t, stack, cnt);
-        }
-    }
-    return more;
-}
-#else
 template <bool COUNT, int NODES = -1>
 __device__ __forceinline__ bool travVote(const SceneView& sc, const SceneMem& mem, Trav& t, bool active, LaneStack& stack,
                                          TraceCounters& cnt) {
@@ -520,7 +401,6 @@ __device__ __forceinline__ bool travVote(const SceneView& sc, const SceneMem& me
     }
     return more;
 }
-#endif
 
 // Whole-ray loop for one lane (ray-batch queries, MNEE chains): closest hit (ANY = false) or first hit
 // (ANY = true).  Returns hit.prim == kHitMiss on a miss.  Same step functions as the persistent kernels.
@@ -532,11 +412,7 @@ __device__ __forceinline__ TraceHit traverse(const SceneView& sc, f3 org, f3 dir
     if (!travBegin(sc, t, org, dir, tnear, tfar, ANY, stack)) return t.hit;
     bool more = true;
     while (more) {
-#if PTR_POSTPONE_LEAVES
-        more = travCanWalk(t) ? travNodeStep<COUNT>(sc, mem, t, stack, cnt) : travPrimStep<COUNT>(sc, mem, t, stack, cnt);
-#else
         more = travAtLeaf(t) ? travPrimStep<COUNT>(sc, mem, t, stack, cnt) : travNodeStep<COUNT>(sc, mem, t, stack, cnt);
-#endif
     }
     return t.hit;
 }

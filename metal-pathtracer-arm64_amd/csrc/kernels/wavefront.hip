@@ -23,7 +23,6 @@
 #include <type_traits>
 #include "traverse.h"
 #include "texture.h"
-#include "traverse_dual.h"
 #include "vec.h"
 
 namespace ptrk {
@@ -533,6 +532,7 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
     stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
     stack.spill = spill;
     stack.spillStride = spillStride;
+    stack.limit = sc.stackLimit;
     stack.sp = 0u;
     TraceCounters cnt{0u, 0u};
     uint32_t rays = 0u;
@@ -543,14 +543,6 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
     const long long kernelStart = COUNT ? clock64() : 0ll;
 
     SceneMem mem = sceneMem(sc);
-#if PTR_LDS_TOP > 0
-    __shared__ uint4 ldsTop[PTR_LDS_TOP * 2];
-    if (NODES == 1 && sc.nodeBytes >= PTR_LDS_TOP * 32u) {
-        for (uint32_t i = threadIdx.x; i < PTR_LDS_TOP * 2u; i += kTraceBlock) ldsTop[i] = sc.qnodes[i];
-        __syncthreads();
-        mem.top = ldsTop;
-    }
-#endif
     // end of the frame (the ALIVE instantiation): the work is the busy list k_shade left, not the slots (PathPool::busyIn)
     bool listed = ALIVE && pool.busyIn != nullptr;
     SubLists lists{0u, pool.slots};
@@ -623,120 +615,6 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
         addCounter(pool.counters, kCntExtendVoteIterations, voteIterations);
         addCounter(pool.counters, kCntExtendRefillTicks, refillCycles >> 4);
         addCounter(pool.counters, kCntExtendWaveTicks, static_cast<uint32_t>((clock64() - kernelStart) >> 4));
-    }
-}
-
-// ---- k_extend, two rays per lane (traverse_dual.h) ------------------------------------------------------
-// PTR_DUAL_PRIM_BIAS: a primitive step is taken once the lanes that could take one exceed 1/BIAS of the lanes that could take
-// a node step.  kRefillAt: a refill pass runs once this many of the wave's 128 ray register sets are empty.
-#ifndef PTR_DUAL_PRIM_BIAS
-#define PTR_DUAL_PRIM_BIAS 2
-#endif
-#ifndef PTR_DUAL_WAVES
-#define PTR_DUAL_WAVES 5
-#endif
-#define PTR_DUAL_ATTR __attribute__((amdgpu_waves_per_eu(PTR_DUAL_WAVES, PTR_DUAL_WAVES)))
-
-// One vote + exchange: decides the kind of this iteration's step and makes A the ray to step in every lane that has
-// one of that kind.  Returns (wave-uniform) whether it is a node step; `stepping` = this lane takes part.
-__device__ __forceinline__ bool dualVote(RayRegs& A, RayRegs& B, bool& stepping) {
-    const bool aLive = !rayIdle(A), bLive = !rayIdle(B);
-    const bool aLeaf = aLive && rayAtLeaf(A), bLeaf = bLive && rayAtLeaf(B);
-    const bool aNode = aLive && !aLeaf, bNode = bLive && !bLeaf;
-    const int nodeLanes = __popcll(__ballot(aNode | bNode));
-    const int primLanes = __popcll(__ballot(aLeaf | bLeaf));
-    const bool nodeStep = nodeLanes >= primLanes * PTR_DUAL_PRIM_BIAS;
-    const bool wantA = nodeStep ? aNode : aLeaf;
-    const bool wantB = nodeStep ? bNode : bLeaf;
-    const bool exchange = !wantA && wantB;
-    if (__ballot(exchange) != 0ull) {
-        if (exchange) swapRays(A, B);
-    }
-    stepping = wantA | wantB;
-    return nodeStep;
-}
-
-template <bool COUNT, bool QUANT>
-__global__ void __launch_bounds__(kTraceBlock) PTR_DUAL_ATTR k_extend_dual(SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride,
-                                                                            uint32_t* workCounter, int refillAt, uint32_t feederChunk, uint32_t* aliveOut) {
-    __shared__ uint32_t ldsStack[kDualLdsWords];
-    DualStack stack;
-    stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
-    stack.spill = spill;
-    stack.spillStride = spillStride;
-    TraceCounters cnt{0u, 0u};
-    uint32_t rays = 0u, aliveSeen = 0u, refills = 0u, voteIterations = 0u, activeLanes = 0u, leafLanes = 0u;
-
-    const SceneMem mem = sceneMem(sc);
-    WaveFeeder feeder;
-    feeder.init(workCounter, pool.slots, feederChunk);
-    RayRegs A, B;
-    A.cur = kRayIdle;
-    B.cur = kRayIdle;
-    A.column = 0u;
-    B.column = 1u;
-    A.sp = B.sp = 0u;
-    A.tag = B.tag = 0u;
-    A.tfar = B.tfar = 0.0f;
-    A.prim = B.prim = kHitMiss;
-    A.org = A.dir = A.inv = A.oi = mk3(0.0f);
-    B.org = B.dir = B.inv = B.oi = mk3(0.0f);
-    while (true) {
-        const int empty = __popcll(__ballot(rayIdle(A))) + __popcll(__ballot(rayIdle(B)));
-        if (empty >= refillAt && !feeder.exhausted) {
-            // refill pass: the idle register set of every lane that has one becomes B and receives a new ray (a lane with both
-            // sets empty gets its second ray in the next pass)
-            if (COUNT) ++refills;
-            const bool exchange = rayIdle(A) && !rayIdle(B);
-            if (__ballot(exchange) != 0ull) {
-                if (exchange) swapRays(A, B);
-            }
-            const uint32_t idx = feeder.take(rayIdle(B));
-            const uint32_t at = idx != WaveFeeder::kNone ? idx : 0u;
-            const float4 r0 = pool.ray0[at], r1 = pool.ray1[at];   // both in flight before the liveness test
-            const bool live = idx != WaveFeeder::kNone && (__float_as_uint(r1.w) & kFlagAlive);
-            aliveSeen += static_cast<uint32_t>(__popcll(__ballot(live)));   // wave-uniform: stays in an SGPR
-            if (live) {
-                if (COUNT) ++rays;
-                if (!rayBegin<QUANT>(sc, B, mk3(r0), mk3(r0.w, r1.x, r1.y), INFINITY, false, idx, stack)) {
-                    pool.hit[idx] = make_float2(INFINITY, __uint_as_float(kHitMiss));
-                }
-            }
-            continue;
-        }
-        if (empty == 128) break;
-        bool stepping;
-        const bool nodeStep = dualVote(A, B, stepping);
-        if (COUNT) {
-            ++voteIterations;
-            activeLanes += static_cast<uint32_t>(__popcll(__ballot(stepping)));
-            leafLanes += nodeStep ? 0u : static_cast<uint32_t>(__popcll(__ballot(stepping)));
-        }
-        bool more = true;
-        if (nodeStep) {
-            if (COUNT) ++cnt.waveNodeSteps;
-            if (stepping) more = rayNodeStep<QUANT, COUNT>(mem, A, kEps, stack, cnt);
-        } else {
-            if (COUNT) ++cnt.wavePrimSteps;
-            if (stepping) more = rayPrimStep<COUNT>(sc, mem, A, kEps, stack, cnt);
-        }
-        if (!more) pool.hit[A.tag] = make_float2(A.tfar, __uint_as_float(A.prim));
-    }
-    if (aliveOut) {
-        // one atomic per persistent wave: the host's termination check at the end of the frame
-        if (laneId() == 0 && aliveSeen != 0u) atomicAdd(aliveOut, aliveSeen);
-    }
-    if (COUNT) {
-        addCounter(pool.counters, kCntExtendRays, rays);
-        addCounter(pool.counters, kCntExtendNodes, cnt.nodes);
-        addCounter(pool.counters, kCntExtendPrims, cnt.prims);
-        addCounter(pool.counters, kCntExtendLeaves, cnt.leaves);
-        addCounter(pool.counters, kCntExtendWaveNodeSteps, cnt.waveNodeSteps);
-        addCounter(pool.counters, kCntExtendWavePrimSteps, cnt.wavePrimSteps);
-        addCounter(pool.counters, kCntExtendRefillPasses, refills);
-        addCounter(pool.counters, kCntExtendActiveLanes, activeLanes >> 6);
-        addCounter(pool.counters, kCntExtendLeafLanes, leafLanes >> 6);
-        addCounter(pool.counters, kCntExtendVoteIterations, voteIterations);
     }
 }
 
@@ -1705,31 +1583,20 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_connect(RenderP
     stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
     stack.spill = spill;
     stack.spillStride = spillStride;
+    stack.limit = sc.stackLimit;
     stack.sp = 0u;
     TraceCounters cnt{0u, 0u}, cntClosest{0u, 0u};
     uint32_t rays = 0u, raysClosest = 0u, early = 0u;
     const ClampCfg cc = clampCfg(rp);
 
-    // The work list is the slot pool itself: a lane takes a slot, reads its pending mask and resolves that
-    // slot's records one after another (no compaction queue -> no hot atomic counter in k_shade).
+    // The work is the connect list k_shade filled (PathPool::connectList): lane l reads the counter of sub-list l, a wave prefix sum
+    // gives every sub-list its place in one dense index space, and a lane finds the sub-list of an index with six cross-lane reads.
+    // (Round 1 probed every slot's pending byte instead: 3.5 slots per ray found on config 2, a third of the kernel's instructions.)
     SceneMem mem = sceneMem(sc);
-#if PTR_LDS_TOP > 0
-    __shared__ uint4 ldsTop[PTR_LDS_TOP * 2];
-    if (NODES == 1 && sc.nodeBytes >= PTR_LDS_TOP * 32u) {
-        for (uint32_t i = threadIdx.x; i < PTR_LDS_TOP * 2u; i += kTraceBlock) ldsTop[i] = sc.qnodes[i];
-        __syncthreads();
-        mem.top = ldsTop;
-    }
-#endif
-    // With a connect list (PathPool::connectList) the work is the list's entries: lane l reads the counter of sub-list l, a wave
-    // prefix sum gives every sub-list its place in one dense index space, and a lane finds the sub-list of an index with six
-    // cross-lane reads.  Measured before: 3.5 slots probed per ray found on config 2 (a third of the slots queue a record), more as
-    // the frame drains, and the probing passes were a third of the kernel's instructions.
-    const bool listed = pool.connectList != nullptr;
-    SubLists lists{0u, pool.slots};
-    if (listed) lists.init(pool.connectCount, pool.connectRegion);
+    SubLists lists;
+    lists.init(pool.connectCount, pool.connectRegion);
     WaveFeeder feeder;
-    feeder.init(workCounter, lists.total, listed ? 256u : feederChunk);
+    feeder.init(workCounter, lists.total, 256u);
     Trav t;
     t.cur = 0u;
     bool active = false;
@@ -1746,16 +1613,11 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_connect(RenderP
             // every idle lane.  Starting records lane by lane as they finish stalled the whole wave on each load.
             if (!feeder.exhausted) {
                 const uint32_t idx = feeder.take(!active && bits == 0u);
-                if (listed) {
-                    const uint32_t at = lists.position(idx != WaveFeeder::kNone ? idx : 0u, pool.connectRegion);
-                    if (idx != WaveFeeder::kNone) {
-                        const uint32_t entry = pool.connectList[at];
-                        mySlot = entry & ((1u << kConnectMaskShift) - 1u);
-                        bits = entry >> kConnectMaskShift;
-                    }
-                } else if (idx != WaveFeeder::kNone) {
-                    mySlot = idx;
-                    bits = pool.pending[idx] & kFlagPendingMask;
+                const uint32_t at = lists.position(idx != WaveFeeder::kNone ? idx : 0u, pool.connectRegion);
+                if (idx != WaveFeeder::kNone) {
+                    const uint32_t entry = pool.connectList[at];
+                    mySlot = entry & ((1u << kConnectMaskShift) - 1u);
+                    bits = entry >> kConnectMaskShift;
                 }
             }
             if (!active && bits != 0u) {
@@ -1807,110 +1669,6 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_connect(RenderP
     }
 }
 
-// k_connect with two rays per lane (traverse_dual.h).  A lane walks the records of one slot at a time (`bits`); each of its two
-// register sets carries the address of the record it is resolving.
-template <bool COUNT, bool QUANT>
-__global__ void __launch_bounds__(kTraceBlock) PTR_DUAL_ATTR k_connect_dual(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill,
-                                                                             uint32_t spillStride, uint32_t* workCounter, int refillAt,
-                                                                             uint32_t feederChunk) {
-    __shared__ uint32_t ldsStack[kDualLdsWords];
-    DualStack stack;
-    stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
-    stack.spill = spill;
-    stack.spillStride = spillStride;
-    TraceCounters cnt{0u, 0u}, cntClosest{0u, 0u};
-    uint32_t rays = 0u, raysClosest = 0u, early = 0u;
-    const ClampCfg cc = clampCfg(rp);
-
-    const SceneMem mem = sceneMem(sc);
-    WaveFeeder feeder;
-    feeder.init(workCounter, pool.slots, feederChunk);
-    RayRegs A, B;
-    A.cur = kRayIdle;
-    B.cur = kRayIdle;
-    A.column = 0u;
-    B.column = 1u;
-    A.sp = B.sp = 0u;
-    A.tag = B.tag = 0u;
-    A.tfar = B.tfar = 0.0f;
-    A.prim = B.prim = kHitMiss;
-    A.org = A.dir = A.inv = A.oi = mk3(0.0f);
-    B.org = B.dir = B.inv = B.oi = mk3(0.0f);
-    uint32_t mySlot = 0u, bits = 0u;
-    // the record arrays are one allocation: field f of record slot k lives at recBase[(k*4 + f)*slots + slot]
-    float4* const recBase = pool.rec[0].org;
-    const uint32_t slots = pool.recStride;   // field stride (whole pool), not the slot count of this group
-    while (true) {
-        const int empty = __popcll(__ballot(rayIdle(A))) + __popcll(__ballot(rayIdle(B)));
-        const bool lanesWithRecords = __ballot(bits != 0u && (rayIdle(A) || rayIdle(B))) != 0ull;
-        if (empty >= refillAt && (lanesWithRecords || !feeder.exhausted)) {
-            const bool exchange = rayIdle(A) && !rayIdle(B);
-            if (__ballot(exchange) != 0ull) {
-                if (exchange) swapRays(A, B);
-            }
-            if (!feeder.exhausted) {
-                const uint32_t idx = feeder.take(rayIdle(B) && bits == 0u);
-                if (idx != WaveFeeder::kNone) {
-                    mySlot = idx;
-                    bits = pool.pending[idx] & kFlagPendingMask;
-                }
-            }
-            if (rayIdle(B) && bits != 0u) {
-                const uint32_t rec = static_cast<uint32_t>(__ffs(static_cast<int>(bits))) - 1u;
-                bits &= bits - 1u;
-                const uint32_t recAt = rec * 4u * slots + mySlot;
-                const float4 o4 = recBase[recAt], d4 = recBase[recAt + slots];
-                const uint32_t kind = __float_as_uint(d4.w);
-                if (kind != 2u) {   // kind 2 (MNEE chains) is resolved by k_connect_chain
-                    if (COUNT) { if (kind == 0u) ++rays; else ++raysClosest; }
-                    if (!rayBegin<QUANT>(sc, B, mk3(o4), mk3(d4), kind == 0u ? o4.w : INFINITY, kind == 0u, recAt, stack)) {
-                        if (kind != 0u) recBase[recAt + 2u * slots] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    }
-                }
-            }
-            continue;
-        }
-        if (empty == 128) break;
-        bool stepping;
-        const bool nodeStep = dualVote(A, B, stepping);
-        bool more = true;
-        TraceCounters step{0u, 0u};
-        const bool any = rayAnyHit(A);
-        if (nodeStep) {
-            if (stepping) more = rayNodeStep<QUANT, COUNT>(mem, A, kEps, stack, step);
-        } else {
-            if (stepping) more = rayPrimStep<COUNT>(sc, mem, A, kEps, stack, step);
-        }
-        if (COUNT) {
-            // counting build: nodes/prims of closest-hit (kind 1) rays are booked with the extend counters
-            TraceCounters& dst = any ? cnt : cntClosest;
-            dst.nodes += step.nodes;
-            dst.prims += step.prims;
-        }
-        if (!more) {
-            float4* const a = recBase + A.tag + 2u * slots;
-            if (any) {
-                if (COUNT) early += (A.prim != kHitMiss) ? 1u : 0u;
-                if (A.prim != kHitMiss) *a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            } else {
-                const float4 a4 = *a;
-                const TraceHit h{A.tfar, A.prim};
-                const f3 c = rectContribution(rp, sc, cc, A.org, A.dir, h, mk3(a4), a4.w, mk3(recBase[A.tag + 3u * slots]));
-                *a = mk4(c, 0.0f);
-            }
-        }
-    }
-    if (COUNT) {
-        addCounter(pool.counters, kCntShadowRays, rays);
-        addCounter(pool.counters, kCntShadowNodes, cnt.nodes);
-        addCounter(pool.counters, kCntShadowPrims, cnt.prims);
-        addCounter(pool.counters, kCntShadowEarlyExit, early);
-        addCounter(pool.counters, kCntExtendRays, raysClosest);
-        addCounter(pool.counters, kCntExtendNodes, cntClosest.nodes);
-        addCounter(pool.counters, kCntExtendPrims, cntClosest.prims);
-    }
-}
-
 // MNEE two-bounce chains (record slot 4, kind 2; only launched when enableMnee && enableMneeSecondary).
 template <bool COUNT>
 __global__ void __launch_bounds__(kTraceBlock) k_connect_chain(RenderParams rp, SceneView sc, PathPool pool, uint32_t* spill, uint32_t spillStride) {
@@ -1920,6 +1678,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect_chain(RenderParams rp, 
     stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
     stack.spill = spill;
     stack.spillStride = spillStride;
+    stack.limit = sc.stackLimit;
     stack.sp = 0u;
     TraceCounters cnt{0u, 0u}, cntClosest{0u, 0u};
     uint32_t rays = 0u, raysClosest = 0u;
@@ -1995,6 +1754,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_tail_run(RenderParams rp, Scene
     stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
     stack.spill = spill;
     stack.spillStride = spillStride;
+    stack.limit = sc.stackLimit;
     stack.sp = 0u;
     const ClampCfg cc = clampCfg<SSS>(rp);
     TraceCounters cntExtend{0u, 0u}, cntAny{0u, 0u}, cntClosest{0u, 0u};
@@ -2141,6 +1901,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_aovs(RenderParams rp, SceneView
     stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
     stack.spill = spill;
     stack.spillStride = spillStride;
+    stack.limit = sc.stackLimit;
     TraceCounters cnt{0u, 0u};
     const uint32_t pixels = rp.width * rp.height;
     for (uint32_t pixel = gtid; pixel < pixels; pixel += gridDim.x * kTraceBlock) {
@@ -2176,6 +1937,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace_rays(SceneView sc, const 
     stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
     stack.spill = spill;
     stack.spillStride = spillStride;
+    stack.limit = sc.stackLimit;
     TraceCounters cnt{0u, 0u};
     for (uint64_t i = gtid; i < n; i += static_cast<uint64_t>(gridDim.x) * kTraceBlock) {
         const float4 a = rays[i * 2u], b = rays[i * 2u + 1u];
@@ -2283,7 +2045,6 @@ static inline uint32_t ceilDiv(uint64_t a, uint32_t b) { return static_cast<uint
 // bvh_layout.h): same number of resident threads, so the spill area and its stride are unchanged.
 static inline LaunchConfig perBlockSize(LaunchConfig cfg) {
     cfg.traceGrid *= kTraceGridUnit / kTraceBlock;
-    cfg.dualGrid *= kTraceGridUnit / kTraceBlock;
     return cfg;
 }
 
@@ -2293,21 +2054,6 @@ void launchGenerate(const RenderParams& rp, const PathPool& pool, hipStream_t st
 
 void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig& cfgIn, uint32_t* aliveOut, bool count, hipStream_t stream) {
     const LaunchConfig cfg = perBlockSize(cfgIn);
-    if (cfg.dual) {
-        // two rays per lane: PTR_DUAL_WAVES blocks per CU are resident, each thread owns two spill columns
-        const uint32_t stride = cfg.dualGrid * kTraceBlock * 2u;
-        const uint32_t grid = std::min(cfg.dualGrid, ceilDiv(pool.slots, kTraceBlock));
-        auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kTraceBlock), 0, stream, sc, pool, cfg.spill, stride, cfg.workCounters, cfg.dualRefillAt,
-                               cfg.feederChunk, aliveOut);
-        };
-        if (count) {
-            if (sc.useQuantized) launch(k_extend_dual<true, true>); else launch(k_extend_dual<true, false>);
-        } else {
-            if (sc.useQuantized) launch(k_extend_dual<false, true>); else launch(k_extend_dual<false, false>);
-        }
-        return;
-    }
     const uint32_t stride = cfg.traceGrid * kTraceBlock;
     const uint32_t grid = std::min(cfg.traceGrid, ceilDiv(pool.slots, kTraceBlock));
     // the live-slot count is a separate instantiation so the common launch carries no extra register
@@ -2319,7 +2065,7 @@ void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig&
     // counting build keeps the run-time flag
     if (count) {
         if (aliveOut) launch(k_extend<true, true, -1>); else launch(k_extend<true, false, -1>);
-    } else if (sc.useQuantized && sc.useWide && !PTR_POSTPONE_LEAVES) {   // (the postponed-leaf variant knows the binary step only)
+    } else if (sc.useQuantized && sc.useWide) {
         if (aliveOut) launch(k_extend<false, true, 2>); else launch(k_extend<false, false, 2>);
     } else if (sc.useQuantized) {
         if (aliveOut) launch(k_extend<false, true, 1>); else launch(k_extend<false, false, 1>);
@@ -2348,26 +2094,15 @@ void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& po
 
 void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfgIn, bool count, hipStream_t stream) {
     const LaunchConfig cfg = perBlockSize(cfgIn);
-    if (cfg.dual) {
-        const uint32_t stride = cfg.dualGrid * kTraceBlock * 2u;
-        auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(cfg.dualGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1,
-                               cfg.dualRefillAt, cfg.feederChunk);
-        };
-        if (count) {
-            if (sc.useQuantized) launch(k_connect_dual<true, true>); else launch(k_connect_dual<true, false>);
-        } else {
-            if (sc.useQuantized) launch(k_connect_dual<false, true>); else launch(k_connect_dual<false, false>);
-        }
-    } else {
-        const uint32_t stride = cfg.traceGrid * kTraceBlock;
+    const uint32_t stride = cfg.traceGrid * kTraceBlock;
+    {
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride, cfg.workCounters + 1,
                                cfg.refillBelow, cfg.feederChunk);
         };
         if (count) {
             launch(k_connect<true, -1>);
-        } else if (sc.useQuantized && sc.useWide && !PTR_POSTPONE_LEAVES) {
+        } else if (sc.useQuantized && sc.useWide) {
             launch(k_connect<false, 2>);
         } else if (sc.useQuantized) {
             launch(k_connect<false, 1>);
@@ -2375,7 +2110,6 @@ void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& 
             launch(k_connect<false, 0>);
         }
     }
-    const uint32_t stride = cfg.traceGrid * kTraceBlock;
     if (rp.enableMnee && rp.enableMneeSecondary) {
         if (count) {
             hipLaunchKernelGGL(k_connect_chain<true>, dim3(cfg.traceGrid), dim3(kTraceBlock), 0, stream, rp, sc, pool, cfg.spill, stride);

@@ -505,8 +505,8 @@ def test_partition_and_pool_size_invariance(cornell_small):
 
 
 def test_scheduling_knobs_do_not_change_the_image():
-    # How the work is scheduled - pool groups, persistent grid, the connect list, the busy lists at the end of the frame, the
-    # end-of-frame kernels, the pool size - must not show in the result: same image bit for bit, same ray and hit counters.
+    # How the work is scheduled - pool groups, the end-of-frame kernels, the pool size, the node format, the order k_shade visits
+    # the slots of a block in - must not show in the result: same image bit for bit, same ray and hit counters.
     # 1080p x 12 spp = 25 M work items: a 12 Mi-slot pool in 4 groups, large enough for every mechanism to engage.
     host = pt.HostScene.load(os.path.join(SCENES, "cornell_mesh.scene"), SCENES)
     s = host.settings_for(width=1920, height=1080, max_depth=8, seed=1337)
@@ -525,9 +525,14 @@ def test_scheduling_knobs_do_not_change_the_image():
 
     base, base_counts = render({})
     assert np.isfinite(base).all() and base.mean() > 0.01 and base_counts[4] == 1920 * 1080 * 12
-    for env in ({"PTR_CONNECT_LIST": "0"}, {"PTR_BUSY_LISTS": "0"}, {"PTR_POOL_GROUPS": "1"}, {"PTR_TRACE_BLOCKS_PER_CU": "8"},
-                {"PTR_TAIL_BELOW": "0"}, {"PTR_POOL_SLOTS": str(3 << 20), "PTR_REFILL_BELOW": "24"},
-                {"PTR_WIDE_NODES": "0"}):   # the binary walk instead of the four-wide nodes (same tree, one level at a time)
+    # every environment variable the library reads (csrc/host/knobs.h) appears here
+    for env in ({"PTR_POOL_GROUPS": "1"}, {"PTR_TAIL_BELOW": "0"}, {"PTR_POOL_SLOTS": str(3 << 20), "PTR_REFILL_BELOW": "24"},
+                {"PTR_WIDE_NODES": "0"},        # the binary walk instead of the four-wide nodes (same tree, one level at a time)
+                {"PTR_QUANTIZED_NODES": "0"},   # 64 B float nodes (box tests only prune: the hits are the same)
+                {"PTR_SHADE_SORT": "0"},        # k_shade visits the slots where they lie instead of sorted by material within a block
+                {"PTR_MAX_ITEMS": str(1920 * 1080 * 12)},   # the whole frame still fits one pass
+                {"PTR_BUILD_THREADS": "3", "PTR_VERBOSE": "build"},   # same tree from any number of builder threads
+                {"PTR_NO_OVERSIZE": "1"}):      # (this scene keeps every triangle in the tree anyway)
         image, counts = render(env)
         assert np.array_equal(image, base), env
         assert counts == base_counts, env

@@ -74,3 +74,32 @@ def test_jpeg_baseline_against_pillow():
     Image.fromarray(img, "RGB").save(buf, "JPEG", progressive=True)
     with pytest.raises(pt.PtrError, match="progressive"):
         pt.decode_image(buf.getvalue())
+
+
+def test_decoders_survive_hostile_files():
+    import struct
+    import zlib
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+
+    # an 8x8 RGB header whose IDAT stream expands to 64 MB of zeros (a few dozen KB compressed): refused at the size the image needs
+    bomb = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 8, 8, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(64 << 20), 9)) +
+            chunk(b"IEND", b""))
+    with pytest.raises(pt.PtrError):
+        pt.decode_image(bomb)
+    # every prefix of a valid PNG and of a valid JPEG is either decoded or refused with a message - never a crash
+    png = _png(np.arange(16 * 16 * 3, dtype=np.uint8).reshape(16, 16, 3), "RGB")
+    buf = io.BytesIO()
+    Image.fromarray(np.arange(24 * 24 * 3, dtype=np.uint8).reshape(24, 24, 3), "RGB").save(buf, "JPEG", quality=80)
+    jpeg = buf.getvalue()
+    for data in (png, jpeg):
+        for cut in range(0, len(data), 7):
+            try:
+                pt.decode_image(data[:cut])
+            except pt.PtrError:
+                pass
+    # a JPEG that ends on a scan header of length 2 (no component count behind it)
+    sos = jpeg.index(b"\xff\xda")
+    with pytest.raises(pt.PtrError):
+        pt.decode_image(jpeg[:sos] + b"\xff\xda\x00\x02")

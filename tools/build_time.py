@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host-side preparation time of a scene (no GPU work): parse + load, then world-space bake + BVH build + leaf-order arrays through
-ptr_debug_scene_geometry, with the builder's own phase timings (PTR_BUILD_VERBOSE).   python tools/build_time.py [scene] [repeats]"""
+ptr_debug_scene_geometry, with the builder's own phase timings (PTR_VERBOSE=build).   python tools/build_time.py [scene] [repeats]"""
 import importlib
 import os
 import re
@@ -9,7 +9,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["PTR_BUILD_VERBOSE"] = "1"
+os.environ["PTR_VERBOSE"] = "build"
 pt = importlib.import_module("metal-pathtracer-arm64_amd")
 from scenes.gen_assets import ensure_assets, ensure_large_asset
 

@@ -3,7 +3,7 @@
 
   PTR_POOL_GROUPS=1 python tools/launch_timeline.py [--parts 8] [--spp 256] [--scene scenes/cornell_mesh.scene]
 
-Renders partition 0 of `--parts` (what one rank of that many does) with PTR_TRACE_ITERATIONS set, so the library prints
+Renders partition 0 of `--parts` (what one rank of that many does) with PTR_VERBOSE=polls,launches set, so the library prints
 one "[launch] kind K start S end E" line per kernel (kind 0 extend, 1 shade, 2 connect; ms from the first launch) to
 stderr, then summarises them per iteration.  With one pool group the three kernels of an iteration are consecutive; with
 several groups the lines of the groups interleave.
@@ -29,7 +29,7 @@ def child(args):
     rows = bands.max_band_count(s.height, args.parts) * bands.BAND_ROWS
     out = torch.zeros((rows, s.width, 3), dtype=torch.float32, device="cuda")
     scene.render_device(s, args.spp, out.data_ptr(), 0, 0, args.parts, want_stats=False)   # warm-up
-    os.environ["PTR_TRACE_ITERATIONS"] = "1"
+    os.environ["PTR_VERBOSE"] = "polls,launches"
     st = scene.render_device(s, args.spp, out.data_ptr(), 0, 0, args.parts, want_stats=True)
     print("total %.3f ms" % (st.totalSeconds * 1e3))
 

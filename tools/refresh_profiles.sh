@@ -19,14 +19,14 @@ solo)
 from scenes.gen_assets import ensure_assets, ensure_large_asset
 ensure_assets(); ensure_large_asset('lucy_standin_28005128.ply'); ensure_large_asset('blob_1002528.ply')"
   bash tools/measure_solo.sh solo_cfg2_$TAG > gpurun_out/solo_cfg2_$TAG.log 2>&1 && cp gpurun_out/solo_cfg2_$TAG.json profiles/r2_solo_cfg2.json
-  PTR_BUILD_VERBOSE=1 bash tools/measure_solo.sh solo_cfg5_$TAG $CFG5 > gpurun_out/solo_cfg5_$TAG.log 2>&1 && cp gpurun_out/solo_cfg5_$TAG.json profiles/r2_solo_cfg5.json
+  PTR_VERBOSE=build bash tools/measure_solo.sh solo_cfg5_$TAG $CFG5 > gpurun_out/solo_cfg5_$TAG.log 2>&1 && cp gpurun_out/solo_cfg5_$TAG.json profiles/r2_solo_cfg5.json
   timeout -k 10 300 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
   cut -c1-300 gpurun_out/bench_$TAG.json
   (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1)
   find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -delete
   ;;
 configs)
-  PTR_BUILD_VERBOSE=1 timeout -k 10 1000 python tools/full_configs.py --configs 2,3,4,5 --out gpurun_out/full_configs_$TAG.json > gpurun_out/full_configs_$TAG.log 2>&1
+  PTR_VERBOSE=build timeout -k 10 1000 python tools/full_configs.py --configs 2,3,4,5 --out gpurun_out/full_configs_$TAG.json > gpurun_out/full_configs_$TAG.log 2>&1
   tail -5 gpurun_out/full_configs_$TAG.log
   ;;
 rest)

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""Lane-utilisation bookkeeping of k_extend (counting build, library env PTR_TRACE_STEPS) for one scene:
-    python tools/steps_probe.py [scene] [spp]        (knobs such as PTR_TRAVERSAL / PTR_DUAL_REFILL_AT come from the environment)"""
+"""Lane-utilisation bookkeeping of k_extend (counting build, library env PTR_VERBOSE=steps) for one scene:
+    python tools/steps_probe.py [scene] [spp]        (knobs such as PTR_POOL_GROUPS come from the environment)"""
 import importlib
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["PTR_TRACE_STEPS"] = "1"
+os.environ["PTR_VERBOSE"] = "steps"
 pt = importlib.import_module("metal-pathtracer-arm64_amd")
 from scenes.gen_assets import ensure_assets
 
