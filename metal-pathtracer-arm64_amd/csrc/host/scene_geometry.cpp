@@ -98,10 +98,10 @@ void parallelFor(size_t n, const std::function<void(size_t, size_t)>& body) {
 
 // Writes one triangle (input order) into the 12-float records and its padded bounds.
 void storeTri(float* tri, float* nrm, BuildPrim& prim, const float3& v0, const float3& v1, const float3& v2, const float3& n0,
-              const float3& n1, const float3& n2, uint32_t material, uint32_t kind, uint32_t geomIndex, uint32_t primIndex) {
+              const float3& n1, const float3& n2, uint32_t material, uint32_t shadeKey, uint32_t kind, uint32_t geomIndex, uint32_t primIndex) {
     const float3 e1 = v0 - v1, e2 = v2 - v0;
     tri[0] = v0.x, tri[1] = v0.y, tri[2] = v0.z, tri[3] = bitsToFloat(material);
-    tri[4] = e1.x, tri[5] = e1.y, tri[6] = e1.z, tri[7] = bitsToFloat((kind << 30) | (geomIndex & 0x3FFFFFFFu));
+    tri[4] = e1.x, tri[5] = e1.y, tri[6] = e1.z, tri[7] = bitsToFloat((kind << 30) | ((shadeKey & ptrk::kHitKeyMask) << ptrk::kHitKeyShift) | (geomIndex & ptrk::kTriGeomMask));
     tri[8] = e2.x, tri[9] = e2.y, tri[10] = e2.z, tri[11] = bitsToFloat(primIndex);
     nrm[0] = n0.x, nrm[1] = n0.y, nrm[2] = n0.z, nrm[3] = 0.0f;
     nrm[4] = n1.x, nrm[5] = n1.y, nrm[6] = n1.z, nrm[7] = 0.0f;
@@ -135,6 +135,16 @@ bool BuildSceneGeometry(const PtrSceneDesc& desc, uint32_t leafMax, SceneGeometr
         error = "scene exceeds 64M primitives";
         return false;
     }
+    if (desc.meshCount > ptrk::kTriGeomMask) {
+        error = "scene exceeds 64M meshes";
+        return false;
+    }
+    // shade key of a primitive (kernels/bvh_layout.h): material type + 1, what k_shade sorts the slots of a block by
+    auto shadeKeyOf = [&](uint32_t material) -> uint32_t {
+        if (desc.materialCount == 0u || desc.materials == nullptr) return 0u;
+        const uint32_t type = static_cast<uint32_t>(desc.materials[std::min(material, desc.materialCount - 1u)].typeEta[0]);
+        return std::min(type, 7u) + 1u;
+    };
     const uint32_t triCount = static_cast<uint32_t>(triTotal);
     std::vector<float> triIn(static_cast<size_t>(triCount) * 12), nrmIn(static_cast<size_t>(triCount) * 12);
     std::vector<BuildPrim> prims(static_cast<size_t>(triCount) + desc.sphereCount);
@@ -184,7 +194,7 @@ bool BuildSceneGeometry(const PtrSceneDesc& desc, uint32_t leafMax, SceneGeometr
                 }
                 const size_t k = base + t;
                 storeTri(&triIn[k * 12], &nrmIn[k * 12], prims[k], pos[i0], pos[i1], pos[i2], nrm[i0], nrm[i1], nrm[i2],
-                         mesh.materialIndex, 0u, mi, static_cast<uint32_t>(t));
+                         mesh.materialIndex, shadeKeyOf(mesh.materialIndex), 0u, mi, static_cast<uint32_t>(t));
                 if (textured) {
                     const uint32_t vi[3] = {i0, i1, i2};
                     float* uv = &uvIn[k * 16];
@@ -254,7 +264,7 @@ bool BuildSceneGeometry(const PtrSceneDesc& desc, uint32_t leafMax, SceneGeometr
         for (int half = 0; half < 2; ++half) {
             const size_t k = cursor++;
             storeTri(&triIn[k * 12], &nrmIn[k * 12], prims[k], p[o[half * 3]], p[o[half * 3 + 1]], p[o[half * 3 + 2]], n, n, n,
-                     r.materialTwoSided[0], 2u, ri, ri * 2u + static_cast<uint32_t>(half));
+                     r.materialTwoSided[0], shadeKeyOf(r.materialTwoSided[0]), 2u, ri, ri * 2u + static_cast<uint32_t>(half));
         }
     }
     for (uint32_t si = 0; si < desc.sphereCount; ++si) {

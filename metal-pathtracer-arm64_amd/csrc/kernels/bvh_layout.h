@@ -25,7 +25,15 @@ constexpr uint32_t kLdsStackLevels = 16u;        // stack levels kept in LDS; de
 #endif
 constexpr uint32_t kTraceBlock = PTR_TRACE_BLOCK;   // threads per block of the traversal kernels
 constexpr uint32_t kTraceGridUnit = 256u;           // the host sizes traversal grids (and the spill area) in units of this many threads
+// Hit word of a traced ray: kHitMiss, or  bit31 = sphere | bits 26..29 = shade key | bits 0..25 = leaf-order primitive index.
+// The shade key (0 = not known here, else material type + 1) rides in the triangle record (bits 26..29 of t[1].w, next to kind and
+// geometry index) and is copied into the hit word by the primitive test that accepts the hit: k_shade sorts the slots of a block
+// by it before shading them (wavefront.hip, k_shade_sorted) without a dependent fetch.
 constexpr uint32_t kHitMiss = 0xFFFFFFFFu;
 constexpr uint32_t kHitSphereBit = 0x80000000u;
+constexpr uint32_t kHitKeyShift = 26u;
+constexpr uint32_t kHitKeyMask = 0xFu;
+constexpr uint32_t kHitIndexMask = kRefOffsetMask;
+constexpr uint32_t kTriGeomMask = (1u << kHitKeyShift) - 1u;   // geometry index field of t[1].w
 
 }  // namespace ptrk

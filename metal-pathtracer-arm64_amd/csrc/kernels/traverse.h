@@ -344,7 +344,7 @@ __device__ __forceinline__ bool travPrimStep(const SceneView& sc, const SceneMem
         float tt, u, v;
         if (triangleTest(mk3(a), mk3(b), mk3(c), t.org, t.dir, t.tnear, t.hit.t, tt, u, v)) {
             t.hit.t = tt;
-            t.hit.prim = index;
+            t.hit.prim = index | (__float_as_uint(b.w) & (kHitKeyMask << kHitKeyShift));   // the triangle's shade key rides along
             if (t.anyHit) return false;
         }
     }

@@ -350,6 +350,7 @@ struct Surface {
 __device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 dir, float t, uint32_t prim) {
     Surface s;
     s.t = t;
+    prim &= kHitSphereBit | kHitIndexMask;   // (the shade key in bits 26..29 is k_shade's business)
     s.prim = prim;
     s.bu = 0.0f;
     s.bv = 0.0f;
@@ -387,7 +388,7 @@ __device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 d
     if ((meta >> 30) == 0u) {
         s.primType = 0u;
         s.primIndex = __float_as_uint(c.w);
-        s.geomIndex = meta & 0x3FFFFFFFu;
+        s.geomIndex = meta & kTriGeomMask;
         float u, v;   // the traversal kernels store distance and primitive only
         triangleUv(mk3(a), mk3(b), mk3(c), org, dir, u, v);
         s.bu = u;
@@ -400,7 +401,7 @@ __device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 d
         }
     } else {
         s.primType = 2u;
-        s.primIndex = meta & 0x3FFFFFFFu;
+        s.primIndex = meta & kTriGeomMask;
         shading = mk3(n0);
         if (dot(shading, adjusted) < 0.0f) shading = -shading;
         s.twoSided = __float_as_uint(sc.rects[static_cast<size_t>(s.primIndex) * 5u + 4u].y) != 0u;
@@ -791,6 +792,65 @@ __device__ __forceinline__ bool applyPbrTextures(const SceneView& sc, const Surf
 #endif
 // (the instantiation with the Metal-only subsurface / PBR models runs at 4 waves too)
 #define PTR_SHADE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SSS ? 4 : PTR_SHADE_WAVES, SSS ? 4 : PTR_SHADE_WAVES)))
+// Work items for the lanes of a converged wave whose lane l holds slot 64 w + l (dense k_shade; the claim pass of k_shade_sorted).
+// Each wave holds a reservation of kItemReserve consecutive items in HBM and refills it with ONE atomic on one of kItemHeads range
+// heads (a per-lane or even per-wave-per-bounce atomic on one address caps at ~88 ops/us chip-wide; so does one shared head once
+// items are single samples).  Returns the lane's item, or rp.itemCount when it wanted none / none is left.  Must be called by all
+// 64 lanes.
+__device__ __forceinline__ uint32_t claimItems(const RenderParams& rp, const PathPool& pool, const uint32_t slot, const bool needItem) {
+    const unsigned long long mask = __ballot(needItem);
+    if (mask == 0ull) return rp.itemCount;
+    const uint32_t waveId = slot / 64u;     // slot >= pool.slots lanes never need items
+    const uint32_t firstLane = static_cast<uint32_t>(__ffsll(static_cast<long long>(mask))) - 1u;
+    uint2 res = pool.itemReserve[__builtin_amdgcn_readfirstlane(waveId)];
+    const uint32_t resOld = res.x;
+    const uint32_t n = static_cast<uint32_t>(__popcll(mask));
+    const uint32_t avail = res.y - res.x;
+    uint32_t newBase = rp.itemCount, newEnd = rp.itemCount;   // "no items": ids >= itemCount are rejected by the caller
+    if (avail < n) {
+        // The wave keeps drawing from the range of its last reservation (initially range waveId % kItemHeads)
+        // and moves on to the next range when that one is exhausted; a wave that finds all of them exhausted
+        // raises the "dry" word so nobody else has to go round again.  Heads sit kItemHeadStride words apart:
+        // same-LINE atomics serialise just like same-address ones.
+        const uint32_t wid = __builtin_amdgcn_readfirstlane(waveId);
+        uint32_t head = (res.y > rp.itemHeadFirst && rp.itemsPerHead > 0u) ? (res.y - 1u - rp.itemHeadFirst) / rp.itemsPerHead : wid % kItemHeads;
+        head = min(head, kItemHeads - 1u);
+        uint32_t* const dry = pool.nextItem + kItemHeads * kItemHeadStride;
+        bool found = false;
+        if (rp.itemsPerHead > 0u && __builtin_amdgcn_readfirstlane(*dry) == 0u) {
+            for (uint32_t tries = 0; tries < kItemHeads && !found; ++tries) {
+                const uint32_t headEnd = min(rp.itemHeadFirst + (head + 1u) * rp.itemsPerHead, rp.itemCount);
+                uint32_t* const counter = pool.nextItem + head * kItemHeadStride;
+                uint32_t base = headEnd;
+                if (laneId() == firstLane && *counter < headEnd) base = atomicAdd(counter, kItemReserve);
+                base = __shfl(base, static_cast<int>(firstLane), 64);
+                if (base < headEnd) {
+                    newBase = base;
+                    newEnd = min(base + kItemReserve, headEnd);
+                    found = true;
+                } else {
+                    head = (head + 1u) % kItemHeads;
+                }
+            }
+            if (!found && laneId() == firstLane) *dry = 1u;
+        }
+    }
+    const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << laneId()) - 1ull)));
+    // lanes beyond the old reservation and the fresh one get no item (id = itemCount): only when every range is
+    // exhausted, or for the last few items of the frame (ranges are multiples of kItemReserve, only the final
+    // one is clipped)
+    const uint32_t fresh = newEnd - newBase;   // 0 when every range is exhausted
+    const uint32_t claimed = (rank < avail) ? (resOld + rank) : ((rank - avail < fresh) ? newBase + (rank - avail) : rp.itemCount);
+    if (avail < n) {
+        res.x = newBase + min(n - avail, fresh);
+        res.y = newEnd;
+    } else {
+        res.x += n;
+    }
+    if (laneId() == firstLane) pool.itemReserve[waveId] = res;
+    return needItem ? claimed : rp.itemCount;
+}
+
 // SSS: the instantiation with the Metal subsurface semantics (launched when PTR_METAL_SSS is set)
 struct ShadeCounts {
     uint32_t shadedHit = 0u, triHit = 0u, primary = 0u;   // counting build
@@ -802,24 +862,27 @@ struct ShadeCounts {
 // work items are claimed lane by lane.  kShadeTail: the caller is the end-of-frame kernel (k_tail_run), whose lanes hold arbitrary
 // slots AND diverge - nothing in here may then rely on the wave (no ballots, no list appends).
 // `listWave`: which sub-list this wave appends to (wave-uniform; unused in kShadeTail).
-constexpr int kShadeDense = 0, kShadeListed = 1, kShadeTail = 2;
+constexpr int kShadeDense = 0, kShadeListed = 1, kShadeTail = 2, kShadeSorted = 3;
+// kShadeSorted: the caller is k_shade_sorted - the lanes of the (converged) wave hold slots of the block's 256-slot window in the order
+// of their shading keys; work items are claimed afterwards by the slot's own thread, so a finished path is left dead here.
+// Returns the slot's new flags word, bit 31 set when the slot wants a new work item (0 for a slot that was not touched).
 // TEX (only with SSS): the scene has material textures - the per-hit texture lookups and the path's ray cone are compiled in.  A
 // separate instantiation because they cost registers whether or not a scene uses them: with the texture code in, the Metal-model
 // kernel drops to 3 waves/SIMD and untextured Metal-semantics scenes ran 19-25 % slower than in round 1.
 template <bool COUNT, bool SSS, bool TEX, int MODE>
-__device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const uint32_t slot, const bool inRange,
-                                          const bool drained, const uint32_t listWave, ShadeCounts& counts) {
+__device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const uint32_t slot, const bool inRange,
+                                              const bool drained, const uint32_t listWave, ShadeCounts& counts) {
     constexpr bool TAIL = MODE == kShadeTail;
     // Everything that depends only on the slot index is requested up front, and the record loads are pointed at a
     // zero word when the record is not pending, so the kernel has ~11 loads in flight per lane after ONE dependent
     // step (the state word) instead of walking a chain of ten load-wait pairs at 5 waves per SIMD.
     const uint32_t at = inRange ? slot : 0u;
     float4 ray1v = pool.ray1[at];
-    if (!TAIL && drained) {
+    if (!TAIL && MODE != kShadeSorted && drained) {
         // end of the frame: most waves cover 64 dead slots, and the loads below would still stream 56 B per slot
         const uint32_t peek = __float_as_uint(ray1v.w);
         const bool busy = inRange && (peek & (kFlagAlive | kFlagFlush | (kFlagPendingMask << kFlagPendingShift))) != 0u;
-        if (__ballot(busy) == 0ull) return;
+        if (__ballot(busy) == 0ull) return 0u;
     }
     const float4 ray0v = pool.ray0[at];
     const float2 hitv = pool.hit[at];
@@ -1298,7 +1361,9 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
 
     if (COUNT) counts.stage[8] += needItem ? 1u : 0u;
     // ---- claim new work items ----
-    if (MODE != kShadeDense) {
+    if (MODE == kShadeSorted) {
+        // the slot's own thread claims after the sorted pass (k_shade_sorted): the path is left dead here
+    } else if (MODE != kShadeDense) {
         // end of the frame: the range heads are dry; what can be left is the unused part of the last reservation of this slot's
         // 64-slot group (csrc/host/hip_backend.cpp hands a group to the tail kernel only after the heads ran dry)
         if (needItem) {
@@ -1315,68 +1380,13 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
             }
         }
     } else {
-    // Each wave holds a reservation of kItemReserve consecutive items in HBM and refills it with ONE atomic on one of
-    // kItemHeads range heads (a per-lane or even per-wave-per-bounce atomic on one address caps at ~88 ops/us
-    // chip-wide; so does one shared head once items are single samples).
-    {
-        const unsigned long long mask = __ballot(needItem);
-        if (mask != 0ull) {
-            const uint32_t waveId = slot / 64u;     // slot >= pool.slots lanes never need items
-            const uint32_t firstLane = static_cast<uint32_t>(__ffsll(static_cast<long long>(mask))) - 1u;
-            uint2 res = pool.itemReserve[__builtin_amdgcn_readfirstlane(waveId)];
-            const uint32_t resOld = res.x;
-            const uint32_t n = static_cast<uint32_t>(__popcll(mask));
-            const uint32_t avail = res.y - res.x;
-            uint32_t newBase = rp.itemCount, newEnd = rp.itemCount;   // "no items": ids >= itemCount are rejected below
-            if (avail < n) {
-                // The wave keeps drawing from the range of its last reservation (initially range waveId % kItemHeads)
-                // and moves on to the next range when that one is exhausted; a wave that finds all of them exhausted
-                // raises the "dry" word so nobody else has to go round again.  Heads sit kItemHeadStride words apart:
-                // same-LINE atomics serialise just like same-address ones.
-                const uint32_t wid = __builtin_amdgcn_readfirstlane(waveId);
-                uint32_t head = (res.y > rp.itemHeadFirst && rp.itemsPerHead > 0u) ? (res.y - 1u - rp.itemHeadFirst) / rp.itemsPerHead : wid % kItemHeads;
-                head = min(head, kItemHeads - 1u);
-                uint32_t* const dry = pool.nextItem + kItemHeads * kItemHeadStride;
-                bool found = false;
-                if (rp.itemsPerHead > 0u && __builtin_amdgcn_readfirstlane(*dry) == 0u) {
-                    for (uint32_t tries = 0; tries < kItemHeads && !found; ++tries) {
-                        const uint32_t headEnd = min(rp.itemHeadFirst + (head + 1u) * rp.itemsPerHead, rp.itemCount);
-                        uint32_t* const counter = pool.nextItem + head * kItemHeadStride;
-                        uint32_t base = headEnd;
-                        if (laneId() == firstLane && *counter < headEnd) base = atomicAdd(counter, kItemReserve);
-                        base = __shfl(base, static_cast<int>(firstLane), 64);
-                        if (base < headEnd) {
-                            newBase = base;
-                            newEnd = min(base + kItemReserve, headEnd);
-                            found = true;
-                        } else {
-                            head = (head + 1u) % kItemHeads;
-                        }
-                    }
-                    if (!found && laneId() == firstLane) *dry = 1u;
-                }
-            }
-            const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << laneId()) - 1ull)));
-            // lanes beyond the old reservation and the fresh one get no item (id = itemCount): only when every range is
-            // exhausted, or for the last few items of the frame (ranges are multiples of kItemReserve, only the final
-            // one is clipped)
-            const uint32_t fresh = newEnd - newBase;   // 0 when every range is exhausted
-            const uint32_t claimed = (rank < avail) ? (resOld + rank) : ((rank - avail < fresh) ? newBase + (rank - avail) : rp.itemCount);
-            if (avail < n) {
-                res.x = newBase + min(n - avail, fresh);
-                res.y = newEnd;
-            } else {
-                res.x += n;
-            }
-            if (laneId() == firstLane) pool.itemReserve[waveId] = res;
-            if (needItem && claimed < rp.itemCount) {
-                item = claimed;
-                beginSample(rp, pool.pixelOfLocal[claimed % rp.localPixels], claimed / rp.localPixels, rng, nextO, nextD);
-                stillAlive = true;
-                newSample = true;
-            }
+        const uint32_t claimed = claimItems(rp, pool, slot, needItem);
+        if (needItem && claimed < rp.itemCount) {
+            item = claimed;
+            beginSample(rp, pool.pixelOfLocal[claimed % rp.localPixels], claimed / rp.localPixels, rng, nextO, nextD);
+            stillAlive = true;
+            newSample = true;
         }
-    }
     }
 
     // light connections of this bounce: k_connect walks the slots and reads the pending mask
@@ -1385,10 +1395,12 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
     for (uint32_t k = 0; k < kRecSlots; ++k) {
         if (want[k]) pendingMask |= 1u << k;
     }
+    uint32_t newFlags = 0u;
     if (touched) {
         const uint32_t flags = (stillAlive ? kFlagAlive : 0u) | (lastDelta ? kFlagLastDelta : 0u) | (flushNext ? kFlagFlush : 0u) |
                                (walkFlag ? kFlagWalk : 0u) | (depth << kFlagDepthShift) | (specDepth << kFlagSpecDepthShift) |
                                (mediumDepth << kFlagMediumShift) | (pendingMask << kFlagPendingShift);
+        newFlags = flags;
         pool.ray1[slot] = make_float4(nextD.y, nextD.z, lastPdf, __uint_as_float(flags));
         pool.accum[slot] = mk4(acc, __uint_as_float(item));
         if (pendingMask != 0u || pendingIn != 0u) pool.pending[slot] = static_cast<uint8_t>(pendingMask);
@@ -1414,7 +1426,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
         }
     }
 
-    if (!TAIL && pool.busyOut) {
+    if (!TAIL && MODE != kShadeSorted && pool.busyOut) {
         // end of the frame: the slots the next iteration has to visit (same scheme)
         const bool busy = touched && (stillAlive || pendingMask != 0u || flushNext);
         const unsigned long long mask = __ballot(busy);
@@ -1433,6 +1445,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
         counts.triHit += triHit;
         counts.primary += primary;
     }
+    return touched ? (newFlags | (needItem && !stillAlive ? 0x80000000u : 0u)) : 0u;
 }
 
 // LISTED: the launch walks pool.busyIn instead of the slots (end of the frame, see PathPool)
@@ -1466,6 +1479,169 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
         shadeSlot<COUNT, SSS, TEX, kShadeListed>(rp, sc, pool, slot, inRange, drained, index >> 6, counts);
     } else {
         shadeSlot<COUNT, SSS, TEX, kShadeDense>(rp, sc, pool, index, index < pool.slots, resets.drained != 0u, index >> 6, counts);
+    }
+    if (COUNT) {
+        addCounter(pool.counters, kCntShadedHits, counts.shadedHit);
+        addCounter(pool.counters, kCntTriangleHits, counts.triHit);
+        addCounter(pool.counters, kCntPrimaryRays, counts.primary);
+#pragma unroll
+        for (uint32_t k = 0; k < 9u; ++k) addCounter(pool.counters, kCntShadeWaves + k, counts.stage[k]);
+    }
+}
+
+// =====================================================================================================
+// k_shade_sorted: k_shade for a full pool, with the slots of a wave's window visited in the order of their shading keys
+// =====================================================================================================
+// What a visit does depends on what the slot's ray found: nothing to do / records to add up / the background / a light / a surface
+// of one of eight material models.  Visited where they lie, the 64 slots of a wave are a mix of all of these and every branch runs
+// with the lanes of its own kind only (config 2: 62 % of the lanes shade a surface, 26 % the background, 33 % start a new sample;
+// VALU lane utilisation 0.51, and 0.25 on the scene with car paint next to Lambertian walls).  Here ONE WAVE owns a window of
+// kSortWindow consecutive slots (kSortRounds per lane) and
+//   1. classifies them from two words that are read in slot order (flags, hit word: the shade key of the primitive rides in the hit
+//      word, kernels/bvh_layout.h) - no dependent fetch;
+//   2. sorts them by key: ballots give a slot its rank among the equal keys before it, lane k counts key k, one prefix sum over
+//      those counts places the keys, and the order goes to LDS (stable: within a key the slots keep their order, so the loads of a
+//      visit still fall into a few cache lines of the window);
+//   3. runs the ordinary visit (shadeSlot) on 64 slots of that order at a time: a visit is uniform in what it does except at the
+//      seams between two keys, idle slots sort to the end and are never visited (a window of 512 with 62 % Lambertian hits: five
+//      visits run the surface code instead of eight).  The window's state is read and written by this wave alone, so HBM traffic
+//      is what it was;
+//   4. back in slot order, claims a new work item for every slot whose path ended (the per-wave reservations want the dense
+//      order) and writes the camera rays.
+// No barriers and nothing shared between waves (a block-wide sort was built first: its waves waited for each other at the barriers
+// and the idle ones held wave slots - 7 % slower than no sort at all; profiles/r3_ab_shade_sort.txt).
+constexpr uint32_t kSortRounds = 8u;                      // slots per lane
+constexpr uint32_t kSortWindow = 64u * kSortRounds;       // slots per wave
+constexpr uint32_t kKeyWalk = 12u, kKeyMiss = 13u, kKeyLand = 14u, kKeyIdle = 15u;   // keys 0..8: unknown, material type + 1
+
+template <bool COUNT, bool SSS, bool TEX>
+__global__ void __launch_bounds__(64) PTR_SHADE_WAVES_ATTR k_shade_sorted(RenderParams rp, SceneView sc, PathPool pool, ShadeResets resets) {
+    __shared__ uint16_t order[kSortWindow];    // sorted position -> slot of the window
+    __shared__ uint32_t result[kSortWindow];   // per slot of the window: shadeSlot's result word
+    const uint32_t lane = threadIdx.x;         // a block is one wave
+    const uint32_t base = blockIdx.x * kSortWindow;
+    if (blockIdx.x == 0u) {
+        if (lane == 0u) {
+            // k_shade runs between this iteration's k_extend and k_connect: it clears the work heads they will claim from next
+            if (resets.extendHead) *resets.extendHead = 0u;
+            if (resets.connectHead) *resets.connectHead = 0u;
+            if (resets.nextAlive) *resets.nextAlive = 0u;
+        }
+        // the next iteration's list counters (kConnectQueues == 64: one per lane)
+        if (pool.connectClear) pool.connectClear[lane * kConnectCountStride] = 0u;
+        if (pool.busyCountClear) pool.busyCountClear[lane * kConnectCountStride] = 0u;
+    }
+    // ---- 1. classify the window (lane l: slots base + 64 r + l) ----
+    uint32_t keys = 0u;   // 4 bits per round
+#pragma unroll
+    for (uint32_t r = 0; r < kSortRounds; ++r) {
+        const uint32_t own = base + r * 64u + lane;
+        const bool inRange = own < pool.slots;
+        const uint32_t at = inRange ? own : 0u;
+        const uint32_t flagsIn = inRange ? reinterpret_cast<const uint32_t*>(pool.ray1 + at)[3] : 0u;
+        const uint32_t primIn = reinterpret_cast<const uint32_t*>(pool.hit + at)[1];
+        result[r * 64u + lane] = 0u;
+        const bool active = (flagsIn & kFlagAlive) != 0u;
+        const bool touched = active || ((flagsIn >> kFlagPendingShift) & kFlagPendingMask) != 0u || (flagsIn & kFlagFlush) != 0u;
+        uint32_t key = touched ? kKeyLand : kKeyIdle;
+        if (active) {
+            if (SSS && (flagsIn & kFlagWalk)) {
+                key = kKeyWalk;
+            } else if (primIn == kHitMiss) {
+                key = kKeyMiss;
+            } else if (primIn & kHitSphereBit) {
+                key = 0u;
+                if (sc.materialCount > 0u) {
+                    const uint32_t material = min(sc.sphereInfo[primIn & kHitIndexMask].y, sc.materialCount - 1u);
+                    key = min(static_cast<uint32_t>(sc.materials[static_cast<size_t>(material) * kMaterialVec4 + kMatTypeEta].x), 7u) + 1u;
+                }
+            } else {
+                key = (primIn >> kHitKeyShift) & kHitKeyMask;
+            }
+        }
+        keys |= key << (4u * r);
+    }
+    // ---- 2. sort by key ----
+    uint32_t count = 0u;                      // lane k (< 16): slots of key k so far
+    uint32_t ranks[kSortRounds / 2u];         // rank of each of the lane's slots among the equal keys before it (two per word)
+#pragma unroll
+    for (uint32_t r = 0; r < kSortRounds; ++r) {
+        const uint32_t key = (keys >> (4u * r)) & 15u;
+        uint32_t rank = 0u;
+        unsigned long long remaining = ~0ull;
+        while (remaining != 0ull) {
+            const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(remaining))) - 1u;
+            const uint32_t k = __builtin_amdgcn_readlane(key, leader);
+            const unsigned long long same = __ballot(key == k);
+            const uint32_t before = __builtin_amdgcn_readlane(count, k);
+            if (key == k) rank = before + static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
+            if (lane == k) count += static_cast<uint32_t>(__popcll(same));
+            remaining &= ~same;
+        }
+        if (r & 1u) ranks[r / 2u] |= rank << 16; else ranks[r / 2u] = rank;
+    }
+    uint32_t firstOfKey;   // lane k: sorted position of the first slot of key k
+    {
+        uint32_t incl = count;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (static_cast<int>(lane) >= off) incl += up;
+        }
+        firstOfKey = incl - count;
+    }
+    const uint32_t touchedCount = __builtin_amdgcn_readlane(firstOfKey, kKeyIdle);   // everything before the idle slots
+    if (touchedCount == 0u) return;   // nothing in this window needs a visit
+#pragma unroll
+    for (uint32_t r = 0; r < kSortRounds; ++r) {
+        const uint32_t key = (keys >> (4u * r)) & 15u;
+        const uint32_t rank = (ranks[r / 2u] >> ((r & 1u) * 16u)) & 0xFFFFu;
+        order[__shfl(firstOfKey, static_cast<int>(key), 64) + rank] = static_cast<uint16_t>(r * 64u + lane);
+    }
+    __syncthreads();   // (a one-wave block: orders the LDS accesses, no s_barrier)
+    // ---- 3. the visits, 64 slots of the sorted order at a time ----
+    ShadeCounts counts;
+    for (uint32_t first = 0u; first < touchedCount; first += 64u) {
+        const bool mine = first + lane < touchedCount;
+        const uint32_t pick = order[mine ? first + lane : 0u];
+        // (connect list: visit `first / 64` of window w appends to the sub-list wave 8 w + first / 64 of the unsorted kernel would use -
+        // at most 64 entries per visit, so the sub-lists' regions hold them)
+        const uint32_t word = shadeSlot<COUNT, SSS, TEX, kShadeSorted>(rp, sc, pool, base + pick, mine, false, blockIdx.x * kSortRounds + (first >> 6), counts);
+        if (mine) result[pick] = word;
+    }
+    __syncthreads();
+    // ---- 4. new work items, in slot order ----
+    for (uint32_t r = 0; r < kSortRounds; ++r) {
+        const uint32_t own = base + r * 64u + lane;
+        const uint32_t word = result[r * 64u + lane];
+        if (__ballot(word != 0u) == 0ull) continue;
+        const bool needItem = (word >> 31) != 0u;
+        uint32_t flags = word & 0x7FFFFFFFu;
+        const uint32_t claimed = claimItems(rp, pool, own, needItem);
+        if (needItem && claimed < rp.itemCount) {
+            uint32_t rng;
+            f3 o, d;
+            beginSample(rp, pool.pixelOfLocal[claimed % rp.localPixels], claimed / rp.localPixels, rng, o, d);
+            flags |= kFlagAlive;   // (a finished path left lastDelta set, depth 0, lastPdf 1)
+            pool.ray0[own] = mk4(o, d.x);
+            pool.ray1[own] = make_float4(d.y, d.z, 1.0f, __uint_as_float(flags));
+            pool.thr[own] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng));
+            reinterpret_cast<uint32_t*>(pool.accum + own)[3] = claimed;
+            if (TEX && pool.cone) pool.cone[own] = primaryCone(rp);
+        }
+        if (pool.busyOut) {
+            // end of the frame: the slots the next iteration has to visit (see shadeSlot)
+            const bool busy = (flags & (kFlagAlive | kFlagFlush | (kFlagPendingMask << kFlagPendingShift))) != 0u;
+            const unsigned long long mask = __ballot(busy);
+            if (mask != 0ull) {
+                const uint32_t queue = (blockIdx.x * kSortRounds + r) & (kConnectQueues - 1u);
+                uint32_t at = 0u;
+                if (lane == 0u) at = atomicAdd(pool.busyCountOut + queue * kConnectCountStride, static_cast<uint32_t>(__popcll(mask)));
+                at = __builtin_amdgcn_readfirstlane(at);
+                const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+                if (busy) pool.busyOut[queue * pool.connectRegion + at + rank] = own | ((flags & kFlagAlive) ? kBusyAliveBit : 0u);
+            }
+        }
     }
     if (COUNT) {
         addCounter(pool.counters, kCntShadedHits, counts.shadedHit);
@@ -1958,9 +2134,9 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace_rays(SceneView sc, const 
             if (!ANY) {
                 if (h.prim & kHitSphereBit) {
                     r.primType = 1u;
-                    r.primIndex = sc.sphereInfo[h.prim & ~kHitSphereBit].x;
+                    r.primIndex = sc.sphereInfo[h.prim & kHitIndexMask].x;
                 } else {
-                    const float4* tp = sc.tris + static_cast<size_t>(h.prim) * 3u;
+                    const float4* tp = sc.tris + static_cast<size_t>(h.prim & kHitIndexMask) * 3u;
                     const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
                     const uint32_t meta = __float_as_uint(t1.w);
                     triangleUv(mk3(t0), mk3(t1), mk3(t2), org, dir, hu, hv);
@@ -1972,11 +2148,11 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace_rays(SceneView sc, const 
                     r.ng[2] = ng.z;
                     if ((meta >> 30) == 0u) {
                         r.primType = 0u;
-                        r.geomIndex = meta & 0x3FFFFFFFu;
+                        r.geomIndex = meta & kTriGeomMask;
                         r.primIndex = __float_as_uint(t2.w);
                     } else {
                         r.primType = 2u;
-                        r.primIndex = meta & 0x3FFFFFFFu;
+                        r.primIndex = meta & kTriGeomMask;
                     }
                 }
             }
@@ -2074,13 +2250,23 @@ void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig&
     }
 }
 
-void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, bool count,
+void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, bool count, bool sorted,
                  hipStream_t stream) {
-    const uint32_t grid = ceilDiv(pool.slots, kShadeBlock);
     const bool sss = (rp.mediaMode & (PTR_METAL_SSS | PTR_METAL_PBR | PTR_METAL_CLAMPS)) != 0u;   // the instantiation that carries those Metal-only models
-    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, resets); };
     const bool listed = pool.busyIn != nullptr;   // the grid still covers every slot: waves beyond the list leave at once
     const bool tex = sss && sc.textureCount > 0u;   // the instantiation with the texture lookups and the ray cone
+    if (sorted && !listed) {
+        const uint32_t grid = ceilDiv(pool.slots, kSortWindow);
+        auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, stream, rp, sc, pool, resets); };
+        if (count) {
+            if (tex) launch(k_shade_sorted<true, true, true>); else if (sss) launch(k_shade_sorted<true, true, false>); else launch(k_shade_sorted<true, false, false>);
+        } else {
+            if (tex) launch(k_shade_sorted<false, true, true>); else if (sss) launch(k_shade_sorted<false, true, false>); else launch(k_shade_sorted<false, false, false>);
+        }
+        return;
+    }
+    const uint32_t grid = ceilDiv(pool.slots, kShadeBlock);
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, resets); };
     auto pick = [&](auto countTag, auto listedTag) {
         constexpr bool C = decltype(countTag)::value, L = decltype(listedTag)::value;
         if (tex) launch(k_shade<C, true, true, L>); else if (sss) launch(k_shade<C, true, false, L>); else launch(k_shade<C, false, false, L>);

@@ -529,13 +529,16 @@ def test_scheduling_knobs_do_not_change_the_image():
     for env in ({"PTR_POOL_GROUPS": "1"}, {"PTR_TAIL_BELOW": "0"}, {"PTR_POOL_SLOTS": str(3 << 20), "PTR_REFILL_BELOW": "24"},
                 {"PTR_WIDE_NODES": "0"},        # the binary walk instead of the four-wide nodes (same tree, one level at a time)
                 {"PTR_QUANTIZED_NODES": "0"},   # 64 B float nodes (box tests only prune: the hits are the same)
-                {"PTR_SHADE_SORT": "0"},        # k_shade visits the slots where they lie instead of sorted by material within a block
+                {"PTR_SHADE_SORT": "1"},        # k_shade visits the slots of a window sorted by shading key instead of where they lie
                 {"PTR_MAX_ITEMS": str(1920 * 1080 * 12)},   # the whole frame still fits one pass
                 {"PTR_BUILD_THREADS": "3", "PTR_VERBOSE": "build"},   # same tree from any number of builder threads
                 {"PTR_NO_OVERSIZE": "1"}):      # (this scene keeps every triangle in the tree anyway)
         image, counts = render(env)
         assert np.array_equal(image, base), env
-        assert counts == base_counts, env
+        if "PTR_QUANTIZED_NODES" in env:   # float boxes are tighter than their 16-bit roundings: fewer node visits, the same rays and hits
+            assert counts[:3] == base_counts[:3] and counts[4] == base_counts[4] and counts[3] <= base_counts[3], env
+        else:
+            assert counts == base_counts, env
 
 
 def test_frames_rendered_in_several_passes(cornell_small):
