@@ -203,6 +203,7 @@ struct PreparedScene {
     std::vector<float> mats, lights;
     std::vector<int32_t> lightIndexByRect;
     uint32_t lightCount = 0;
+    bool lightsHaveTriangles = true;   // every rectangle light found its two triangles in the geometry (always, unless degenerate)
     bool hasRandomWalkMaterial = false;
     ptr::EnvImportanceDistribution envDist;
     bool hasEnvDist = false;
@@ -304,6 +305,7 @@ void prepareScene(const PtrSceneDesc& desc, PreparedScene& ps) {
             const uint32_t t0 = ps.geo.rectTriLeaf[static_cast<size_t>(i) * 2u], t1 = ps.geo.rectTriLeaf[static_cast<size_t>(i) * 2u + 1u];
             const bool haveTris = t0 != 0xFFFFFFFFu && t1 != 0xFFFFFFFFu;
             put4(ps.lights, n, haveTris ? 1.0f : 0.0f);
+            ps.lightsHaveTriangles = ps.lightsHaveTriangles && haveTris;
             put4(ps.lights, e, 0.0f);
             for (uint32_t t : {t0, t1}) {
                 for (int row = 0; row < 3; ++row) {
@@ -402,6 +404,7 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     v.materialCount = desc.materialCount;
     v.rectCount = desc.rectCount;
     v.rectLightCount = lightCount;
+    v.settleRectLights = (lightCount > 0u && lightCount <= 8u && ps.lightsHaveTriangles) ? 1u : 0u;   // kSettleLightsMax of wavefront.hip
 
     if (desc.envRgba && desc.envWidth > 0 && desc.envHeight > 0) {
         const size_t texels = static_cast<size_t>(desc.envWidth) * desc.envHeight;

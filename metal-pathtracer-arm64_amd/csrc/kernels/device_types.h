@@ -63,6 +63,9 @@ struct SceneView {
     const uint4* texInfo;          // kTexInfoVec4 uint4 per texture
     const float4* materialTex;     // kMaterialTexVec4 float4 per material: texture transforms, indices, uv sets, pbr params
     uint32_t textureCount;
+    uint32_t settleRectLights;     // every rectangle light has its two triangles on record and there are few enough of them: k_shade settles
+                                   // specular connections itself (wavefront.hip, kind-3 records)
+    uint32_t pad3;
     uint32_t stackLimit;           // traversal stack entries a ray of this scene can need at most (<= kTraversalStackDepth): LDS levels + spill levels
 };
 
@@ -133,6 +136,8 @@ struct RenderParams {
 //   kind 1: closest hit + rectangle-light evaluation; connect kernel replaces a by the contribution
 //           (a = bsdf weight, w = bsdf pdf; b = throughput)
 //   kind 2: MNEE second bounce (closest hit, delta scatter with a copy of the rng in org.w, then both of the above)
+//   kind 3: any-hit up to tmax that ignores the two triangles of one rectangle (b.x = bits of their meta word): a specular connection
+//           to a rectangle light whose distance and contribution k_shade has already worked out; zeroed when occluded
 struct ShadowRecordView {
     float4* org;
     float4* dir;

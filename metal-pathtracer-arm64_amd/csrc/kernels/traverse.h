@@ -342,7 +342,9 @@ __device__ __forceinline__ bool travPrimStep(const SceneView& sc, const SceneMem
         const uint32_t at = index * 48u;
         const float4 a = load16f(mem.tris, at), b = load16f(mem.tris, at + 16u), c = load16f(mem.tris, at + 32u);
         float tt, u, v;
-        if (triangleTest(mk3(a), mk3(b), mk3(c), t.org, t.dir, t.tnear, t.hit.t, tt, u, v)) {
+        // (an any-hit query starts with the word it must not stop at in its hit word: kHitMiss, which no triangle carries, or the
+        // meta word of the rectangle whose own two triangles a light connection ignores - wavefront.hip, kind-3 records)
+        if (triangleTest(mk3(a), mk3(b), mk3(c), t.org, t.dir, t.tnear, t.hit.t, tt, u, v) && !(t.anyHit && __float_as_uint(b.w) == t.hit.prim)) {
             t.hit.t = tt;
             t.hit.prim = index | (__float_as_uint(b.w) & (kHitKeyMask << kHitKeyShift));   // the triangle's shade key rides along
             if (t.anyHit) return false;
@@ -406,10 +408,11 @@ __device__ __forceinline__ bool travVote(const SceneView& sc, const SceneMem& me
 // (ANY = true).  Returns hit.prim == kHitMiss on a miss.  Same step functions as the persistent kernels.
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ TraceHit traverse(const SceneView& sc, f3 org, f3 dir, float tnear, float tfar,
-                                             LaneStack& stack, TraceCounters& cnt) {
+                                             LaneStack& stack, TraceCounters& cnt, uint32_t ignoreWord = kHitMiss) {
     const SceneMem mem = sceneMem(sc);
     Trav t;
     if (!travBegin(sc, t, org, dir, tnear, tfar, ANY, stack)) return t.hit;
+    if (ANY) t.hit.prim = ignoreWord;
     bool more = true;
     while (more) {
         more = travAtLeaf(t) ? travPrimStep<COUNT>(sc, mem, t, stack, cnt) : travNodeStep<COUNT>(sc, mem, t, stack, cnt);

@@ -478,6 +478,83 @@ __device__ __forceinline__ bool rectLightHit(const SceneView& sc, const Surface&
     return (pdf > 0.0f) && isfinite(pdf);
 }
 
+// ---- specular connections to rectangle lights, settled where they are made ----
+// A delta bounce looks for a rectangle light straight along the sampled direction (specular NEE / MNEE, E:2856-2917): the reference
+// traces a closest-hit ray and asks whether what it found is a light.  Which light that can be, and at what distance, follows from
+// the lights' own rectangles alone: their two triangles ride in the light records exactly as the traversal stores them (rows 5..10),
+// so the same test on the same operands gives the traversal's distance bit for bit.  A direction that meets no light's rectangle
+// needs no ray at all (nearly every delta bounce of a glass object: config 4 queued one closest-hit ray per bounce and k_connect was
+// its largest kernel); one that does becomes an any-hit query up to that distance which ignores the light's own two triangles
+// (record kind 3), with the contribution already computed.
+constexpr uint32_t kSettleLightsMax = 8u;   // scenes with more rectangle lights (or lights without triangles) keep the closest-hit record
+
+__device__ __forceinline__ bool nearestRectLight(const SceneView& sc, f3 org, f3 dir, float& tHit, uint32_t& light, uint32_t& half) {
+    float best = INFINITY;
+    bool found = false;
+    for (uint32_t li = 0; li < sc.rectLightCount; ++li) {
+        const float4* T = sc.rectLights + static_cast<size_t>(li) * kRectLightVec4 + 5u;
+#pragma unroll
+        for (uint32_t h = 0; h < 2u; ++h) {
+            float tt, tu, tv;
+            if (triangleTest(mk3(T[h * 3u]), mk3(T[h * 3u + 1u]), mk3(T[h * 3u + 2u]), org, dir, kEps, best, tt, tu, tv)) {
+                best = tt;
+                light = li;
+                half = h;
+                found = true;
+            }
+        }
+    }
+    tHit = best;
+    return found;
+}
+
+// what reconstruct() would return for a hit on half `half` of light `light` at distance t, as far as rectLightHit reads it
+__device__ __forceinline__ Surface rectLightSurface(const SceneView& sc, f3 org, f3 dir, float t, uint32_t light, uint32_t half, uint32_t& metaWord) {
+    const float4* T = sc.rectLights + static_cast<size_t>(light) * kRectLightVec4 + 5u + half * 3u;
+    const float4 b = T[1], c = T[2];
+    Surface s;
+    s.t = t;
+    s.prim = 0u;
+    s.bu = 0.0f;
+    s.bv = 0.0f;
+    s.position = org + t * dir;
+    s.normal = mk3(0.0f, 1.0f, 0.0f);
+    const f3 ng = cross(mk3(c), mk3(b));
+    if (dot(ng, ng) > 0.0f) s.normal = normalize(ng);
+    s.hitShadingNormal = s.normal;
+    s.frontFace = dot(dir, s.normal) < 0.0f;
+    s.twoSided = false;
+    metaWord = __float_as_uint(b.w);
+    s.primType = 2u;
+    s.primIndex = metaWord & kTriGeomMask;
+    s.geomIndex = 0u;
+    s.material = 0u;
+    return s;
+}
+
+// Contribution of a specular-NEE ray whose closest hit is the light surface `ls` (kind 1 records once traced; kind 3 records up front).
+__device__ __forceinline__ f3 rectContributionAt(const RenderParams& rp, const SceneView& sc, const ClampCfg& cc, const Surface& ls, f3 org, f3 weight,
+                                                 float bsdfPdfIn, f3 thr) {
+    f3 emission;
+    float pdf;
+    if (!rectLightHit(sc, ls, org, rp.emissionScale, emission, pdf)) return mk3(0.0f);
+    const float lightPdf = smax(pdf, kSpecNeePdfFloor);
+    const float invLightPdf = smin(1.0f / lightPdf, kSpecNeeInvPdfClamp);
+    const float bsdfPdf = smax(bsdfPdfIn, kSpecNeePdfFloor);
+    const float denom = lightPdf + bsdfPdf;
+    float mis = denom > 0.0f ? (lightPdf / denom) : 0.0f;
+    mis = clampf(mis, kMisMin, kMisMax);
+    const f3 contrib = (weight * emission) * (mis * invLightPdf);
+    return finite3(contrib) ? clampFirefly(thr, contrib, cc) : mk3(0.0f);
+}
+
+// An any-hit query ends with its hit word either still what it started as - kHitMiss, or for a kind-3 record the meta word of the
+// rectangle it ignores (kind 2 in bits 31:30, the light material's shade key, never 0, in bits 29:26) - or replaced by a hit word:
+// a triangle (bits 31:30 = 0) or a sphere (bit 31, no shade key).
+__device__ __forceinline__ bool anyHitFound(uint32_t hitWord) {
+    return (hitWord >> 30) == 0u || ((hitWord >> 30) == 2u && ((hitWord >> kHitKeyShift) & kHitKeyMask) == 0u);
+}
+
 struct PendingRay {
     f3 org, dir;
     float tmax;
@@ -854,6 +931,7 @@ __device__ __forceinline__ uint32_t claimItems(const RenderParams& rp, const Pat
 // SSS: the instantiation with the Metal subsurface semantics (launched when PTR_METAL_SSS is set)
 struct ShadeCounts {
     uint32_t shadedHit = 0u, triHit = 0u, primary = 0u;   // counting build
+    uint32_t settled = 0u;   // specular connections settled without the reference's closest-hit ray (still booked as extend rays: the counters mirror the reference's)
     uint32_t stage[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // kCntShadeWaves ... kCntShadeNeedItem
 };
 
@@ -1282,7 +1360,20 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
                                     }
                                 }
                             }
-                            if (sc.rectLightCount > 0u) {
+                            if (sc.rectLightCount > 0u && sc.settleRectLights) {
+                                if (COUNT) counts.settled += 1u;
+                                float tl;
+                                uint32_t li = 0u, half = 0u;
+                                if (nearestRectLight(sc, sorg, sdir, tl, li, half)) {
+                                    uint32_t ignore;
+                                    const Surface ls = rectLightSurface(sc, sorg, sdir, tl, li, half, ignore);
+                                    const f3 c = rectContributionAt(rp, sc, cc, ls, sorg, bs.weight, bs.pdf, thr);
+                                    if (c.x != 0.0f || c.y != 0.0f || c.z != 0.0f) {
+                                        storeRecord(pool, slot, 3u, 3u, sorg, tl, sdir, c, 0.0f, mk3(__uint_as_float(ignore), 0.0f, 0.0f));
+                                        want[3] = true;
+                                    }
+                                }
+                            } else if (sc.rectLightCount > 0u) {
                                 storeRecord(pool, slot, 3u, 1u, sorg, INFINITY, sdir, bs.weight, bs.pdf, thr);
                                 want[3] = true;
                             }
@@ -1484,6 +1575,7 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
         addCounter(pool.counters, kCntShadedHits, counts.shadedHit);
         addCounter(pool.counters, kCntTriangleHits, counts.triHit);
         addCounter(pool.counters, kCntPrimaryRays, counts.primary);
+        addCounter(pool.counters, kCntExtendRays, counts.settled);
 #pragma unroll
         for (uint32_t k = 0; k < 9u; ++k) addCounter(pool.counters, kCntShadeWaves + k, counts.stage[k]);
     }
@@ -1647,6 +1739,7 @@ __global__ void __launch_bounds__(64) PTR_SHADE_WAVES_ATTR k_shade_sorted(Render
         addCounter(pool.counters, kCntShadedHits, counts.shadedHit);
         addCounter(pool.counters, kCntTriangleHits, counts.triHit);
         addCounter(pool.counters, kCntPrimaryRays, counts.primary);
+        addCounter(pool.counters, kCntExtendRays, counts.settled);
 #pragma unroll
         for (uint32_t k = 0; k < 9u; ++k) addCounter(pool.counters, kCntShadeWaves + k, counts.stage[k]);
     }
@@ -1699,17 +1792,7 @@ __device__ __forceinline__ f3 rectContribution(const RenderParams& rp, const Sce
                                                const TraceHit& h, f3 weight, float bsdfPdfIn, f3 thr) {
     if (h.prim == kHitMiss) return mk3(0.0f);
     const Surface ls = reconstruct(sc, org, dir, h.t, h.prim);
-    f3 emission;
-    float pdf;
-    if (!rectLightHit(sc, ls, org, rp.emissionScale, emission, pdf)) return mk3(0.0f);
-    const float lightPdf = smax(pdf, kSpecNeePdfFloor);
-    const float invLightPdf = smin(1.0f / lightPdf, kSpecNeeInvPdfClamp);
-    const float bsdfPdf = smax(bsdfPdfIn, kSpecNeePdfFloor);
-    const float denom = lightPdf + bsdfPdf;
-    float mis = denom > 0.0f ? (lightPdf / denom) : 0.0f;
-    mis = clampf(mis, kMisMin, kMisMax);
-    const f3 contrib = (weight * emission) * (mis * invLightPdf);
-    return finite3(contrib) ? clampFirefly(thr, contrib, cc) : mk3(0.0f);
+    return rectContributionAt(rp, sc, cc, ls, org, weight, bsdfPdfIn, thr);
 }
 
 // MNEE second bounce (kind 2 records): follow the specular ray to the next delta surface, scatter with a copy
@@ -1803,9 +1886,11 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_connect(RenderP
                 const float4 o4 = recBase[myRecAt], d4 = recBase[myRecAt + slots];
                 const uint32_t kind = __float_as_uint(d4.w);
                 if (kind != 2u) {   // kind 2 (MNEE chains) is resolved by k_connect_chain
-                    if (COUNT) { if (kind == 0u) ++rays; else ++raysClosest; }
-                    active = travBegin<NODES>(sc, t, mk3(o4), mk3(d4), kEps, kind == 0u ? o4.w : INFINITY, kind == 0u, stack);
-                    if (!active && kind != 0u) recBase[myRecAt + 2u * slots] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    const bool any = kind != 1u;   // kind 0 and kind 3 (any-hit up to o4.w; kind 3 ignores one rectangle's triangles)
+                    if (COUNT) { if (any) ++rays; else ++raysClosest; }
+                    active = travBegin<NODES>(sc, t, mk3(o4), mk3(d4), kEps, any ? o4.w : INFINITY, any, stack);
+                    if (kind == 3u) t.hit.prim = __float_as_uint(recBase[myRecAt + 3u * slots].x);
+                    if (!active && kind == 1u) recBase[myRecAt + 2u * slots] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 }
             }
             continue;
@@ -1824,8 +1909,8 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_connect(RenderP
                 active = false;
                 float4* const a = recBase + myRecAt + 2u * slots;
                 if (t.anyHit) {
-                    if (COUNT) early += (t.hit.prim != kHitMiss) ? 1u : 0u;
-                    if (t.hit.prim != kHitMiss) *a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (COUNT) early += anyHitFound(t.hit.prim) ? 1u : 0u;
+                    if (anyHitFound(t.hit.prim)) *a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 } else {
                     const float4 a4 = *a;
                     const f3 c = rectContribution(rp, sc, cc, t.org, t.dir, t.hit, mk3(a4), a4.w, mk3(recBase[myRecAt + 3u * slots]));
@@ -1973,11 +2058,12 @@ __global__ void __launch_bounds__(kTraceBlock) k_tail_run(RenderParams rp, Scene
                     const float4 o4 = recBase[recAt], d4 = recBase[recAt + slots];
                     float4* const a = recBase + recAt + 2u * slots;
                     const uint32_t kind = __float_as_uint(d4.w);
-                    if (kind == 0u) {
+                    if (kind == 0u || kind == 3u) {
                         if (COUNT) ++raysAny;
-                        const TraceHit h = traverse<true, COUNT>(sc, mk3(o4), mk3(d4), kEps, o4.w, stack, cntAny);
-                        if (COUNT) early += (h.prim != kHitMiss) ? 1u : 0u;
-                        if (h.prim != kHitMiss) *a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        const uint32_t ignore = kind == 3u ? __float_as_uint(recBase[recAt + 3u * slots].x) : kHitMiss;
+                        const TraceHit h = traverse<true, COUNT>(sc, mk3(o4), mk3(d4), kEps, o4.w, stack, cntAny, ignore);
+                        if (COUNT) early += anyHitFound(h.prim) ? 1u : 0u;
+                        if (anyHitFound(h.prim)) *a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     } else if (kind == 1u) {
                         if (COUNT) ++raysClosest;
                         const TraceHit h = traverse<false, COUNT>(sc, mk3(o4), mk3(d4), kEps, INFINITY, stack, cntClosest);
@@ -2006,6 +2092,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_tail_run(RenderParams rp, Scene
         addCounter(pool.counters, kCntShadedHits, counts.shadedHit);
         addCounter(pool.counters, kCntTriangleHits, counts.triHit);
         addCounter(pool.counters, kCntPrimaryRays, counts.primary);
+        addCounter(pool.counters, kCntExtendRays, counts.settled);
     }
 }
 

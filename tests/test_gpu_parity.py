@@ -493,6 +493,27 @@ def test_mnee_modes(tmp_path):
     _image_parity(host, dev, osc, 64, 48, 6, 1, 16, 0.90, enableMnee=1, enableMneeSecondary=0)
 
 
+def test_specular_connections_settled_in_shade_and_traced(tmp_path):
+    # A delta bounce connects to rectangle lights straight along its direction.  With up to 8 lights k_shade works out which light the
+    # direction meets (the lights' own triangles) and queues an any-hit ray up to it, or none; with more it queues the reference's
+    # closest-hit ray.  Both against the oracle, on the same glass-and-mirror scene lit by one light / by nine.
+    head = ("camera target=0,1,0 distance=7 yaw=1.0 pitch=0.4 vfov=40\nrenderer maxDepth=6 seed=5\nbackground solid=0.02,0.02,0.03\n"
+            "material type=lambert albedo=0.7,0.7,0.7\nmaterial type=dielectric ior=1.5\nmaterial type=light emit=20,18,15\nmaterial type=metal albedo=0.9,0.9,0.9 fuzz=0\n"
+            "rectangle x=-6,6 y=0 z=-6,6 normal=1 material=0\nsphere center=0,1,0 radius=1 material=1\nsphere center=2.2,0.7,0.5 radius=0.7 material=3\n"
+            "rectangle x=-2.7 y=0,2 z=-1,1 normal=1 twoSided=1 material=0\n")   # an occluder between some bounce directions and the lights
+    one = "rectangle x=-1.5,1.5 y=5 z=-1.5,1.5 normal=-1 material=2\n"
+    nine = "".join("rectangle x=%g,%g y=5 z=%g,%g normal=-1 material=2\n" % (-1.5 + i, -0.6 + i, -1.5 + j, -0.6 + j) for i in range(3) for j in range(3))
+    for name, lights, count in (("one", one, 1), ("nine", nine, 9)):
+        p = tmp_path / ("spec_%s.scene" % name)
+        p.write_text(head + lights)
+        host = pt.HostScene.load(str(p))
+        dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
+        assert dev.info()["rect_lights"] == count
+        _image_parity(host, dev, osc, 64, 48, 6, 1, 16, 0.90)
+        _image_parity(host, dev, osc, 64, 48, 6, 1, 16, 0.90, enableMnee=1, enableMneeSecondary=1)
+        dev.close()
+
+
 def test_partition_and_pool_size_invariance(cornell_small):
     host, dev, _ = cornell_small
     s = host.settings_for(width=72, height=56, max_depth=5)
