@@ -1026,6 +1026,18 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
                              shadeLanes / 64.0, c[kCntShadeAlive] / shadeLanes, c[kCntShadeSurface] / shadeLanes, c[kCntShadeEmitter] / shadeLanes,
                              c[kCntShadeLightEval] / shadeLanes, c[kCntShadeLightPretest] / shadeLanes, c[kCntShadeLightStored] / shadeLanes,
                              c[kCntShadeBsdfSample] / shadeLanes, c[kCntShadeNeedItem] / shadeLanes);
+                {
+                    static const char* names[kShadeParts] = {"loads + landing", "background", "surface reconstruction", "emitter", "light sample", "env sample",
+                                                             "BSDF sample + next ray", "work item + camera ray", "stores + lists", "subsurface walk"};
+                    double waveTotal = 0.0;
+                    for (uint32_t k = 0; k < kShadeParts; ++k) waveTotal += static_cast<double>(c[kCntShadeWaveTicks + k]);
+                    std::fprintf(stderr, "[steps] k_shade parts (clock ticks between the part's first and last instruction, waits included): share of the waves' time | lanes busy\n");
+                    for (uint32_t k = 0; k < kShadeParts; ++k) {
+                        const double wave = static_cast<double>(c[kCntShadeWaveTicks + k]), lane = static_cast<double>(c[kCntShadeLaneTicks + k]);
+                        if (wave <= 0.0) continue;
+                        std::fprintf(stderr, "[steps]   %-24s %5.1f %% | %.3f\n", names[k], 100.0 * wave / std::max(waveTotal, 1.0), lane / (64.0 * wave));
+                    }
+                }
                 std::fprintf(stderr, "[steps] k_extend: refill passes take %.1f %% of the waves' time in the kernel\n",
                              100.0 * static_cast<double>(c[kCntExtendRefillTicks]) / std::max(static_cast<double>(c[kCntExtendWaveTicks]), 1.0));
             }

@@ -228,6 +228,21 @@ __host__ __device__ inline uint32_t sigHashStep(uint32_t h, uint32_t primType, u
     return x & 0xFFFFu;
 }
 
+// parts of a k_shade visit the counting build times (PTR_VERBOSE=steps)
+enum ShadePart : uint32_t {
+    kShadePartLoad = 0,       // state loads, records landing, publishing a finished item
+    kShadePartMiss = 1,       // background + MIS for a ray that left the scene
+    kShadePartSurface = 2,    // hit reconstruction (triangle, normals, barycentrics), material fetch
+    kShadePartEmitter = 3,    // a light reached by a BSDF-sampled ray
+    kShadePartLightNee = 4,   // rectangle-light sample: BSDF value, weight, the light's own triangles, record
+    kShadePartEnvNee = 5,     // environment sample
+    kShadePartBsdf = 6,       // BSDF sampling, specular connections, throughput, roulette, next ray
+    kShadePartItem = 7,       // claiming a work item and generating its camera ray
+    kShadePartStore = 8,      // state stores, connect / busy list appends
+    kShadePartWalk = 9,       // subsurface random-walk step (Metal semantics)
+    kShadeParts = 10,
+};
+
 enum CounterSlot : uint32_t {
     kCntExtendRays = 0,
     kCntExtendNodes = 1,
@@ -259,7 +274,10 @@ enum CounterSlot : uint32_t {
     kCntShadeLightStored = 30,  // ... and queue a shadow ray
     kCntShadeBsdfSample = 31,   // lanes that sample the BSDF
     kCntShadeNeedItem = 32,     // lanes that ask for a new work item
-    kCounterSlots = 40,
+    // k_shade, counting build: clock ticks per part of a visit (ShadePart), lane-summed [40..49] and per wave [50..59]
+    kCntShadeLaneTicks = 40,
+    kCntShadeWaveTicks = 50,
+    kCounterSlots = 64,
 };
 
 }  // namespace ptrk

@@ -933,7 +933,24 @@ struct ShadeCounts {
     uint32_t shadedHit = 0u, triHit = 0u, primary = 0u;   // counting build
     uint32_t settled = 0u;   // specular connections settled without the reference's closest-hit ray (still booked as extend rays: the counters mirror the reference's)
     uint32_t stage[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // kCntShadeWaves ... kCntShadeNeedItem
+    // clock ticks per part of a visit (kShadePart*): summed over the lanes that ran the part / booked once per wave that ran it
+    uint32_t laneTicks[kShadeParts] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t waveTicks[kShadeParts] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 };
+
+// counting build: a part of a visit runs between partBegin and partEnd inside ONE branch region, so every lane that reaches
+// partEnd ran the whole part with the wave; the first of them books the wave's time
+template <bool COUNT>
+__device__ __forceinline__ long long partBegin() { return COUNT ? clock64() : 0ll; }
+template <bool COUNT>
+__device__ __forceinline__ void partEnd(ShadeCounts& counts, uint32_t part, long long t0) {
+    if (COUNT) {
+        const uint32_t ticks = static_cast<uint32_t>(clock64() - t0);
+        counts.laneTicks[part] += ticks;
+        const unsigned long long here = __ballot(true);
+        if (laneId() + 1u == static_cast<uint32_t>(__ffsll(static_cast<long long>(here)))) counts.waveTicks[part] += ticks;
+    }
+}
 
 // One visit of a path slot: what k_shade does for its thread's slot.  MODE kShadeDense: lane l of wave w holds slot 64 w + l.
 // kShadeListed: the lanes hold the slots of a busy list (end of the frame) - the wave is converged but its slots are arbitrary, so
@@ -954,6 +971,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
     // Everything that depends only on the slot index is requested up front, and the record loads are pointed at a
     // zero word when the record is not pending, so the kernel has ~11 loads in flight per lane after ONE dependent
     // step (the state word) instead of walking a chain of ten load-wait pairs at 5 waves per SIMD.
+    const long long tLoad = partBegin<COUNT>();
     const uint32_t at = inRange ? slot : 0u;
     float4 ray1v = pool.ray1[at];
     if (!TAIL && MODE != kShadeSorted && drained) {
@@ -1019,6 +1037,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
             acc = mk3(0.0f);
             sig = 0u;
         }
+        partEnd<COUNT>(counts, kShadePartLoad, tLoad);
 
         if (active) {
             depth = (flagsIn >> kFlagDepthShift) & kFlagFieldMask;
@@ -1038,6 +1057,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
             bool walking = false;   // SSS: the slot stays in (or enters) a subsurface random walk: no bounce bookkeeping this visit
 
             if (SSS && (flagsIn & kFlagWalk)) {
+                const long long tWalk = partBegin<COUNT>();
                 // ---- one step of a subsurface random walk: this ray was the walk's boundary query (bsdf.h: sssWalkStep) ----
                 const ShadowRecordView& wr = pool.rec[4];
                 const float4 w0 = wr.org[slot], w1 = wr.dir[slot], w2 = wr.a[slot], w3 = wr.b[slot];
@@ -1094,8 +1114,10 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
                         }
                     }
                 }
+                partEnd<COUNT>(counts, kShadePartWalk, tWalk);
             } else if (prim == kHitMiss) {
                 // ---- escaped: background, MIS-weighted against environment sampling ----
+                const long long tMiss = partBegin<COUNT>();
                 f3 bg;
                 if (rp.backgroundMode == PTR_BG_SOLID) {
                     bg = ld3(rp.backgroundColor);
@@ -1115,9 +1137,11 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
                 acc += clampFirefly(thr, bg * mis, cc);
                 if (COUNT) sig = (sig & 0xFFFFu) | (sigHashStep(sig >> 16, 7u, 0u, 0u) << 16);
                 endPath = true;
+                partEnd<COUNT>(counts, kShadePartMiss, tMiss);
             } else if (sc.materialCount == 0u) {
                 endPath = true;
             } else {
+                const long long tSurface = partBegin<COUNT>();
                 const Surface sf = reconstruct(sc, rayO, rayD, hitv.x, prim);
                 if (COUNT) {
                     shadedHit = 1u;
@@ -1170,6 +1194,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
                     }
                 }
 
+                partEnd<COUNT>(counts, kShadePartSurface, tSurface);
                 if (SSS && passThrough) {
                     // pathtrace.metal:6206-6216: the ray carries on through the surface; counts as a specular bounce
                     nextO = offsetOrigin(sf, rayD);
@@ -1178,6 +1203,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
                     lastDelta = true;
                     specDepth += 1u;
                 } else if (type == 3u) {
+                    const long long tEmitter = partBegin<COUNT>();
                     if (COUNT) counts.stage[3] += 1u;
                     // ---- emitter reached by a BSDF-sampled ray ----
                     const float4 em = mat.v(kMatEmission);
@@ -1197,12 +1223,14 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
                         acc += clampFirefly(thr, emission * mis, cc);
                     }
                     endPath = true;
+                    partEnd<COUNT>(counts, kShadePartEmitter, tEmitter);
                 } else {
                     bool surfaceDelta = materialIsDelta(mat);
                     if (SSS && cc.metalPbr && type == 7u) surfaceDelta = mat.roughness01() <= 1.0e-3f;   // pathtrace.metal:4578-4581
 
                     // ---- rectangle-light NEE (3 random numbers, drawn even if the sample is rejected) ----
                     if (!surfaceDelta && sc.rectLightCount > 0u) {
+                        const long long tLight = partBegin<COUNT>();
                         const uint32_t nL = sc.rectLightCount;
                         const uint32_t sel = min(static_cast<uint32_t>(rngNext(rng) * static_cast<float>(nL)), nL - 1u);
                         const float lu = rngNext(rng);
@@ -1263,10 +1291,12 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
                                 }
                             }
                         }
+                        partEnd<COUNT>(counts, kShadePartLightNee, tLight);
                     }
 
                     // ---- environment NEE (3 random numbers: marginal, conditional, jitter) ----
                     if (!surfaceDelta && sc.envSampling) {
+                        const long long tEnv = partBegin<COUNT>();
                         const float uM = rngNext(rng);
                         const float uC = rngNext(rng);
                         const float uJ = rngNext(rng);
@@ -1290,9 +1320,11 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
                                 }
                             }
                         }
+                        partEnd<COUNT>(counts, kShadePartEnvNee, tEnv);
                     }
 
                     // ---- continue the path ----
+                    const long long tBsdf = partBegin<COUNT>();
                     BsdfSampleResult bs{mk3(0.0f), mk3(0.0f), 0.0f, false, 0, false, mk3(0.0f)};
                     bool haveSample = false;
                     if (SSS && type == 5u && cc.metalSss && rp.sssMode == 2u && mat.v(kMatSssParams).y >= 0.5f && sf.frontFace) {
@@ -1418,6 +1450,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
                             }
                         }
                     }
+                    partEnd<COUNT>(counts, kShadePartBsdf, tBsdf);
                 }
             }
 
@@ -1452,6 +1485,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
 
     if (COUNT) counts.stage[8] += needItem ? 1u : 0u;
     // ---- claim new work items ----
+    const long long tItem = partBegin<COUNT>();
     if (MODE == kShadeSorted) {
         // the slot's own thread claims after the sorted pass (k_shade_sorted): the path is left dead here
     } else if (MODE != kShadeDense) {
@@ -1480,7 +1514,9 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
         }
     }
 
-    // light connections of this bounce: k_connect walks the slots and reads the pending mask
+    partEnd<COUNT>(counts, kShadePartItem, tItem);
+    const long long tStore = partBegin<COUNT>();
+    // light connections of this bounce: k_connect walks the connect list k_shade appends to below
     uint32_t pendingMask = 0u;
 #pragma unroll
     for (uint32_t k = 0; k < kRecSlots; ++k) {
@@ -1531,6 +1567,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
         }
     }
 
+    partEnd<COUNT>(counts, kShadePartStore, tStore);
     if (COUNT) {
         counts.shadedHit += shadedHit;
         counts.triHit += triHit;
@@ -1578,6 +1615,11 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
         addCounter(pool.counters, kCntExtendRays, counts.settled);
 #pragma unroll
         for (uint32_t k = 0; k < 9u; ++k) addCounter(pool.counters, kCntShadeWaves + k, counts.stage[k]);
+#pragma unroll
+        for (uint32_t k = 0; k < kShadeParts; ++k) {
+            addCounter(pool.counters, kCntShadeLaneTicks + k, counts.laneTicks[k]);
+            addCounter(pool.counters, kCntShadeWaveTicks + k, counts.waveTicks[k]);
+        }
     }
 }
 
@@ -1742,6 +1784,11 @@ __global__ void __launch_bounds__(64) PTR_SHADE_WAVES_ATTR k_shade_sorted(Render
         addCounter(pool.counters, kCntExtendRays, counts.settled);
 #pragma unroll
         for (uint32_t k = 0; k < 9u; ++k) addCounter(pool.counters, kCntShadeWaves + k, counts.stage[k]);
+#pragma unroll
+        for (uint32_t k = 0; k < kShadeParts; ++k) {
+            addCounter(pool.counters, kCntShadeLaneTicks + k, counts.laneTicks[k]);
+            addCounter(pool.counters, kCntShadeWaveTicks + k, counts.waveTicks[k]);
+        }
     }
 }
 
