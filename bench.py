@@ -22,10 +22,15 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6.29 TB/s measured streaming copy
 # Per-kernel records of tools/measure_solo.sh (rocprofv3 --kernel-trace --stats, --pmc FETCH_SIZE / WRITE_SIZE / VALU groups, pool as
-# ONE group so kernels never overlap): config 2 = this benchmark's own command line, config 5 = the scene whose BVH lives in HBM
-SOLO_FILE = os.path.join(ROOT, "profiles", "r2_solo_cfg2.json")
-SOLO_FILE_CFG5 = os.path.join(ROOT, "profiles", "r2_solo_cfg5.json")
-EXTEND_KERNEL = "k_extend<false,false"   # prefix: the third template argument names the node format (1 = 32 B quantised, 0 = 64 B float)
+# ONE group so kernels never overlap), one per workload: the command line each was taken with is in the file
+SOLO_FILES = {
+    ("cornell_mesh.scene", 1920, 1080, 8, 256): "profiles/r3_solo_cfg2.json",      # BASELINE configs[1]: this benchmark's default
+    ("knot_glass.scene", 1920, 1080, 16, 128): "profiles/r3_solo_cfg4.json",       # configs[3] stand-in
+    ("lucy_standin.scene", 3840, 2160, 12, 16): "profiles/r3_solo_cfg5.json",      # configs[4] stand-in: the scene lives in HBM
+}
+SOLO_FILE_CFG5 = os.path.join(ROOT, "profiles", "r3_solo_cfg5.json")
+# the three kernels of an iteration, by the prefix of their timed (non-counting) instantiations
+KERNEL_PREFIX = {"extend": "k_extend<false,", "shade": "k_shade<false,", "connect": "k_connect<false,"}
 
 
 def measured_stream_gbs(torch, device):
@@ -60,7 +65,7 @@ def recorded_parity():
     seed-to-seed noise floor N, mean-luminance ratio), or None."""
     try:
         row = None
-        for name in ("r2_full_configs.json", "r1_full_configs.json"):
+        for name in ("r3_full_configs.json", "r2_full_configs.json", "r1_full_configs.json"):
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 row = json.load(open(path))["2"]
@@ -71,18 +76,33 @@ def recorded_parity():
         return None
 
 
-def recorded_kernel(path, kernel=EXTEND_KERNEL):
-    """One kernel's row of a tools/measure_solo.sh record (None when the file is absent): dispatches, avg_ms, hbm_bytes_per_dispatch
-    (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 wide-read correction of MI355X_MICROARCH.md), valu_lane_utilisation, valu_issue."""
+def recorded_kernel(path, prefix):
+    """One kernel's row of a tools/measure_solo.sh record (None when the file is absent): of the instantiations whose name starts with
+    `prefix`, the one with the most kernel time.  Fields: dispatches, avg_ms (rocprofv3), hbm_bytes_per_dispatch (FETCH_SIZE + WRITE_SIZE +
+    streamed reads / 2, profiles/r3_fetch_size_calibration.txt), hbm_gbs, hbm_frac_of_8TBs, valu_issue, valu_lane_utilisation."""
     try:
         with open(path) as f:
             rec = json.load(f)
-        names = [k for k in rec["kernels"] if k.startswith(kernel)]
-        row = dict(rec["kernels"][max(names, key=lambda k: rec["kernels"][k].get("dispatches", 0) * rec["kernels"][k].get("avg_ms", 0.0))])
+        names = [k for k in rec["kernels"] if k.startswith(prefix) and rec["kernels"][k].get("avg_ms")]
+        name = max(names, key=lambda k: rec["kernels"][k].get("dispatches", 0) * rec["kernels"][k].get("avg_ms", 0.0))
+        row = dict(rec["kernels"][name])
+        row["name"] = name
         row["command"] = rec.get("command", "")
         return row
     except (OSError, ValueError, KeyError, TypeError):
         return None
+
+
+def kernel_roofline(row, live_ms, source):
+    """The HBM roofline entry of one kernel, every figure from ONE committed record (bytes from the PMC passes over the rocprofv3
+    average duration of the same command line); the duration this run measured with HIP events rides beside it."""
+    if not row or not row.get("hbm_bytes_per_dispatch"):
+        return None
+    return {"kernel": row["name"], "bound": "hbm", "achieved": row.get("hbm_gbs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": row.get("hbm_frac_of_8TBs"), "traffic": row["hbm_bytes_per_dispatch"], "avg_launch_ms": row.get("avg_ms"),
+            "avg_launch_ms_live": round(live_ms, 4) if live_ms else None, "dispatches": row.get("dispatches"),
+            "valu_issue": row.get("valu_issue"), "valu_lane_utilisation": row.get("valu_lane_utilisation"),
+            "wave_cycles_waiting": row.get("wave_cycles_waiting"), "source": source}
 
 
 def algorithmic_bytes(nodes, prims, shaded=0, tri_hits=0, samples=0):
@@ -163,9 +183,28 @@ def main():
     # ---- setup (untimed): parse, build BVH, upload; output buffers in HBM ----
     host = pt.HostScene.load(args.scene, os.path.join(ROOT, "scenes"))
     settings = host.settings_for(width=args.width, height=args.height, max_depth=args.depth, seed=1337, metalSemantics=args.semantics)
+    bvh_build_s = 0.0
+    cache_path = None
+    if world > 1:
+        # ONE BVH build for the node: rank 0 prepares the geometry on the host (no GPU call) and writes it to /dev/shm, the other
+        # ranks read it (N concurrent 64-thread builds on one host would each take several times their solo time)
+        cache_path = "/dev/shm/ptr_geometry_%s_%d.bin" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+        if rank == 0:
+            bvh_build_s = pt.prepare_geometry(host.desc, cache_path)
+        dist.barrier()
     t0 = time.time()
-    scene = pt.DeviceScene(host.desc, local_rank, keepalive=host)
+    scene = pt.DeviceScene(host.desc, local_rank, keepalive=host, prepared=cache_path)
     upload_s = time.time() - t0
+    timings = scene.timings()
+    if world == 1:
+        bvh_build_s = timings["geometry_s"]
+    if world > 1:
+        dist.barrier()
+        if rank == 0:
+            try:
+                os.remove(cache_path)
+            except OSError:
+                pass
     rows = bands.max_band_count(args.height, world) * bands.BAND_ROWS
     local = torch.zeros((rows, args.width, 3), dtype=torch.float32, device=device)
     stream = torch.cuda.current_stream(device)
@@ -242,36 +281,40 @@ def main():
         path_gbs = path_bytes * args.steps / elapsed / 1e9 / world
 
         stream_gbs = measured_stream_gbs(torch, device)
-        default_workload = (os.path.basename(args.scene) == "cornell_mesh.scene" and (args.width, args.height, args.depth, args.spp) == (1920, 1080, 8, 256)
-                            and args.semantics == 0)
-        rec2 = recorded_kernel(SOLO_FILE) if (world == 1 and default_workload) else None
-        rec5 = recorded_kernel(SOLO_FILE_CFG5)
-        # k_extend alone on the chip (pool as one group): the launch duration is measured live by this run (HIP events on the
-        # kernel's stream, an extra untimed render); the HBM-side bytes of such a launch come from the committed PMC passes of the
-        # same command line.  Their quotient is the physical HBM rate of the traversal kernel.
-        physical = None
-        if rec2 and solo and rec2.get("hbm_bytes_per_dispatch"):
-            physical = rec2["hbm_bytes_per_dispatch"] / (solo["avg_launch_ms"] * 1e-3) / 1e9
-        roofline = {
-            "bound": "hbm",
-            "kernel": "k_extend (closest-hit BVH traversal), path-slot pool as one group (nothing else on the chip)",
-            "achieved": round(physical, 1) if physical else None,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(physical / HBM_PEAK_GBS, 4) if physical else None,
-            "traffic": rec2["hbm_bytes_per_dispatch"] if rec2 else None,
-            "traffic_source": ("recorded: profiles/r2_solo_cfg2.json (2 x FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes of `%s`); "
-                               "rocprofv3 average launch %.4f ms in that record" % (rec2["command"], rec2["avg_ms"])) if rec2 else
-                              "no PMC record for this command line",
-            "avg_launch_ms": solo["avg_launch_ms"] if solo else None,
+        workload_key = (os.path.basename(args.scene), args.width, args.height, args.depth, args.spp)
+        solo_rel = SOLO_FILES.get(workload_key) if (world == 1 and args.semantics == 0) else None
+        solo_path = os.path.join(ROOT, solo_rel) if solo_rel else None
+        # live launch durations with the pool as one group (HIP events on the kernels' stream, the extra untimed render above)
+        live = {}
+        if world == 1 and sstats.traceLaunches > 0:
+            n = float(sstats.traceLaunches)   # one k_extend, one k_shade and one k_connect per iteration
+            live = {"extend": sstats.traceKernelMs / n, "shade": sstats.shadeKernelMs / n, "connect": sstats.shadowKernelMs / n}
+        per_kernel = {}
+        for which, prefix in KERNEL_PREFIX.items():
+            entry = kernel_roofline(recorded_kernel(solo_path, prefix) if solo_path else None, live.get(which), solo_rel)
+            if entry:
+                per_kernel[which] = entry
+        step_ms = {"extend": trace_ms / args.steps, "shade": shade_ms / args.steps, "connect": connect_ms / args.steps}
+        dominant = max(step_ms, key=step_ms.get)
+        rec5 = recorded_kernel(SOLO_FILE_CFG5, KERNEL_PREFIX["extend"])
+        # `roofline` describes the kernel with the most kernel time in THIS run's timed region (kernel_ms_per_step below); the other
+        # two kernels of an iteration are in roofline["kernels"].  Every frac = bytes of the committed PMC passes / the rocprofv3 average
+        # launch of the same record / 8 TB/s - recomputable from the one file named in `source`.
+        roofline = dict(per_kernel.get(dominant) or {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                     "frac": None, "traffic": None, "source": "no PMC record for this command line"})
+        roofline.update({
+            "dominant_by": "kernel_ms_per_step of this run: " + ", ".join("%s %.1f" % (k, v) for k, v in step_ms.items()),
+            "kernels": per_kernel,
             "peak_measured": round(stream_gbs, 1),
-            "note": "HBM is NOT what bounds this kernel on this workload: the scene (a few MB of four-wide nodes and triangles) is served by "
-                    "L1 / L2 / Infinity Cache and HBM only carries the ray-state stream; the binding resource is VALU issue at partial lane "
-                    "occupancy (`valu`).  `algorithmic` is SURVEY.md section 8(d)'s reference-layout figure (64 B per binary node visit, "
-                    "68 B per primitive test, counted by the counting build on the binary tree) over the same launches - an effective, "
-                    "cache-served rate that can exceed the HBM peak; `hbm_resident_scene` is the same kernel on BASELINE configs[4], whose "
-                    "1 GB of four-wide nodes and 1.4 GB of triangles do come from HBM.",
+            "note": "Physical HBM-side traffic (PMC) over launch time, per kernel, with the path-slot pool as one group so nothing else is on the "
+                    "chip.  On this workload no kernel is bound by HBM: the scene (a few MB of four-wide nodes and triangles) is served by L1 / L2 / "
+                    "Infinity Cache and HBM carries the path-state stream; k_extend and k_connect are bound by VALU issue at partial lane "
+                    "occupancy, k_shade by VALU issue and its own dependent loads (valu_issue, valu_lane_utilisation, wave_cycles_waiting of each "
+                    "entry).  `algorithmic` is SURVEY.md section 8(d)'s reference-layout figure for k_extend (64 B per binary node visit, 68 B per "
+                    "primitive test, counted by the counting build on the binary tree): a cache-served rate that can exceed the HBM peak.  "
+                    "`hbm_resident_scene` is k_extend on BASELINE configs[4], whose 1 GB of four-wide nodes and 1.4 GB of triangles do come from HBM.",
             "algorithmic": {
+                "kernel": "k_extend",
                 "bytes_per_launch": solo["alg_bytes_per_launch"] if solo else None,
                 "achieved": solo["achieved"] if solo else None,
                 "frac": solo["frac"] if solo else None,
@@ -285,16 +328,19 @@ def main():
                 "rays_per_sample": round((ext_rays + sh_rays) / total_samples, 3),
             },
             "hbm_resident_scene": ({"workload": "BASELINE configs[4] stand-in (29 M triangles), " + rec5["command"].split("--no-cpu-baseline")[-1].strip(),
-                                    "avg_launch_ms": rec5.get("avg_ms"), "traffic": rec5.get("hbm_bytes_per_dispatch"),
+                                    "kernel": rec5["name"], "avg_launch_ms": rec5.get("avg_ms"), "traffic": rec5.get("hbm_bytes_per_dispatch"),
                                     "achieved": rec5.get("hbm_gbs"), "frac": rec5.get("hbm_frac_of_8TBs"),
+                                    "gather_ceiling_gbs": 3450.0,
                                     "valu_issue": rec5.get("valu_issue"), "valu_lane_utilisation": rec5.get("valu_lane_utilisation"),
-                                    "source": "recorded: profiles/r2_solo_cfg5.json"} if rec5 else None),
-        }
+                                    "source": "profiles/r3_solo_cfg5.json; gather ceiling = random 64 B records from a 2 GiB table, "
+                                              "profiles/r3_fetch_size_calibration.txt"} if rec5 else None),
+        })
         valu = None
-        if rec2 and rec2.get("valu_issue") is not None:
-            valu = {"kernel": "k_extend", "issue": rec2["valu_issue"], "lane_utilisation": rec2["valu_lane_utilisation"],
-                    "useful": round(rec2["valu_issue"] * rec2["valu_lane_utilisation"], 4),
-                    "source": "recorded: profiles/r2_solo_cfg2.json (SQ_INSTS_VALU x 4 / (GRBM_GUI_ACTIVE x 128); SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64))",
+        ext = per_kernel.get("extend")
+        if ext and ext.get("valu_issue") is not None:
+            valu = {"kernel": ext["kernel"], "issue": ext["valu_issue"], "lane_utilisation": ext["valu_lane_utilisation"],
+                    "useful": round(ext["valu_issue"] * ext["valu_lane_utilisation"], 4),
+                    "source": "recorded: %s (SQ_INSTS_VALU x 4 / (GRBM_GUI_ACTIVE x 128); SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64))" % solo_rel,
                     "note": "the binding resource of the traversal kernels on this workload: share of SIMD cycles that issue a VALU instruction x share of "
                             "the 64 lanes those instructions keep busy"}
         out = {
@@ -316,7 +362,9 @@ def main():
                             + ", %dx%d, depth %d, %d spp, seed 1337" % (args.width, args.height, args.depth, args.spp)
                             + (", metalSemantics %d" % args.semantics if args.semantics else ""),
                 "partition": "8-row bands round-robin over %d rank(s), RCCL gather of the HDR buffer" % world,
-                "bvh_upload_s": round(upload_s, 3),
+                "bvh_build_s": round(bvh_build_s, 3),     # host: bake, SAH build, leaf order, wide nodes (once per node: rank 0)
+                "upload_s": round(upload_s - (timings["geometry_s"] if world == 1 else 0.0), 3),   # shading tables + copies to the device (+ reading the prepared geometry when N > 1), this rank
+                "geometry_shared": bool(world > 1),
             },
             "roofline": roofline,
             "valu": valu,

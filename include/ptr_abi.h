@@ -265,6 +265,19 @@ void ptr_scene_release(PtrDeviceScene* scene);
 
 /* BVH facts for tests/diagnostics: [0]=nodes,[1]=leaves,[2]=triangles,[3]=spheres,[4]=max depth,[5]=max leaf size */
 int ptr_scene_info(const PtrDeviceScene* scene, uint64_t out[8]);
+/* Where the upload's time went: [0] geometry preparation on the host (bake, BVH build, leaf order, wide nodes) or reading it from a
+ * geometry cache, [1] shading tables (materials, lights, environment alias tables, texture mips), [2] copies to the device,
+ * [3] 1.0 when the geometry came from a cache file. */
+int ptr_scene_timings(const PtrDeviceScene* scene, double out[4]);
+
+/* One BVH build for the processes of a multi-GPU render (one process per device).  ptr_scene_prepare_geometry runs the
+ * device-independent geometry preparation on the host - no GPU call - and writes it to cache_path (a file under /dev/shm);
+ * ptr_scene_upload_prepared is ptr_scene_upload with the geometry read from that file instead of built.  The file carries a
+ * fingerprint of the scene description; a process holding another description is refused.
+ * ("BVH build once"; the reference builds per process, SceneAccel.mm:23-325.) */
+int ptr_scene_prepare_geometry(const PtrSceneDesc* scene, const char* cache_path, double* seconds, char* err, size_t err_cap);
+int ptr_scene_upload_prepared(const PtrSceneDesc* scene, const char* cache_path, int device, PtrDeviceScene** out_scene,
+                              char* err, size_t err_cap);
 
 /* Render the whole image, result copied to host `out_rgb` (width*height*3, row 0 = top). */
 int ptr_render(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t spp, int verbose,

@@ -36,7 +36,8 @@ int ptr_debug_render_signatures(PtrDeviceScene* scene, const PtrSettings* settin
 int ptr_debug_texture_sample(PtrDeviceScene* scene, uint32_t texture, const float* in, uint64_t n, float* out, char* err, size_t err_cap);
 
 /* ptr_render_multi on an explicit list of devices; an id may appear more than once, which lets a one-GPU box run the whole
- * multi-device path (threads, partitions, hand-over, interleave). */
+ * multi-device path (threads, partitions, hand-over, interleave).  An id given as -(id + 1) routes that partition's bands through the
+ * pinned-host staging copy ptr_render_multi falls back to when two devices cannot address each other (hipDeviceCanAccessPeer). */
 int ptr_debug_render_multi_on(const PtrSceneDesc* scene, const PtrSettings* settings, uint32_t spp, const int* device_ids, int n,
                               float* out_rgb, PtrRenderStats* stats, char* err, size_t err_cap);
 

@@ -213,6 +213,7 @@ ABI_SYMBOLS = (
     "ptr_render_bands_device", "ptr_part_band_count", "ptr_render_bands", "ptr_trace_rays", "ptr_render_aovs",
     "ptr_host_scene_load", "ptr_host_scene_free", "ptr_host_scene_desc", "ptr_host_write_image", "ptr_host_write_exr_multilayer",
     "ptr_host_read_pfm", "ptr_version", "ptr_render_multi", "ptr_host_write_exr_aovs", "ptr_host_decode_image",
+    "ptr_scene_timings", "ptr_scene_prepare_geometry", "ptr_scene_upload_prepared",
 )
 # include/ptr_debug.h (test-only device-function probes)
 DEBUG_SYMBOLS = ("ptr_debug_eval_bsdf", "ptr_debug_sample_bsdf", "ptr_debug_camera_rays", "ptr_debug_env_distribution",
@@ -238,6 +239,9 @@ def load_library() -> C.CDLL:
     lib.ptr_device_count.restype = C.c_int
     lib.ptr_scene_upload.argtypes = [C.POINTER(PtrSceneDesc), C.c_int, C.POINTER(vp), cp, sz]
     lib.ptr_scene_release.argtypes = [vp]
+    lib.ptr_scene_timings.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.ptr_scene_prepare_geometry.argtypes = [C.POINTER(PtrSceneDesc), cp, C.POINTER(C.c_double), cp, sz]
+    lib.ptr_scene_upload_prepared.argtypes = [C.POINTER(PtrSceneDesc), cp, C.c_int, C.POINTER(vp), cp, sz]
     lib.ptr_scene_release.restype = None
     lib.ptr_scene_info.argtypes = [vp, C.POINTER(u64)]
     lib.ptr_render.argtypes = [C.POINTER(PtrSceneDesc), C.POINTER(PtrSettings), u32, C.c_int, C.POINTER(C.c_float),
@@ -357,17 +361,38 @@ class HostScene:
 # ----------------------------------------------------------------------------- device path
 
 
+def prepare_geometry(desc: PtrSceneDesc, path: str) -> float:
+    """Host-only: bake the scene, build the BVH and write the device-independent arrays to `path` (a file under /dev/shm) for
+    DeviceScene(..., prepared=path) in this or another process.  No GPU call.  Returns the seconds it took."""
+    lib = load_library()
+    err = _err_buf()
+    seconds = C.c_double(0.0)
+    _check(lib.ptr_scene_prepare_geometry(C.byref(desc), path.encode(), C.byref(seconds), err, len(err)), err)
+    return float(seconds.value)
+
+
 class DeviceScene:
     """A scene resident in HBM: SAH BVH + SoA primitive/material/light arrays (ptr_scene_upload)."""
 
-    def __init__(self, desc: PtrSceneDesc, device: int = 0, keepalive=None):
+    def __init__(self, desc: PtrSceneDesc, device: int = 0, keepalive=None, prepared: Optional[str] = None):
+        """prepared: a geometry cache written by prepare_geometry() for this description - the BVH is read, not built
+        (the processes of a multi-GPU render build it once)."""
         lib = load_library()
         if lib.ptr_device_count() <= 0:
             raise PtrError("no HIP device visible: the HIP render path has no CPU fallback")
         self._keepalive = keepalive
         self._h = C.c_void_p()
         err = _err_buf()
-        _check(lib.ptr_scene_upload(C.byref(desc), device, C.byref(self._h), err, len(err)), err)
+        if prepared:
+            _check(lib.ptr_scene_upload_prepared(C.byref(desc), prepared.encode(), device, C.byref(self._h), err, len(err)), err)
+        else:
+            _check(lib.ptr_scene_upload(C.byref(desc), device, C.byref(self._h), err, len(err)), err)
+
+    def timings(self) -> dict:
+        """Seconds of the upload: geometry preparation (or cache read), shading tables, copies to the device."""
+        out = (C.c_double * 4)()
+        load_library().ptr_scene_timings(self._h, out)
+        return {"geometry_s": out[0], "shading_tables_s": out[1], "copy_s": out[2], "geometry_from_cache": bool(out[3])}
 
     def info(self) -> dict:
         out = (C.c_uint64 * 8)()

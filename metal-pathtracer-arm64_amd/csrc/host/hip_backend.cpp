@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -23,6 +24,7 @@
 #include "../kernels/launch.h"
 #include "bvh_builder.h"
 #include "env_importance_sampler.h"
+#include "geometry_cache.h"
 #include "knobs.h"
 #include "parallel.h"
 #include "ptr_abi.h"
@@ -123,6 +125,7 @@ struct PtrDeviceScene {
     SceneView view{};
     uint64_t info[8] = {0};
     double uploadSeconds = 0.0;
+    double timings[4] = {0.0, 0.0, 0.0, 0.0};   // geometry preparation (or cache read), shading tables, copies to the device, 1 = geometry came from a cache
     uint64_t deviceTotalBytes = 0;        // hipDeviceProp_t::totalGlobalMem
     bool hasRandomWalkMaterial = false;   // a type-5 material with sssParams.y >= 0.5 (Metal random-walk subsurface)
 
@@ -199,7 +202,7 @@ void compactMaterial(const PtrMaterial& m, std::vector<float>& out) {
 // Device-independent half of a scene upload: geometry bake + BVH, compact materials, light list, environment tables.  Built once
 // and uploaded to every device a frame is rendered on (ptr_render_multi).
 struct PreparedScene {
-    ptr::SceneGeometry geo;
+    ptr::PreparedGeometry pg;   // BVH, leaf-order arrays, four-wide nodes, node format: what a geometry cache file holds
     std::vector<float> mats, lights;
     std::vector<int32_t> lightIndexByRect;
     uint32_t lightCount = 0;
@@ -212,12 +215,10 @@ struct PreparedScene {
     std::vector<float> texels;
     std::vector<uint32_t> texInfo;
     std::vector<float> materialTex;
-    // node format of the persistent kernels, decided once for all devices: 32 B quantised nodes unless the 16-bit grid is coarse next
-    // to the primitives, and the four-wide array derived from them (bvh_builder.h BuildWideNodes)
-    bool useQuantized = false;
-    std::unique_ptr<uint32_t[]> wide;
-    uint32_t wideCount = 0;
-    double seconds = 0.0;
+    double geometrySeconds = 0.0;   // bake + BVH + leaf order + wide nodes, or reading them from a geometry cache
+    double shadingSeconds = 0.0;    // materials, lights, environment tables, texture mips
+    bool geometryFromCache = false;
+    double seconds = 0.0;           // both
 };
 
 // Mip chain of one texture appended to `texels`: level l + 1 halves both sizes (at least 1) and averages the 2x2 block of level
@@ -258,24 +259,36 @@ void appendTextureWithMips(const PtrTexture& t, std::vector<float>& texels, std:
     }
 }
 
-void prepareScene(const PtrSceneDesc& desc, PreparedScene& ps) {
-    const auto t0 = std::chrono::steady_clock::now();
+// The geometry half of the preparation: everything a geometry cache file holds (host/geometry_cache.h).
+void prepareGeometry(const PtrSceneDesc& desc, ptr::PreparedGeometry& pg) {
     const ptr::Knobs knobs = ptr::readKnobs();
     std::string geoError;
-    if (!ptr::BuildSceneGeometry(desc, 0, ps.geo, geoError)) throw HipError{geoError};
-    {
-        // 32 B quantised nodes halve the node fetches; use them unless the 16-bit grid is coarse next to the primitives (cell > 1/8 of
-        // the mean primitive extent would inflate leaf boxes noticeably)
-        const ptr::FlatBvh& bvh = ps.geo.bvh;
-        const float maxCell = std::max(std::max(bvh.gridCell[0], bvh.gridCell[1]), bvh.gridCell[2]);
-        ps.useQuantized = bvh.nodeCount > 0 && maxCell * 8.0f <= bvh.meanPrimExtent;
-        if (knobs.quantizedNodes >= 0) ps.useQuantized = bvh.nodeCount > 0 && knobs.quantizedNodes != 0;
-        // four-wide nodes for the persistent traversal kernels; the binary array stays for the cold kernels and the counting build
-        if (ps.useQuantized && knobs.wideNodes != 0) {
-            ps.wideCount = ptr::BuildWideNodes(bvh, true, ps.wide);
-            if (static_cast<uint64_t>(ps.wideCount) * 64u > 0xFFFFFFFFull) throw HipError{"scene exceeds the 4 GiB node array limit"};
-        }
+    if (!ptr::BuildSceneGeometry(desc, 0, pg.geo, geoError)) throw HipError{geoError};
+    // 32 B quantised nodes halve the node fetches; use them unless the 16-bit grid is coarse next to the primitives (cell > 1/8 of
+    // the mean primitive extent would inflate leaf boxes noticeably)
+    const ptr::FlatBvh& bvh = pg.geo.bvh;
+    const float maxCell = std::max(std::max(bvh.gridCell[0], bvh.gridCell[1]), bvh.gridCell[2]);
+    pg.useQuantized = bvh.nodeCount > 0 && maxCell * 8.0f <= bvh.meanPrimExtent;
+    if (knobs.quantizedNodes >= 0) pg.useQuantized = bvh.nodeCount > 0 && knobs.quantizedNodes != 0;
+    // four-wide nodes for the persistent traversal kernels; the binary array stays for the cold kernels and the counting build
+    if (pg.useQuantized && knobs.wideNodes != 0) {
+        pg.wideCount = ptr::BuildWideNodes(bvh, true, pg.wide);
+        if (static_cast<uint64_t>(pg.wideCount) * 64u > 0xFFFFFFFFull) throw HipError{"scene exceeds the 4 GiB node array limit"};
     }
+}
+
+// cachePath (may be null): read the geometry from that file instead of building it
+void prepareScene(const PtrSceneDesc& desc, PreparedScene& ps, const char* cachePath = nullptr) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (cachePath && *cachePath) {
+        std::string error;
+        if (!ptr::ReadGeometryCache(cachePath, ptr::SceneFingerprint(desc), ps.pg, error)) throw HipError{error};
+        ps.geometryFromCache = true;
+    } else {
+        prepareGeometry(desc, ps.pg);
+    }
+    ps.geometrySeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const ptr::SceneGeometry& geoRef = ps.pg.geo;
 
     // compact materials
     ps.mats.reserve(static_cast<size_t>(desc.materialCount) * kMaterialVec4 * 4);
@@ -302,14 +315,14 @@ void prepareScene(const PtrSceneDesc& desc, PreparedScene& ps) {
             put4(ps.lights, ev, bitsToFloat(i));
             // rows 5..10: the light's own two triangles exactly as the traversal reads them (leaf-order records), for k_shade's
             // self-occlusion test of a light sample; normal.w = 1 when they are present
-            const uint32_t t0 = ps.geo.rectTriLeaf[static_cast<size_t>(i) * 2u], t1 = ps.geo.rectTriLeaf[static_cast<size_t>(i) * 2u + 1u];
+            const uint32_t t0 = geoRef.rectTriLeaf[static_cast<size_t>(i) * 2u], t1 = geoRef.rectTriLeaf[static_cast<size_t>(i) * 2u + 1u];
             const bool haveTris = t0 != 0xFFFFFFFFu && t1 != 0xFFFFFFFFu;
             put4(ps.lights, n, haveTris ? 1.0f : 0.0f);
             ps.lightsHaveTriangles = ps.lightsHaveTriangles && haveTris;
             put4(ps.lights, e, 0.0f);
             for (uint32_t t : {t0, t1}) {
                 for (int row = 0; row < 3; ++row) {
-                    const float* src = haveTris ? &ps.geo.triData[static_cast<size_t>(t) * 12u + static_cast<size_t>(row) * 4u] : nullptr;
+                    const float* src = haveTris ? &geoRef.triData[static_cast<size_t>(t) * 12u + static_cast<size_t>(row) * 4u] : nullptr;
                     for (int c = 0; c < 4; ++c) ps.lights.push_back(src ? src[c] : 0.0f);
                 }
             }
@@ -319,7 +332,7 @@ void prepareScene(const PtrSceneDesc& desc, PreparedScene& ps) {
     if (desc.envRgba && desc.envWidth > 0 && desc.envHeight > 0) {
         ps.hasEnvDist = ptr::BuildEnvImportanceDistribution(desc.envRgba, desc.envWidth, desc.envHeight, &ps.envDist);
     }
-    if (desc.textures && desc.textureCount > 0 && !ps.geo.triUv.empty()) {
+    if (desc.textures && desc.textureCount > 0 && !geoRef.triUv.empty()) {
         for (uint32_t i = 0; i < desc.textureCount; ++i) {
             if (!desc.textures[i].rgba || desc.textures[i].width == 0 || desc.textures[i].height == 0) throw HipError{"texture without pixels"};
             appendTextureWithMips(desc.textures[i], ps.texels, ps.texInfo);
@@ -342,11 +355,12 @@ void prepareScene(const PtrSceneDesc& desc, PreparedScene& ps) {
         }
     }
     ps.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ps.shadingSeconds = ps.seconds - ps.geometrySeconds;
 }
 
 void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceScene& ds) {
     const auto t0 = std::chrono::steady_clock::now();
-    const ptr::SceneGeometry& geo = ps.geo;
+    const ptr::SceneGeometry& geo = ps.pg.geo;
     const ptr::FlatBvh& bvh = geo.bvh;
     const uint32_t triCount = geo.triCount;
     const uint32_t lightCount = ps.lightCount;
@@ -355,7 +369,7 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     HIP_CHECK(hipSetDevice(ds.device));
     // only the node array the kernels will read goes to the device (a 29 M-triangle scene: 0.5 GB instead of 1.5 GB of nodes)
     const ptr::Knobs knobs = ptr::readKnobs();
-    const bool useQuantized = ps.useQuantized;
+    const bool useQuantized = ps.pg.useQuantized;
     if (useQuantized) {
         ds.nodes.release();
         ds.qnodes.upload(reinterpret_cast<const uint4*>(bvh.qnodes.data()), bvh.qnodes.size() / 4);
@@ -388,10 +402,10 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     std::memcpy(v.gridCell, bvh.gridCell, sizeof(v.gridCell));
     for (int a = 0; a < 3; ++a) v.gridInvCell[a] = 1.0f / bvh.gridCell[a];
     v.useQuantized = useQuantized ? 1u : 0u;
-    if (ps.wideCount > 0u) {
-        ds.wnodes.upload(reinterpret_cast<const uint4*>(ps.wide.get()), static_cast<size_t>(ps.wideCount) * 4u);
+    if (ps.pg.wideCount > 0u) {
+        ds.wnodes.upload(reinterpret_cast<const uint4*>(ps.pg.wide.get()), static_cast<size_t>(ps.pg.wideCount) * 4u);
         v.wnodes = ds.wnodes.ptr;
-        v.wideBytes = static_cast<uint32_t>(static_cast<size_t>(ps.wideCount) * 64u);
+        v.wideBytes = static_cast<uint32_t>(static_cast<size_t>(ps.pg.wideCount) * 64u);
         v.useWide = 1u;
     }
     const size_t nodeBytes = v.useQuantized ? bvh.qnodes.size() * 4u : bvh.nodes.size() * 4u;
@@ -476,12 +490,16 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ds.pinnedAlive), sizeof(uint32_t) * (kPinnedHeadsOffset + kItemHeads), hipHostMallocDefault));
     const double copySeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ds.uploadSeconds = ps.seconds + copySeconds;
+    ds.timings[0] = ps.geometrySeconds;
+    ds.timings[1] = ps.shadingSeconds;
+    ds.timings[2] = copySeconds;
+    ds.timings[3] = ps.geometryFromCache ? 1.0 : 0.0;
     if (knobs.verboseBuild) std::fprintf(stderr, "[upload] prepare %.2f s, copies to the device %.2f s\n", ps.seconds, copySeconds);
 }
 
-void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds) {
+void buildScene(const PtrSceneDesc& desc, PtrDeviceScene& ds, const char* cachePath = nullptr) {
     PreparedScene ps;
-    prepareScene(desc, ps);
+    prepareScene(desc, ps, cachePath);
     uploadScene(desc, ps, ds);
 }
 
@@ -1153,6 +1171,48 @@ int ptr_scene_info(const PtrDeviceScene* scene, uint64_t out[8]) {
     return 0;
 }
 
+int ptr_scene_timings(const PtrDeviceScene* scene, double out[4]) {
+    if (!scene || !out) return 1;
+    std::memcpy(out, scene->timings, sizeof(scene->timings));
+    return 0;
+}
+
+int ptr_scene_prepare_geometry(const PtrSceneDesc* scene, const char* cache_path, double* seconds, char* err, size_t err_cap) {
+    if (!scene || !cache_path || !*cache_path) {
+        setErr(err, err_cap, "ptr_scene_prepare_geometry: null argument");
+        return 1;
+    }
+    try {
+        const auto t0 = std::chrono::steady_clock::now();
+        ptr::PreparedGeometry pg;
+        prepareGeometry(*scene, pg);
+        std::string error;
+        if (!ptr::WriteGeometryCache(cache_path, pg, ptr::SceneFingerprint(*scene), error)) throw HipError{error};
+        if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    }
+    PTR_CATCH_ALL(err, err_cap)
+}
+
+int ptr_scene_upload_prepared(const PtrSceneDesc* scene, const char* cache_path, int device, PtrDeviceScene** out_scene, char* err, size_t err_cap) {
+    if (!scene || !out_scene || !cache_path || !*cache_path) {
+        setErr(err, err_cap, "ptr_scene_upload_prepared: null argument");
+        return 1;
+    }
+    if (ptr_device_count() <= device || device < 0) {
+        setErr(err, err_cap, "ptr_scene_upload_prepared: no such HIP device (the HIP path has no CPU fallback)");
+        return 2;
+    }
+    try {
+        auto ds = std::make_unique<PtrDeviceScene>();
+        ds->device = device;
+        buildScene(*scene, *ds, cache_path);
+        *out_scene = ds.release();
+        return 0;
+    }
+    PTR_CATCH_ALL(err, err_cap)
+}
+
 int ptr_render_bands_device(PtrDeviceScene* scene, const PtrSettings* settings, uint32_t spp, uint32_t part_index,
                             uint32_t part_count, void* d_out_rgb, void* stream, int count_traversal,
                             PtrRenderStats* stats, char* err, size_t err_cap) {
@@ -1231,9 +1291,15 @@ static int renderMulti(const PtrSceneDesc* scene, const PtrSettings* settings, u
         if (settings->width == 0 || settings->height == 0) throw HipError{"render size must be non-zero"};
         const int available = ptr_device_count();
         if (available < 1) throw HipError{"no HIP device (the HIP path has no CPU fallback)"};
+        // (test hook of ptr_debug_render_multi_on: an id given as -(id + 1) sends that partition's bands through the host-staging path)
+        std::vector<int> devices(static_cast<size_t>(n));
+        std::vector<char> forceStaged(static_cast<size_t>(n), 0);
         for (int i = 0; i < n; ++i) {
-            if (device_ids[i] < 0 || device_ids[i] >= available) throw HipError{"ptr_render_multi: no such HIP device"};
+            forceStaged[static_cast<size_t>(i)] = device_ids[i] < 0 ? 1 : 0;
+            devices[static_cast<size_t>(i)] = device_ids[i] < 0 ? -device_ids[i] - 1 : device_ids[i];
+            if (devices[static_cast<size_t>(i)] >= available) throw HipError{"ptr_render_multi: no such HIP device"};
         }
+        device_ids = devices.data();
         const auto t0 = std::chrono::steady_clock::now();
         PreparedScene prepared;
         prepareScene(*scene, prepared);
@@ -1257,6 +1323,7 @@ static int renderMulti(const PtrSceneDesc* scene, const PtrSettings* settings, u
         std::vector<PtrRenderStats> partStats(parts);
         std::vector<std::string> errors(parts);
         std::vector<double> uploadSeconds(parts, 0.0), renderSeconds(parts, 0.0);
+        std::atomic<uint32_t> stagedParts{0};   // partitions whose bands went through host memory (no peer access)
         auto worker = [&](uint32_t p) {
             try {
                 const auto w0 = std::chrono::steady_clock::now();
@@ -1271,9 +1338,34 @@ static int renderMulti(const PtrSceneDesc* scene, const PtrSettings* settings, u
                 HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
                 const auto r0 = std::chrono::steady_clock::now();
                 renderBands(*ds, *settings, spp, p, parts, ds->outBands.ptr, stream, 0, &partStats[p]);
-                // the partition's bands travel to the first device (device-to-device over the fabric; a plain copy when it is local)
-                if (floats) {
-                    HIP_CHECK(hipMemcpyPeerAsync(gathered.ptr + partOffset[p], rootDevice, ds->outBands.ptr, ds->device, floats * sizeof(float), stream));
+                // the partition's bands travel to the first device: a plain copy when it is local, device-to-device over the fabric
+                // (xGMI between the GPUs of a node) when the two devices can address each other, through pinned host memory otherwise
+                if (floats && ds->device == rootDevice && !forceStaged[p]) {
+                    HIP_CHECK(hipMemcpyAsync(gathered.ptr + partOffset[p], ds->outBands.ptr, floats * sizeof(float), hipMemcpyDeviceToDevice, stream));
+                } else if (floats) {
+                    int direct = 0;
+                    if (ds->device != rootDevice) HIP_CHECK(hipDeviceCanAccessPeer(&direct, ds->device, rootDevice));
+                    if (forceStaged[p]) direct = 0;
+                    if (direct) {
+                        const hipError_t enabled = hipDeviceEnablePeerAccess(rootDevice, 0);   // (this thread's current device is ds->device)
+                        if (enabled != hipSuccess && enabled != hipErrorPeerAccessAlreadyEnabled) direct = 0;
+                        (void)hipGetLastError();
+                    }
+                    if (direct) {
+                        HIP_CHECK(hipMemcpyPeerAsync(gathered.ptr + partOffset[p], rootDevice, ds->outBands.ptr, ds->device, floats * sizeof(float), stream));
+                    } else {
+                        std::fprintf(stderr, "[ptr] device %d does not address device %d directly: its bands go through pinned host memory\n", ds->device, rootDevice);
+                        float* staging = nullptr;
+                        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&staging), floats * sizeof(float), hipHostMallocDefault));
+                        hipError_t copied = hipMemcpyAsync(staging, ds->outBands.ptr, floats * sizeof(float), hipMemcpyDeviceToHost, stream);
+                        if (copied == hipSuccess) copied = hipStreamSynchronize(stream);
+                        if (copied == hipSuccess) copied = hipSetDevice(rootDevice);
+                        if (copied == hipSuccess) copied = hipMemcpy(gathered.ptr + partOffset[p], staging, floats * sizeof(float), hipMemcpyHostToDevice);
+                        (void)hipSetDevice(ds->device);
+                        (void)hipHostFree(staging);
+                        HIP_CHECK(copied);
+                        stagedParts.fetch_add(1);
+                    }
                 }
                 HIP_CHECK(hipStreamSynchronize(stream));
                 renderSeconds[p] = std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();

@@ -77,3 +77,44 @@ def test_assemble_matches_numpy_reference_for_many_partitions():
             trimmed = [p.numpy()[: bands.band_count(height, r, world) * bands.BAND_ROWS] for r, p in enumerate(parts)]
             assert np.array_equal(pt.assemble_bands(trimmed, 8, height), img)
             assert [bands.band_count(height, r, world) for r in range(world)] == [pt.band_count(height, r, world) for r in range(world)]
+
+
+def _geometry_worker(rank, world, port, scene_path, scenes_dir, cache_path, result_path):
+    """bench.py's setup with N > 1: rank 0 prepares the geometry once (host only) and the others find the finished file after the
+    barrier - never half a file (it is written under a temporary name and renamed)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pt = importlib.import_module("metal-pathtracer-arm64_amd")
+        host = pt.HostScene.load(scene_path, scenes_dir)
+        if rank == 0:
+            seconds = pt.prepare_geometry(host.desc, cache_path)
+            assert seconds > 0.0
+        dist.barrier()
+        assert os.path.exists(cache_path) and not os.path.exists(cache_path + ".tmp")
+        size = os.path.getsize(cache_path)
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([size], dtype=torch.int64))
+        assert all(int(s.item()) == size for s in sizes)
+        if rank == 1:
+            with open(result_path, "w") as f:
+                f.write(str(size))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_prepared_geometry(tmp_path):
+    scenes = os.path.join(ROOT, "scenes")
+    cache = str(tmp_path / "geometry.bin")
+    out = str(tmp_path / "size.txt")
+    mp.spawn(_geometry_worker, args=(2, _free_port(), os.path.join(ROOT, "tests", "golden", "cornell_small_mesh.scene"), scenes, cache, out), nprocs=2, join=True)
+    assert int(open(out).read()) > 10000
+    # the file is a function of the scene alone: a second preparation writes the same bytes (the builder is deterministic)
+    pt = importlib.import_module("metal-pathtracer-arm64_amd")
+    host = pt.HostScene.load(os.path.join(ROOT, "tests", "golden", "cornell_small_mesh.scene"), scenes)
+    again = str(tmp_path / "again.bin")
+    pt.prepare_geometry(host.desc, again)
+    a, b = open(cache, "rb").read(), open(again, "rb").read()
+    # (the header carries the three phase timings of the preparation: bytes 0..7 magic, 8..15 fingerprint; compare those and the arrays)
+    assert a[:16] == b[:16] and len(a) == len(b) and a[256:] == b[256:]

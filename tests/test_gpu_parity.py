@@ -514,6 +514,55 @@ def test_specular_connections_settled_in_shade_and_traced(tmp_path):
         dev.close()
 
 
+def test_scene_from_a_prepared_geometry_file(tmp_path, cornell_small):
+    # one BVH build for the processes of a multi-GPU render: the geometry written by prepare_geometry (host only) gives the same
+    # device scene as building it in place - same tree, same image bit for bit; a file made for another scene is refused
+    host, dev, _ = cornell_small
+    path = str(tmp_path / "geometry.bin")
+    assert pt.prepare_geometry(host.desc, path) > 0.0
+    shared = pt.DeviceScene(host.desc, 0, keepalive=host, prepared=path)
+    assert shared.info() == dev.info() and shared.timings()["geometry_from_cache"] and not dev.timings()["geometry_from_cache"]
+    s = host.settings_for(width=72, height=56, max_depth=5)
+    assert np.array_equal(shared.render_image(s, 4)[0], dev.render_image(s, 4)[0])
+    shared.close()
+    other = pt.HostScene.load(os.path.join(SCENES, "cornell.scene"), SCENES)
+    with pytest.raises(pt.PtrError, match="another scene"):
+        pt.DeviceScene(other.desc, 0, keepalive=other, prepared=path)
+    with pytest.raises(pt.PtrError, match="cannot open"):
+        pt.DeviceScene(host.desc, 0, keepalive=host, prepared=str(tmp_path / "missing.bin"))
+
+
+def test_rccl_gather_and_reduce_on_the_device(tmp_path):
+    # bench.py --gpus N: one process per GPU, RCCL gather of the band buffers to rank 0 and an all_reduce(MAX) of the timing.  A
+    # one-GPU box can only run world size 1, but that still loads RCCL, creates the communicator on the device and drives both
+    # collectives on device buffers (in a child process: a process group is per process)
+    import subprocess
+    import sys
+    code = """
+import importlib, os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, HSA_ENABLE_IPC_MODE_LEGACY="0")
+bands = importlib.import_module("metal-pathtracer-arm64_amd.bands")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+rows = bands.max_band_count(40, 1) * bands.BAND_ROWS
+local = torch.arange(rows * 24 * 3, dtype=torch.float32, device="cuda").reshape(rows, 24, 3)
+recv = [torch.empty_like(local)]
+dist.gather(local, gather_list=recv, dst=0)          # the collective gather_bands issues when there is more than one rank
+img = bands.assemble(recv, 40)
+assert img.is_cuda and torch.equal(img, local[:40]) and torch.equal(bands.gather_bands(local, 40, 0, 1), img)
+t = torch.tensor([1.25], dtype=torch.float64, device="cuda")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert t.item() == 1.25
+dist.barrier()
+dist.destroy_process_group()
+print("rccl ok")
+""" % (ROOT, str(29500 + os.getpid() % 2000))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "rccl ok" in res.stdout, res.stderr[-2000:]
+
+
 def test_partition_and_pool_size_invariance(cornell_small):
     host, dev, _ = cornell_small
     s = host.settings_for(width=72, height=56, max_depth=5)
@@ -733,7 +782,8 @@ def test_multi_device_render_matches_single_device(cornell_small):
     host, dev, _ = cornell_small
     s = host.settings_for(width=88, height=72, max_depth=5, seed=1337)
     single, _ = dev.render_image(s, 6)
-    for ids in ([0], [0, 0], [0, 0, 0], [0] * 9):             # 9 bands of 8 rows: the last case gives every partition one band
+    # ids given as -(id + 1): that partition's bands take the pinned-host staging path (devices that cannot address each other)
+    for ids in ([0], [0, 0], [0, 0, 0], [0] * 9, [0, -1, -1]):   # 9 bands of 8 rows: [0] * 9 gives every partition one band
         multi, st = pt.render_multi(host.desc, s, 6, device_ids=ids)
         assert np.array_equal(multi, single), ids             # bit-identical, whatever the number of partitions
         assert st.samples == 88 * 72 * 6 and st.totalSeconds > 0

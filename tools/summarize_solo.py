@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Turn one tools/measure_solo.sh directory into a per-kernel JSON record:
-durations from the --stats pass, HBM-side bytes from the FETCH_SIZE / WRITE_SIZE passes (FETCH doubled: on gfx950 the counter
-tallies the 128 B requests of wide reads at 64 B, MI355X_MICROARCH.md section HBM; both are reported in KB), VALU lane
+durations from the --stats pass, HBM-side bytes from the FETCH_SIZE / WRITE_SIZE passes (both reported in KB).  FETCH_SIZE books
+64 B per fabric request: right for scattered 16-64 B fetches, half the bytes for the 128 B requests of wide coalesced reads
+(profiles/r3_fetch_size_calibration.txt), so  hbm bytes = FETCH_SIZE + WRITE_SIZE + (streamed read bytes) / 2  with the streamed
+bytes a kernel is known to read in slot order (STREAM_BYTES_PER_SLOT x the slots of a launch; everything for the reductions).  VALU lane
 utilisation = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64), VALU issue = SQ_INSTS_VALU x 4 / (GRBM_GUI_ACTIVE x 128),
 share of the waves' cycles spent waiting = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES."""
 import csv
@@ -36,7 +38,27 @@ for path in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv
             tot[k][c] += float(row.get("Counter_Value", 0) or 0)
             calls[k][c] += 1
 HBM_PEAK = 8.0e12
+# coalesced reads per path slot and launch (16 B per lane, lanes on consecutive slots): k_extend walks ray0 + ray1, k_shade ray1, ray0, hit,
+# thr and accum; k_connect's records and every scene fetch are gathers.  The reductions read nothing but streams.
+STREAM_BYTES_PER_SLOT = {"k_extend": 32.0, "k_shade<": 72.0}
+ALL_STREAM = ("k_resolve", "k_flush", "k_generate", "k_tail_collect")
+
+
+def pool_slots(bench_args):
+    """Slots of a --solo launch (the whole pool as one group), as csrc/host/hip_backend.cpp sizes it."""
+    import re
+    def opt(name, default):
+        m = re.search(r"--%s[ =](\d+)" % name, bench_args)
+        return int(m.group(1)) if m else default
+    items = opt("width", 1920) * opt("height", 1080) * opt("spp", 256)
+    return min(32 << 20, max(1 << 20, items // 2), items) & ~255
+
+
+SLOTS = pool_slots(args)
 rec = {"command": "rocprofv3 --kernel-trace [--stats | --pmc <group>] -- python3 bench.py --solo --steps 1 --warmup 1 --no-cpu-baseline " + args,
+       "pool_slots": SLOTS,
+       "hbm_bytes": "FETCH_SIZE + WRITE_SIZE + streamed_read_bytes / 2 (FETCH_SIZE books the 128 B requests of coalesced reads at 64 B and "
+                    "every scattered fetch at the 64 B it moves: profiles/r3_fetch_size_calibration.txt)",
        "note": "pool as ONE group: kernels never overlap; per-dispatch means over every dispatch of the process (warm-up, timed step, solo "
                "re-render); <true,..> instantiations are the counting build of bench.py's extra render",
        "kernels": {}}
@@ -50,10 +72,17 @@ for k in sorted(set(dur) | set(tot)):
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c and k in dur and dur[k]["avg_ms"] > 0:
         fetch = c["FETCH_SIZE"] / max(calls[k]["FETCH_SIZE"], 1) * 1024.0
         write = c["WRITE_SIZE"] / max(calls[k]["WRITE_SIZE"], 1) * 1024.0
-        hbm = 2.0 * fetch + write
+        if k.startswith(ALL_STREAM):
+            streamed = 2.0 * fetch
+        else:
+            per_slot = next((v for key, v in STREAM_BYTES_PER_SLOT.items() if k.startswith(key)), 0.0)
+            streamed = min(per_slot * SLOTS, 2.0 * fetch)   # (an end-of-frame launch over a drained pool reads less)
+        hbm = fetch + 0.5 * streamed + write
         r.update({"fetch_size_bytes_per_dispatch": round(fetch), "write_size_bytes_per_dispatch": round(write),
+                  "streamed_read_bytes_per_dispatch": round(streamed),
                   "hbm_bytes_per_dispatch": round(hbm), "hbm_gbs": round(hbm / (dur[k]["avg_ms"] * 1e-3) / 1e9, 1),
-                  "hbm_frac_of_8TBs": round(hbm / (dur[k]["avg_ms"] * 1e-3) / HBM_PEAK, 4)})
+                  "hbm_frac_of_8TBs": round(hbm / (dur[k]["avg_ms"] * 1e-3) / HBM_PEAK, 4),
+                  "hbm_bytes_if_all_reads_were_streams": round(2.0 * fetch + write)})
     if c.get("SQ_ACTIVE_INST_VALU", 0) > 0:
         r["valu_lane_utilisation"] = round(c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
         r["valu_insts_per_dispatch"] = round(c["SQ_INSTS_VALU"] / max(calls[k]["SQ_INSTS_VALU"], 1))
