@@ -56,6 +56,11 @@ int ptr_debug_env_distribution(const float* rgba, uint32_t w, uint32_t h, float*
  * persistent kernels; bit 63: those nodes have a bad reference or do not reach every primitive exactly once).  leaf_max = 0 uses the default.  Returns non-zero with a message on bad input. */
 int ptr_debug_scene_geometry(const PtrSceneDesc* scene, uint32_t leaf_max, uint64_t out[16], char* err, size_t err_cap);
 
+/* Host-side (no GPU): the tangent generator behind glTF primitives without TANGENT (csrc/host/tangent_space.cpp, the MikkTSpace method;
+ * reference: src/assets/TangentGen.mm:181-230 over external/MikkTSpace/mikktspace.c).  A triangle soup - corner c of triangle f is
+ * element 3 f + c of positions (xyz), unit normals (xyz) and uvs (st); out_tangents: xyz + sign per corner.  0 on success. */
+int ptr_debug_generate_tangents(const float* positions, const float* normals, const float* uvs, uint64_t triangle_count, float* out_tangents);
+
 #ifdef __cplusplus
 }
 #endif

@@ -217,7 +217,8 @@ ABI_SYMBOLS = (
 )
 # include/ptr_debug.h (test-only device-function probes)
 DEBUG_SYMBOLS = ("ptr_debug_eval_bsdf", "ptr_debug_sample_bsdf", "ptr_debug_camera_rays", "ptr_debug_env_distribution",
-                 "ptr_debug_scene_geometry", "ptr_debug_render_signatures", "ptr_debug_render_multi_on", "ptr_debug_texture_sample")
+                 "ptr_debug_scene_geometry", "ptr_debug_render_signatures", "ptr_debug_render_multi_on", "ptr_debug_texture_sample",
+                 "ptr_debug_generate_tangents")
 
 _lib: Optional[C.CDLL] = None
 

@@ -14,6 +14,7 @@
 #include "ptr_abi.h"
 #include "ptr_debug.h"
 #include "scene_geometry.h"
+#include "tangent_space.h"
 #include "scene_manager.h"
 
 struct PtrHostScene {
@@ -230,6 +231,14 @@ int ptr_debug_env_distribution(const float* rgba, uint32_t w, uint32_t h, float*
         if (total_weight) *total_weight = d.totalWeight;
         return 0;
     });
+}
+
+int ptr_debug_generate_tangents(const float* positions, const float* normals, const float* uvs, uint64_t triangle_count, float* out_tangents) {
+    try {
+        return ptr::GenerateTangentSpace(positions, normals, uvs, static_cast<size_t>(triangle_count), out_tangents) ? 0 : 1;
+    } catch (...) {
+        return 2;
+    }
 }
 
 int ptr_debug_scene_geometry(const PtrSceneDesc* scene, uint32_t leaf_max, uint64_t out[16], char* err, size_t err_cap) {

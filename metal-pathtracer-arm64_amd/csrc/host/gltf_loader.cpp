@@ -11,6 +11,7 @@
 // (SceneResources.mm:1279-1284); texture coordinate sets and KHR_texture_transform rows are still stored.
 // The JSON reader below replaces NSJSONSerialization.
 #include "gltf_loader.h"
+#include "tangent_space.h"
 
 #include "image_decoders.h"
 
@@ -1067,16 +1068,23 @@ bool LoadGltfScene(const std::string& path, SceneResources& resources, std::stri
                 if (length(accum[i]) > 0.0f) vertices[i].normal = normalize(accum[i]);
             }
         }
+        // a primitive with texture coordinates and no TANGENT gets MikkTSpace tangents, one vertex per triangle corner
+        // (GltfLoader.mm:1447-1451 -> TangentGen.mm:181-230)
+        bool generatedTangents = false;
+        if (!hasTangents && hasUvs) {
+            GenerateTangents(vertices, indices);
+            generatedTangents = true;
+        }
         uint32_t materialIndex = 0u;
         if (prim.material >= 0 && prim.material < static_cast<int>(materialMap.size())) materialIndex = materialMap[static_cast<size_t>(prim.material)];
         const uint32_t meshIndex = resources.addMesh(vertices.data(), static_cast<uint32_t>(vertices.size()), indices.data(),
                                                      static_cast<uint32_t>(indices.size()), localToWorld, materialIndex, name);
-        // texture coordinates / tangents travel with the mesh (a mesh without tangents gets its tangent frame per triangle from the
-        // UV derivatives, like the reference kernel when SceneVertex::tangent.w is 0 - shaders/pathtrace.metal:843-911)
+        // texture coordinates / tangents travel with the mesh (a mesh without texture coordinates has no tangents: the kernel then builds
+        // an arbitrary frame, like the reference's when SceneVertex::tangent.w is 0 - shaders/pathtrace.metal:843-911)
         SceneResources::Mesh& stored = resources.meshAt(meshIndex);
         stored.hasUv0 = hasUvs;
         stored.hasUv1 = hasUvs1;
-        stored.hasTangents = hasTangents;
+        stored.hasTangents = hasTangents || generatedTangents;
         return true;
     };
 

@@ -112,10 +112,32 @@ bool LoadObjMesh(const std::string& path, LoadedMeshData& out, std::string& erro
                 if (!parseCorner(p, counts, key)) break;
                 poly.push_back(key);
             }
-            for (size_t k = 1; k + 1 < poly.size(); ++k) {  // fan triangulation
-                corners.push_back(poly[0]);
-                corners.push_back(poly[k]);
-                corners.push_back(poly[k + 1]);
+            // Triangulation as the reference's OBJ library does it (tinyobjloader, external/tinyobjloader/tiny_obj_loader.h:1520-1620,
+            // called with triangulate = true, SceneManager.mm:100): a quad is cut along its shorter diagonal - (0 1 2)(0 2 3) when
+            // |v2 - v0|^2 < |v3 - v1|^2, else (0 1 3)(1 2 3); larger polygons are fanned from their first corner (the library clips
+            // ears there: the same triangles for the convex polygons exporters write).
+            bool cut13 = false;
+            if (poly.size() == 4) {
+                const float* v[4];
+                bool known = true;
+                for (int k = 0; k < 4; ++k) {
+                    known = known && poly[static_cast<size_t>(k)].p >= 0 && static_cast<size_t>(poly[static_cast<size_t>(k)].p) * 3 + 2 < pos.size();
+                    v[k] = known ? &pos[static_cast<size_t>(poly[static_cast<size_t>(k)].p) * 3] : nullptr;
+                }
+                if (known) {
+                    const float ax = v[2][0] - v[0][0], ay = v[2][1] - v[0][1], az = v[2][2] - v[0][2];
+                    const float bx = v[3][0] - v[1][0], by = v[3][1] - v[1][1], bz = v[3][2] - v[1][2];
+                    cut13 = !(ax * ax + ay * ay + az * az < bx * bx + by * by + bz * bz);
+                }
+            }
+            if (cut13) {
+                for (int k : {0, 1, 3, 1, 2, 3}) corners.push_back(poly[static_cast<size_t>(k)]);
+            } else {
+                for (size_t k = 1; k + 1 < poly.size(); ++k) {
+                    corners.push_back(poly[0]);
+                    corners.push_back(poly[k]);
+                    corners.push_back(poly[k + 1]);
+                }
             }
         }
     }

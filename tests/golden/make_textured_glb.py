@@ -2,7 +2,7 @@
 """Writes tests/golden/textured.glb: a small textured glTF for the Metal metallic-roughness model's texture path.
 
 Two primitives over one vertex buffer (a 48 x 24 lat-long sphere with TEXCOORD_0, TEXCOORD_1 and analytic TANGENTs) plus a
-ground quad WITHOUT tangents (its normal map falls back to the per-triangle UV basis):
+ground quad WITHOUT tangents (the loader generates MikkTSpace tangents for it, like the reference):
   * "shell"  (upper sphere): base colour PNG (sRGB RGBA, alpha used by alphaMode MASK), metallic-roughness + occlusion in one
                              ORM PNG, normal map PNG, KHR_texture_transform on the base colour, mirrored-repeat sampler
   * "glow"   (lower sphere): emissive baseline JPEG (4:2:0) on TEXCOORD_1, alphaMode BLEND with a baseColorFactor alpha of 0.6

@@ -34,9 +34,16 @@ def test_loader_decodes_and_binds_the_textures(textured):
     sizes = [(d.textures[i].width, d.textures[i].height) for i in range(6)]
     assert sizes == [(256, 128), (64, 64), (96, 96), (128, 64), (32, 32), (96, 96)]
     assert (d.textures[0].wrapS, d.textures[0].wrapT) == (2, 0) and (d.textures[5].wrapS, d.textures[5].wrapT) == (1, 1)     # mirrored / clamp
-    # texture coordinates and tangents travel with the meshes; the ground quad has no tangents
+    # texture coordinates and tangents travel with the meshes; the ground quad's file has no TANGENT attribute: the loader gives it
+    # MikkTSpace tangents, one vertex per triangle corner, as the reference does (src/assets/TangentGen.mm:181-230)
     assert all(bool(d.meshes[i].uv0) and bool(d.meshes[i].uv1) for i in range(3))
-    assert bool(d.meshes[0].tangents) and bool(d.meshes[1].tangents) and not bool(d.meshes[2].tangents)
+    assert all(bool(d.meshes[i].tangents) for i in range(3))
+    ground_mesh = d.meshes[2]
+    assert ground_mesh.vertexCount == ground_mesh.indexCount == 6
+    assert list(np.ctypeslib.as_array(ground_mesh.indices, (6,))) == [0, 1, 2, 3, 4, 5]
+    tangents = np.ctypeslib.as_array(ground_mesh.tangents, (6, 4))
+    assert np.allclose(np.linalg.norm(tangents[:, :3], axis=1), 1.0, atol=1e-6) and np.all(np.abs(tangents[:, 3]) == 1.0)
+    assert np.allclose(tangents, tangents[0], atol=1e-6)                    # a flat quad with one linear mapping: one frame
     shell, glow, ground = d.materials[1], d.materials[2], d.materials[3]
     assert list(shell.textureIndices0) == [0, 1, 2, 1] and list(glow.textureIndices1)[:2] == [3, 0xFFFFFFFF]
     assert list(ground.textureIndices0) == [4, 0xFFFFFFFF, 5, 0xFFFFFFFF]

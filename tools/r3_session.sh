@@ -1,8 +1,6 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-python3 -c "
-from scenes.gen_assets import ensure_assets, ensure_large_asset
-ensure_assets(); [ensure_large_asset(a) for a in ('torus_knot_871200.ply', 'lucy_standin_28005128.ply', 'blob_1002528.ply')]"
-{ echo "# tools/steps_probe.py (counting build, PTR_VERBOSE=steps, PTR_POOL_GROUPS=1): where a k_shade visit's time goes";
-for sc in cornell_mesh lucy_standin knot_glass helmet_env; do echo "== scenes/$sc.scene"; PTR_POOL_GROUPS=1 timeout -k 10 300 python tools/steps_probe.py scenes/$sc.scene 16 2>&1 | grep -v "^\[upload\|^\[bvh\|^\[geometry"; done; } > gpurun_out/r3_steps_probe.txt 2>&1
-cat gpurun_out/r3_steps_probe.txt
+python -m pytest tests -m gpu -q > gpurun_out/r3_tests.log 2>&1; tail -5 gpurun_out/r3_tests.log
+bash tools/measure_solo.sh r3_solo_cfg2 > gpurun_out/r3_solo_cfg2.log 2>&1 && cp gpurun_out/r3_solo_cfg2.json profiles/r3_solo_cfg2.json
+timeout -k 10 300 python bench.py > gpurun_out/r3_bench.json 2> gpurun_out/r3_bench.err; cut -c1-300 gpurun_out/r3_bench.json; tail -3 gpurun_out/r3_bench.err
+HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --backend gloo --single-device --spp 32 --steps 2 --warmup 1 > gpurun_out/r3_bench_2rank_rehearsal.json 2> gpurun_out/r3_bench_2rank_rehearsal.err; cut -c1-700 gpurun_out/r3_bench_2rank_rehearsal.json; tail -3 gpurun_out/r3_bench_2rank_rehearsal.err
