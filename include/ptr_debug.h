@@ -35,6 +35,13 @@ int ptr_debug_render_signatures(PtrDeviceScene* scene, const PtrSettings* settin
  * {u, v, lod}, out n * 4 floats RGBA (-1 in every channel when the scene has no such texture). */
 int ptr_debug_texture_sample(PtrDeviceScene* scene, uint32_t texture, const float* in, uint64_t n, float* out, char* err, size_t err_cap);
 
+/* Closest hit, surface record and next-ray origin for a batch of rays: what k_shade reconstructs at a hit (interpolated shading normal
+ * flipped to the geometric side, shaders/pathtrace.metal:597-638 / EmbreeHeadlessRenderer.mm:2348-2367) and where it starts the next ray
+ * (offset_ray_origin, pathtrace.metal:1196-1208 / OffsetRayOrigin, EmbreeHeadlessRenderer.mm:917-931).
+ * in: n x 9 floats {origin, direction, next direction}; out: n x 16 floats {hit (1/0), t, position xyz, geometric normal xyz,
+ * shading normal xyz, front face (1/0), next origin xyz, 0}. */
+int ptr_debug_surface_hits(PtrDeviceScene* scene, const float* in, uint64_t n, float* out, char* err, size_t err_cap);
+
 /* ptr_render_multi on an explicit list of devices; an id may appear more than once, which lets a one-GPU box run the whole
  * multi-device path (threads, partitions, hand-over, interleave).  An id given as -(id + 1) routes that partition's bands through the
  * pinned-host staging copy ptr_render_multi falls back to when two devices cannot address each other (hipDeviceCanAccessPeer). */

@@ -218,7 +218,7 @@ ABI_SYMBOLS = (
 # include/ptr_debug.h (test-only device-function probes)
 DEBUG_SYMBOLS = ("ptr_debug_eval_bsdf", "ptr_debug_sample_bsdf", "ptr_debug_camera_rays", "ptr_debug_env_distribution",
                  "ptr_debug_scene_geometry", "ptr_debug_render_signatures", "ptr_debug_render_multi_on", "ptr_debug_texture_sample",
-                 "ptr_debug_generate_tangents")
+                 "ptr_debug_generate_tangents", "ptr_debug_surface_hits")
 
 _lib: Optional[C.CDLL] = None
 
@@ -400,6 +400,16 @@ class DeviceScene:
         load_library().ptr_scene_info(self._h, out)
         keys = ("nodes", "leaves", "triangles", "spheres", "max_depth", "max_leaf", "sah_cost_x1000", "rect_lights")
         return dict(zip(keys, [int(v) for v in out]))
+
+    def surface_hits(self, rays) -> np.ndarray:
+        """ptr_debug_surface_hits: rays [n, 9] {origin, direction, next direction} -> [n, 16]."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 9)
+        out = np.zeros((rays.shape[0], 16), dtype=np.float32)
+        lib = load_library()
+        lib.ptr_debug_surface_hits.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint64, C.POINTER(C.c_float), C.c_char_p, C.c_size_t]
+        err = _err_buf()
+        _check(lib.ptr_debug_surface_hits(self._h, _fptr(rays), rays.shape[0], _fptr(out), err, len(err)), err)
+        return out
 
     def render(self, settings: PtrSettings, spp: int, part: int = 0, parts: int = 1, count: bool = False
                ) -> Tuple[np.ndarray, PtrRenderStats]:

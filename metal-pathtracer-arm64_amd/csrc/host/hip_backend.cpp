@@ -1566,6 +1566,26 @@ int ptr_debug_texture_sample(PtrDeviceScene* scene, uint32_t texture, const floa
     PTR_CATCH_ALL(err, err_cap)
 }
 
+int ptr_debug_surface_hits(PtrDeviceScene* scene, const float* in, uint64_t n, float* out, char* err, size_t err_cap) {
+    if (!scene || (!in && n) || (!out && n)) {
+        setErr(err, err_cap, "ptr_debug_surface_hits: null argument");
+        return 1;
+    }
+    try {
+        HIP_CHECK(hipSetDevice(scene->device));
+        if (n == 0) return 0;
+        DeviceBuffer<float> din, dout;
+        din.upload(in, n * 9);
+        dout.ensure(n * 16);
+        LaunchConfig cfg{scene->traceGrid, scene->spill.ptr, scene->scalars.ptr + 1, scene->refillBelow};
+        launchDebugSurfaceHits(scene->view, din.ptr, n, dout.ptr, cfg, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(out, dout.ptr, n * 16 * sizeof(float), hipMemcpyDeviceToHost));
+        return 0;
+    }
+    PTR_CATCH_ALL(err, err_cap)
+}
+
 int ptr_debug_eval_bsdf(const PtrMaterial* material, const PtrSettings* settings, const float* in, uint64_t n, float* out,
                         char* err, size_t err_cap) {
     try {

@@ -2334,6 +2334,35 @@ __global__ void k_debug_tex_sample(SceneView sc, uint32_t texture, const float* 
     out[i] = texSample(sc, texture, in[i * 3u], in[i * 3u + 1u], in[i * 3u + 2u], make_float4(-1.0f, -1.0f, -1.0f, -1.0f));
 }
 
+// closest hit + surface reconstruction + next-ray origin, the pieces k_shade builds a bounce from (tests of a13 / a14)
+__global__ void __launch_bounds__(kTraceBlock) k_debug_surface(SceneView sc, const float* in, uint64_t n, float* out, uint32_t* spill, uint32_t spillStride) {
+    __shared__ uint32_t ldsStack[kLdsStackLevels * kTraceBlock];
+    const uint32_t gtid = blockIdx.x * kTraceBlock + threadIdx.x;
+    LaneStack stack;
+    stack.lds = (LdsWord*)(ldsStack + threadIdx.x);
+    stack.spill = spill;
+    stack.spillStride = spillStride;
+    stack.limit = sc.stackLimit;
+    TraceCounters cnt{0u, 0u};
+    for (uint64_t i = gtid; i < n; i += static_cast<uint64_t>(gridDim.x) * kTraceBlock) {
+        const float* r = in + i * 9u;
+        float* o = out + i * 16u;
+        for (int k = 0; k < 16; ++k) o[k] = 0.0f;
+        const f3 org = ld3(r), dir = ld3(r + 3);
+        const TraceHit h = traverse<false, false>(sc, org, dir, kEps, INFINITY, stack, cnt);
+        if (h.prim == kHitMiss) continue;
+        const Surface sf = reconstruct(sc, org, dir, h.t, h.prim);
+        const f3 next = offsetOrigin(sf, ld3(r + 6));
+        o[0] = 1.0f;
+        o[1] = sf.t;
+        o[2] = sf.position.x, o[3] = sf.position.y, o[4] = sf.position.z;
+        o[5] = sf.normal.x, o[6] = sf.normal.y, o[7] = sf.normal.z;
+        o[8] = sf.hitShadingNormal.x, o[9] = sf.hitShadingNormal.y, o[10] = sf.hitShadingNormal.z;
+        o[11] = sf.frontFace ? 1.0f : 0.0f;
+        o[12] = next.x, o[13] = next.y, o[14] = next.z;
+    }
+}
+
 __global__ void k_debug_camera(RenderParams rp, const uint32_t* xys, uint64_t n, float* out, uint32_t* rngOut) {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -2501,6 +2530,13 @@ void launchDebugSampleBsdf(const float4* dMaterial, const RenderParams& rp, cons
 
 void launchDebugTexSample(const SceneView& sc, uint32_t texture, const float* dIn, uint64_t n, float4* dOut, hipStream_t stream) {
     hipLaunchKernelGGL(k_debug_tex_sample, dim3(std::max(1u, ceilDiv(n, 128))), dim3(128), 0, stream, sc, texture, dIn, n, dOut);
+}
+
+void launchDebugSurfaceHits(const SceneView& sc, const float* dIn, uint64_t n, float* dOut, const LaunchConfig& cfgIn, hipStream_t stream) {
+    const LaunchConfig cfg = perBlockSize(cfgIn);
+    const uint32_t stride = cfg.traceGrid * kTraceBlock;
+    const uint32_t grid = std::min(cfg.traceGrid, std::max(1u, ceilDiv(n, kTraceBlock)));
+    hipLaunchKernelGGL(k_debug_surface, dim3(grid), dim3(kTraceBlock), 0, stream, sc, dIn, n, dOut, cfg.spill, stride);
 }
 
 void launchDebugCameraRays(const RenderParams& rp, const uint32_t* dXys, uint64_t n, float* dOut, uint32_t* dRngOut, hipStream_t stream) {

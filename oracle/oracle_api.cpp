@@ -102,6 +102,28 @@ void oracle_trace_rays(const OracleScene* s, const float* rays, uint64_t n, int 
     }
 }
 
+// Surface records of the integrator's IntersectScene twin (E:2302-2410: position, geometric and interpolated shading normal, facing)
+// and the next-ray origin OffsetRayOrigin gives for a direction (E:917-931).
+// in: n * 9 floats {origin, direction, next direction}; out: n * 16 floats {hit, t, position, normal, shading normal, front face, next origin}
+void oracle_surface_hits(const OracleScene* s, const float* in, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        const float* r = in + i * 9;
+        float* o = out + i * 16;
+        std::memset(o, 0, 16 * sizeof(float));
+        HitInfo hit;
+        const Ray ray{V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5])};
+        if (!intersectScene(s->scene, ray, hit)) continue;
+        const V3 next = nextRayOrigin(hit, V3(r[6], r[7], r[8]));
+        o[0] = 1.0f;
+        o[1] = hit.t;
+        o[2] = hit.position.x, o[3] = hit.position.y, o[4] = hit.position.z;
+        o[5] = hit.normal.x, o[6] = hit.normal.y, o[7] = hit.normal.z;
+        o[8] = hit.shadingNormal.x, o[9] = hit.shadingNormal.y, o[10] = hit.shadingNormal.z;
+        o[11] = hit.frontFace ? 1.0f : 0.0f;
+        o[12] = next.x, o[13] = next.y, o[14] = next.z;
+    }
+}
+
 // ---- known-answer helpers ----
 
 uint32_t oracle_rng_hash(uint32_t x) { return Rng::hash(x); }

@@ -1769,6 +1769,8 @@ EnvSample sampleEnvironmentCpu(const EnvDistribution& dist, float uMarginal, flo
 // ---------------------------------------------------------------------------------------------
 // scene queries                                                                       E:2302-2433
 // ---------------------------------------------------------------------------------------------
+V3 nextRayOrigin(const HitInfo& hit, V3 direction) { return offsetRayOrigin(hit, direction); }
+
 bool intersectScene(const Scene& scene, const Ray& ray, HitInfo& out, Counters* counters) {
     RayHit rh;
     if (!scene.intersect(ray.origin, ray.direction, kEpsilon, kInf, rh, false, counters)) return false;

@@ -130,6 +130,7 @@ BsdfEval evaluateBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 wi
 BsdfSample sampleBsdf(const PtrMaterial& m, V3 position, V3 normal, V3 wo, V3 incidentDir, bool frontFace, Rng& rng,
                       const ClampParams& cp);
 bool intersectScene(const Scene& scene, const Ray& ray, HitInfo& out, Counters* counters = nullptr);
+V3 nextRayOrigin(const HitInfo& hit, V3 direction);   // OffsetRayOrigin, E:917-931 (for the function-level tests)
 // Samples texture `texture` of the scene with the filtering rule of the textured metallic-roughness model: in n * {u, v, lod}, out n * RGBA.
 void sampleTextures(const PtrSceneDesc& desc, uint32_t texture, const float* in, uint64_t n, float* out);
 

@@ -32,6 +32,7 @@ def lib():
         l.oracle_render_signatures.restype = C.c_double
         l.oracle_texture_sample.argtypes = [C.POINTER(pt.PtrSceneDesc), u32, fp, u64, fp]
         l.oracle_trace_rays.argtypes = [vp, fp, u64, C.c_int, C.c_int, vp]
+        l.oracle_surface_hits.argtypes = [vp, fp, u64, fp]
         l.oracle_rng_hash.argtypes = [u32]
         l.oracle_rng_hash.restype = u32
         l.oracle_rng_floats.argtypes = [u32, u32, fp, up]
@@ -88,6 +89,14 @@ class OracleScene:
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
         out = np.zeros(rays.shape[0], dtype=pt.HIT_DTYPE)
         lib().oracle_trace_rays(self._h, _f(rays), rays.shape[0], int(any_hit), int(brute_force), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def surface_hits(self, rays):
+        """IntersectScene + OffsetRayOrigin: rays [n, 9] {origin, direction, next direction} -> [n, 16]
+        {hit, t, position, normal, shading normal, front face, next origin, 0}."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 9)
+        out = np.zeros((rays.shape[0], 16), dtype=np.float32)
+        lib().oracle_surface_hits(self._h, _f(rays), rays.shape[0], _f(out))
         return out
 
     def close(self):

@@ -37,13 +37,17 @@ def _rmse(a, b):
     return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
 
 
-@pytest.mark.parametrize("name,min_fraction", [("smoke_64x64_d4_4spp_seed1337", 0.97), ("cornell_64x64_d4_1spp_seed1337", 0.93),
-                                               ("materials_96x64_d6_1spp_seed1337", 0.90), ("env_materials_96x64_d6_1spp_seed1337", 0.88)])
+@pytest.mark.parametrize("name,min_fraction", [("smoke_64x64_d4_4spp_seed1337", 0.99), ("cornell_64x64_d4_1spp_seed1337", 0.966),
+                                               ("materials_96x64_d6_1spp_seed1337", 0.987), ("env_materials_96x64_d6_1spp_seed1337", 0.989)])
 def test_low_spp_stream_matches_golden(name, min_fraction):
     img, st, ref, info = _render(name, count=True)
     assert img.shape == ref.shape and np.isfinite(img).all()
     rel = np.abs(img - ref) / (np.abs(ref) + 1e-2)
-    assert float((rel.max(axis=2) <= 1e-3).mean()) >= min_fraction
+    fraction = float((rel.max(axis=2) <= 1e-3).mean())
+    if os.environ.get("PTR_TEST_VERBOSE"):
+        with open(os.path.join(ROOT, "gpurun_out", "parity_fractions.txt"), "a") as f:
+            f.write("golden %s  fraction %.4f  (threshold %.3f)\n" % (name, fraction, min_fraction))
+    assert fraction >= min_fraction
     c = info["counters"]
     assert abs(st.extendRays - c["extendRays"]) <= 0.002 * c["extendRays"] + 2
     assert abs(st.shadedHits - c["shadedHits"]) <= 0.002 * c["shadedHits"] + 2

@@ -195,6 +195,11 @@ def _image_parity(host, dev, osc, width, height, depth, low_spp, high_spp, min_f
     # same stream => (almost) the same number of rays, hits and mesh hits
     assert abs(st1.extendRays - c1["extendRays"]) <= 0.002 * c1["extendRays"] + 2
     assert abs(st1.shadedHits - c1["shadedHits"]) <= 0.002 * c1["shadedHits"] + 2
+    if os.environ.get("PTR_TEST_VERBOSE"):   # what the thresholds were set from: measured fraction per call site (minus a 0.01 margin)
+        import inspect
+        caller = inspect.stack()[1]
+        with open(os.path.join(ROOT, "gpurun_out", "parity_fractions.txt"), "a") as f:
+            f.write("%s:%d  %dx%d d%d  %s  fraction %.4f  (threshold %.3f)\n" % (caller.function, caller.lineno, width, height, depth, overrides, frac, min_fraction))
     assert frac >= min_fraction, frac
     imgN, _ = dev.render_image(s, high_spp)
     refN, _, _ = osc.render(s, high_spp, threads=0)
@@ -214,29 +219,31 @@ def test_smoke_scene_image_parity():
     # the reference's smoke render (64x64, 4 spp, depth 4, seed 1337): no lights, solid background
     host = pt.HostScene.load(os.path.join(GOLDEN, "smoke.scene"))
     dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
-    frac, err, noise, _ = _image_parity(host, dev, osc, 64, 64, 4, 4, 64, 0.97)
+    frac, err, noise, _ = _image_parity(host, dev, osc, 64, 64, 4, 4, 64, 0.99)
     assert err < 0.25 * noise            # far below the noise floor: the streams are the same
 
 
 def test_cornell_image_parity(cornell_small):
     host, dev, osc = cornell_small
-    _image_parity(host, dev, osc, 64, 64, 4, 1, 64, 0.93)
-    _image_parity(host, dev, osc, 80, 48, 8, 1, 32, 0.90)
+    # (Cornell-type scenes: every differing pixel is a marginal rectangle-light shadow decision, quirk Q9 - see
+    # test_deterministic_stream_criterion_and_what_the_rest_comes_from; thresholds = measured fraction - 0.01)
+    _image_parity(host, dev, osc, 64, 64, 4, 1, 64, 0.966)
+    _image_parity(host, dev, osc, 80, 48, 8, 1, 32, 0.959)
 
 
 def test_materials_image_parity_with_and_without_specular_nee(materials_scene):
     host, dev, osc = materials_scene
-    _image_parity(host, dev, osc, 96, 64, 6, 1, 32, 0.90)
-    _image_parity(host, dev, osc, 96, 64, 6, 1, 16, 0.90, enableSpecularNee=0, enableRussianRoulette=0)
-    _image_parity(host, dev, osc, 96, 64, 12, 1, 16, 0.88, fireflyClampEnabled=0)
+    _image_parity(host, dev, osc, 96, 64, 6, 1, 32, 0.987)
+    _image_parity(host, dev, osc, 96, 64, 6, 1, 16, 0.987, enableSpecularNee=0, enableRussianRoulette=0)
+    _image_parity(host, dev, osc, 96, 64, 12, 1, 16, 0.988, fireflyClampEnabled=0)
 
 
 def test_environment_lit_image_parity():
     # env NEE (alias tables), MIS against the env pdf, bilinear lookups, specular NEE along delta bounces, env portal
     host = pt.HostScene.load(os.path.join(GOLDEN, "env_materials.scene"), SCENES)
     dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
-    _image_parity(host, dev, osc, 96, 64, 6, 1, 32, 0.88)
-    _image_parity(host, dev, osc, 64, 48, 4, 1, 16, 0.88, environmentRotation=2.1, environmentIntensity=0.5, enableSpecularNee=0)
+    _image_parity(host, dev, osc, 96, 64, 6, 1, 32, 0.989)
+    _image_parity(host, dev, osc, 64, 48, 4, 1, 16, 0.99, environmentRotation=2.1, environmentIntensity=0.5, enableSpecularNee=0)
 
 
 def test_config3_standin_glb_under_hdr_environment():
@@ -244,7 +251,7 @@ def test_config3_standin_glb_under_hdr_environment():
     # 2048x1024 RGBE environment with three suns of very different radiance (alias tables), envRotation 30 deg
     host = pt.HostScene.load(os.path.join(SCENES, "helmet_env.scene"), SCENES)
     dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
-    _image_parity(host, dev, osc, 192, 108, 8, 1, 32, 0.88)
+    _image_parity(host, dev, osc, 192, 108, 8, 1, 32, 0.99)
 
 
 def test_config4_standin_glass_knot_depth16():
@@ -257,7 +264,7 @@ def test_config4_standin_glass_knot_depth16():
     assert info["triangles"] == 871200 + 12 and info["max_depth"] < 48
     if os.environ.get("PTR_TEST_VERBOSE"):
         print("knot scene", info)
-    _image_parity(host, dev, osc, 160, 90, 16, 1, 32, 0.85)
+    _image_parity(host, dev, osc, 160, 90, 16, 1, 32, 0.97)
     rays = _random_rays(200_000, -50.0, 600.0, 11)
     hits = dev.trace_rays(rays, any_hit=False)[0]
     ref = osc.trace_rays(rays, any_hit=False)
@@ -269,7 +276,7 @@ def test_config5_reduced_sss_and_carpaint_meshes():
     ensure_large_asset("blob_125000.ply")
     host = pt.HostScene.load(os.path.join(GOLDEN, "lucy_small.scene"), SCENES)
     dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
-    _image_parity(host, dev, osc, 160, 90, 12, 1, 32, 0.88)
+    _image_parity(host, dev, osc, 160, 90, 12, 1, 32, 0.989)
 
 
 def test_metal_media_semantics(tmp_path):
@@ -293,7 +300,7 @@ def test_metal_media_semantics(tmp_path):
     host = pt.HostScene.load(str(p))
     dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
     for sem in (7, 5, 4):
-        _image_parity(host, dev, osc, 96, 64, 12, 1, 32, 0.88, metalSemantics=sem, enableRussianRoulette=0)
+        _image_parity(host, dev, osc, 96, 64, 12, 1, 32, 0.989, metalSemantics=sem, enableRussianRoulette=0)
     # the modes really differ from the Embree-parity image and from each other
     s0 = host.settings_for(width=96, height=64, max_depth=12, seed=9)
     base, _ = dev.render_image(s0, 16)
@@ -319,7 +326,7 @@ def test_metal_specular_semantics(materials_scene):
     # PTR_METAL_SPECULAR: rough metals with VNDF sampling, the G1 pdf and energy compensation (Metal formulas, restated in
     # the oracle too): device functions and images agree with the oracle, and differ from the Embree-parity mode
     host, dev, osc = materials_scene
-    _image_parity(host, dev, osc, 96, 64, 6, 1, 32, 0.88, metalSemantics=8)
+    _image_parity(host, dev, osc, 96, 64, 6, 1, 32, 0.987, metalSemantics=8)
     s0 = host.settings_for(width=96, height=64, max_depth=6, seed=1337)
     s8 = s0.copy()
     s8.metalSemantics = 8
@@ -366,7 +373,7 @@ def test_metal_subsurface_semantics(tmp_path):
     dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
     s0 = host.settings_for(seed=1337)
     assert s0.sssMode == 1
-    _image_parity(host, dev, osc, 96, 64, 6, 1, 32, 0.88, metalSemantics=16)
+    _image_parity(host, dev, osc, 96, 64, 6, 1, 32, 0.99, metalSemantics=16)
     s16 = s0.copy()
     s16.metalSemantics = 16
     assert _rmse(dev.render_image(s0, 32)[0], dev.render_image(s16, 32)[0]) > 0.005
@@ -396,8 +403,8 @@ def test_metal_subsurface_semantics(tmp_path):
     wdev, wosc = pt.DeviceScene(wh.desc, 0, keepalive=wh), ol.OracleScene(wh)
     sw = wh.settings_for(seed=1337, metalSemantics=16)
     assert sw.sssMode == 2 and sw.sssMaxSteps == 32
-    _image_parity(wh, wdev, wosc, 96, 64, 6, 1, 32, 0.85, metalSemantics=16)
-    _image_parity(wh, wdev, wosc, 64, 48, 6, 1, 16, 0.85, metalSemantics=16, sssMaxSteps=3, enableRussianRoulette=0)
+    _image_parity(wh, wdev, wosc, 96, 64, 6, 1, 32, 0.988, metalSemantics=16)
+    _image_parity(wh, wdev, wosc, 64, 48, 6, 1, 16, 0.988, metalSemantics=16, sssMaxSteps=3, enableRussianRoulette=0)
     # the walk costs closest-hit queries: more rays than the same frame without it, and the image differs from separable mode
     _, st_walk = wdev.render_image(sw, 4, count=True)
     s_sep = sw.copy()
@@ -421,7 +428,7 @@ def test_metal_pbr_semantics():
     glassy.dielectricSigmaA[0], glassy.dielectricSigmaA[1], glassy.dielectricSigmaA[2] = 0.2, 0.5, 1.0
     sharp.pbrExtras[2], sharp.pbrParams[0], sharp.baseColorRoughness[3] = 0.5, 0.0, 0.0
     dev, osc = pt.DeviceScene(d, 0, keepalive=host), ol.OracleScene(host)
-    _image_parity(host, dev, osc, 160, 90, 8, 1, 32, 0.85, metalSemantics=32)
+    _image_parity(host, dev, osc, 160, 90, 8, 1, 32, 0.99, metalSemantics=32)
     s0 = host.settings_for(width=160, height=90, max_depth=8, seed=1337)
     s32 = s0.copy()
     s32.metalSemantics = 32
@@ -477,7 +484,7 @@ def test_first_hit_aovs(materials_scene):
 
 def test_gradient_sky_and_thin_lens(materials_scene):
     host, dev, osc = materials_scene
-    _image_parity(host, dev, osc, 64, 48, 5, 1, 16, 0.90, backgroundMode=0, cameraDefocusAngle=1.5, cameraFocusDistance=8.0)
+    _image_parity(host, dev, osc, 64, 48, 5, 1, 16, 0.987, backgroundMode=0, cameraDefocusAngle=1.5, cameraFocusDistance=8.0)
 
 
 def test_mnee_modes(tmp_path):
@@ -489,8 +496,8 @@ def test_mnee_modes(tmp_path):
     p.write_text(text)
     host = pt.HostScene.load(str(p))
     dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
-    _image_parity(host, dev, osc, 64, 48, 6, 1, 32, 0.90, enableMnee=1, enableMneeSecondary=1)
-    _image_parity(host, dev, osc, 64, 48, 6, 1, 16, 0.90, enableMnee=1, enableMneeSecondary=0)
+    _image_parity(host, dev, osc, 64, 48, 6, 1, 32, 0.99, enableMnee=1, enableMneeSecondary=1)
+    _image_parity(host, dev, osc, 64, 48, 6, 1, 16, 0.99, enableMnee=1, enableMneeSecondary=0)
 
 
 def test_specular_connections_settled_in_shade_and_traced(tmp_path):
@@ -509,8 +516,8 @@ def test_specular_connections_settled_in_shade_and_traced(tmp_path):
         host = pt.HostScene.load(str(p))
         dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
         assert dev.info()["rect_lights"] == count
-        _image_parity(host, dev, osc, 64, 48, 6, 1, 16, 0.90)
-        _image_parity(host, dev, osc, 64, 48, 6, 1, 16, 0.90, enableMnee=1, enableMneeSecondary=1)
+        _image_parity(host, dev, osc, 64, 48, 6, 1, 16, 0.99)
+        _image_parity(host, dev, osc, 64, 48, 6, 1, 16, 0.99, enableMnee=1, enableMneeSecondary=1)
         dev.close()
 
 
@@ -561,6 +568,43 @@ print("rccl ok")
 """ % (ROOT, str(29500 + os.getpid() % 2000))
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "rccl ok" in res.stdout, res.stderr[-2000:]
+
+
+def test_surface_records_and_next_ray_origins_match_the_oracle():
+    # a13 / a14 at function level: what a bounce is built from - the hit point, the geometric normal, the interpolated shading normal
+    # flipped to the geometric side (E:2348-2367), the facing flag, and the origin OffsetRayOrigin (E:917-931) gives the next ray -
+    # for rays at a smooth-shaded mesh, rectangles and spheres, from outside and from inside, next directions on either side
+    host = pt.HostScene.load(os.path.join(GOLDEN, "cornell_small_mesh.scene"), SCENES)
+    dev, osc = pt.DeviceScene(host.desc, 0, keepalive=host), ol.OracleScene(host)
+    rng = np.random.default_rng(11)
+    n = 40000
+    org = rng.uniform(30.0, 525.0, (n, 3)).astype(np.float32)
+    target = rng.uniform(0.0, 555.0, (n, 3)).astype(np.float32)
+    target[: n // 2] = np.array([278.0, 200.0, 278.0], np.float32) + rng.normal(0, 60.0, (n // 2, 3)).astype(np.float32)   # at the mesh
+    d = target - org
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    nxt = rng.normal(size=(n, 3))
+    nxt = (nxt / np.linalg.norm(nxt, axis=1, keepdims=True)).astype(np.float32)
+    rays = np.concatenate([org, d, nxt], axis=1)
+    got, want = dev.surface_hits(rays), osc.surface_hits(rays)
+    hit = want[:, 0] > 0
+    assert np.array_equal(got[:, 0], want[:, 0]) and hit.mean() > 0.9   # (the box is open at the front)
+    assert np.array_equal(got[hit, 1], want[hit, 1])                                  # same distance, bit for bit (a7)
+    assert np.array_equal(got[hit, 2:5], want[hit, 2:5])                              # same hit point
+    assert np.array_equal(got[hit, 11], want[hit, 11])                                # same facing
+    # normals go through a normalisation (sqrt + division: IEEE on both sides) of the same operands: equal, up to primitives hit
+    # exactly on a shared edge where the two sides may pick different triangles
+    same = np.all(got[hit, 5:11] == want[hit, 5:11], axis=1)
+    assert same.mean() > 0.999 and np.abs(got[hit, 5:11] - want[hit, 5:11])[same].max() == 0.0
+    assert np.allclose(np.linalg.norm(got[hit, 8:11], axis=1), 1.0, atol=1e-5)
+    facing = np.where(got[hit, 11:12] > 0, 1.0, -1.0) * got[hit, 5:8]
+    on_side = np.einsum("ij,ij->i", got[hit, 8:11], facing) >= -1e-6                  # meshes and rectangles: flipped to the geometric side;
+    assert on_side.mean() > 0.9                                                       # a sphere seen from inside keeps its outward normal (E:2389-2404)
+    assert np.array_equal(got[hit][same][:, 12:15], want[hit][same][:, 12:15])        # a14: the next origin, bit for bit
+    moved = np.linalg.norm(got[hit, 12:15] - got[hit, 2:5], axis=1)
+    # |offset| <= max(t 1e-4, 1e-4) along the normal + 0.5e-4 along the direction (+ the rounding of coordinates of a few hundred units)
+    assert (moved > 0.0).all() and (moved <= np.maximum(got[hit, 1] * 1e-4, 1e-4) + 0.5e-4 + 4e-4).all()
+    dev.close()
 
 
 def test_partition_and_pool_size_invariance(cornell_small):
@@ -912,8 +956,8 @@ def test_metal_clamp_variants(materials_scene):
     # Parity against the oracle's restatement; and the variant really differs from the Embree-parity clamps.
     host, dev, osc = materials_scene
     assert host.settings.fireflyClampMaxContribution == 1000.0 and host.settings.specularTailClampBase == 0.0
-    _image_parity(host, dev, osc, 96, 64, 6, 1, 32, 0.90, metalSemantics=64)
-    _image_parity(host, dev, osc, 96, 64, 6, 1, 16, 0.90, metalSemantics=64 | 8, minSpecularPdf=1e-3, specularTailClampBase=2.0)
+    _image_parity(host, dev, osc, 96, 64, 6, 1, 32, 0.988, metalSemantics=64)
+    _image_parity(host, dev, osc, 96, 64, 6, 1, 16, 0.987, metalSemantics=64 | 8, minSpecularPdf=1e-3, specularTailClampBase=2.0)
     s0 = host.settings_for(width=96, height=64, max_depth=6, seed=1337)
     s1 = s0.copy()
     s1.metalSemantics = 64
