@@ -130,9 +130,8 @@ struct PtrDeviceScene {
     bool hasRandomWalkMaterial = false;   // a type-5 material with sssParams.y >= 0.5 (Metal random-walk subsurface)
 
     // render-time resources, grown on demand and kept across calls
-    DeviceBuffer<float4> ray0, ray1, thr, accum, recBuf, itemAccum;
+    DeviceBuffer<float4> state, recBuf, itemAccum;   // state: the four 16 B words of every slot (PathPool::ray0 / ray1 / thr / accum)
     DeviceBuffer<float2> hit;
-    DeviceBuffer<uint8_t> pending;
     DeviceBuffer<uint32_t> flushItem, signature, tailList, tailWords;
     DeviceBuffer<uint32_t> connectList, connectCounts;   // PathPool::connectList: per group a list and two sets of sub-list counters
     DeviceBuffer<uint32_t> busyLists, busyCounts;        // PathPool::busyIn / busyOut: per group two lists and three sets of counters
@@ -673,12 +672,8 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
     rp.itemHeadFirst = slots;
     rp.itemsPerHead = static_cast<uint32_t>(((itemCount64 - slots + kItemHeads - 1u) / kItemHeads + 63u) & ~63ull);
 
-    ds.ray0.ensure(slots);
-    ds.ray1.ensure(slots);
+    ds.state.ensure(static_cast<size_t>(slots) * 4u);
     ds.hit.ensure(slots);
-    ds.thr.ensure(slots);
-    ds.accum.ensure(slots);
-    ds.pending.ensure(slots);
     ds.flushItem.ensure(slots);
     if (count) ds.signature.ensure(slots);
     if (ds.tailBelow > 0) {
@@ -694,12 +689,13 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
 
     PathPool pool;
     std::memset(&pool, 0, sizeof(pool));
-    pool.ray0 = ds.ray0.ptr;
-    pool.ray1 = ds.ray1.ptr;
+    // four arrays of `slots` words, or one 64 B record per slot (kernels/device_types.h StateWord)
+    const size_t wordStride = PTR_POOL_AOS ? 1u : slots;
+    pool.ray0.base = ds.state.ptr;
+    pool.ray1.base = ds.state.ptr + wordStride;
+    pool.thr.base = ds.state.ptr + 2u * wordStride;
+    pool.accum.base = ds.state.ptr + 3u * wordStride;
     pool.hit = ds.hit.ptr;
-    pool.thr = ds.thr.ptr;
-    pool.accum = ds.accum.ptr;
-    pool.pending = ds.pending.ptr;
     pool.flushItem = ds.flushItem.ptr;
     pool.signature = count ? ds.signature.ptr : nullptr;
     pool.medium = (rp.mediaMode & PTR_METAL_MEDIA) ? ds.medium.ptr : nullptr;
@@ -775,7 +771,6 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         gr.pool.hit += first;
         gr.pool.thr += first;
         gr.pool.accum += first;
-        gr.pool.pending += first;
         gr.pool.flushItem += first;
         if (gr.pool.signature) gr.pool.signature += first;
         if (gr.pool.medium) gr.pool.medium += first;

@@ -30,6 +30,8 @@ constexpr uint32_t kTraceGridUnit = 256u;           // the host sizes traversal 
 // geometry index) and is copied into the hit word by the primitive test that accepts the hit: k_shade sorts the slots of a block
 // by it before shading them (wavefront.hip, k_shade_sorted) without a dependent fetch.
 constexpr uint32_t kHitMiss = 0xFFFFFFFFu;
+constexpr uint32_t kHitIdle = 0xFFFFFFFEu;   // a slot without a ray and with nothing outstanding (written by k_shade / k_generate, never by a trace)
+constexpr uint32_t kHitLand = 0xFFFFFFFDu;   // a slot without a ray whose connection records / finished item are still to be added up
 constexpr uint32_t kHitSphereBit = 0x80000000u;
 constexpr uint32_t kHitKeyShift = 26u;
 constexpr uint32_t kHitKeyMask = 0xFu;

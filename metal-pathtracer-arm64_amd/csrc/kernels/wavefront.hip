@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams rp, PathPool pool
     pool.ray1[slot] = make_float4(d.y, d.z, 1.0f, __uint_as_float(flags));
     pool.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng));
     pool.accum[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(slot));
-    pool.pending[slot] = 0u;
+    pool.hit[slot] = make_float2(0.0f, __uint_as_float(kHitIdle));   // (a slot with a ray gets its hit word from k_extend)
     if (pool.signature) pool.signature[slot] = 0u;
     if (pool.cone) pool.cone[slot] = primaryCone(rp);
 }
@@ -966,7 +966,7 @@ constexpr int kShadeDense = 0, kShadeListed = 1, kShadeTail = 2, kShadeSorted = 
 // kernel drops to 3 waves/SIMD and untextured Metal-semantics scenes ran 19-25 % slower than in round 1.
 template <bool COUNT, bool SSS, bool TEX, int MODE>
 __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const uint32_t slot, const bool inRange,
-                                              const bool drained, const uint32_t listWave, ShadeCounts& counts) {
+                                              const bool drained, const uint32_t listWave, ShadeCounts& counts, const float2 hitGiven = float2{0.0f, 0.0f}) {
     constexpr bool TAIL = MODE == kShadeTail;
     // Everything that depends only on the slot index is requested up front, and the record loads are pointed at a
     // zero word when the record is not pending, so the kernel has ~11 loads in flight per lane after ONE dependent
@@ -981,7 +981,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
         if (__ballot(busy) == 0ull) return 0u;
     }
     const float4 ray0v = pool.ray0[at];
-    const float2 hitv = pool.hit[at];
+    const float2 hitv = MODE == kShadeSorted ? hitGiven : pool.hit[at];   // (the sorted kernel read the window's hit words in slot order)
     const float4 thr4 = pool.thr[at];
     const float4 acc4 = pool.accum[at];
     const uint32_t flagsIn = inRange ? __float_as_uint(ray1v.w) : 0u;
@@ -1530,7 +1530,8 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
         newFlags = flags;
         pool.ray1[slot] = make_float4(nextD.y, nextD.z, lastPdf, __uint_as_float(flags));
         pool.accum[slot] = mk4(acc, __uint_as_float(item));
-        if (pendingMask != 0u || pendingIn != 0u) pool.pending[slot] = static_cast<uint8_t>(pendingMask);
+        // a slot left without a ray tells its next visit what it is for (a sorted launch claims work items afterwards and writes it then)
+        if (MODE != kShadeSorted && !stillAlive) reinterpret_cast<uint32_t*>(pool.hit + slot)[1] = (pendingMask != 0u || flushNext) ? kHitLand : kHitIdle;
         if (stillAlive) {
             pool.ray0[slot] = mk4(nextO, nextD.x);
             pool.thr[slot] = mk4(thr, __uint_as_float(rng));
@@ -1646,12 +1647,13 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
 // and the idle ones held wave slots - 7 % slower than no sort at all; profiles/r3_ab_shade_sort.txt).
 constexpr uint32_t kSortRounds = 8u;                      // slots per lane
 constexpr uint32_t kSortWindow = 64u * kSortRounds;       // slots per wave
-constexpr uint32_t kKeyWalk = 12u, kKeyMiss = 13u, kKeyLand = 14u, kKeyIdle = 15u;   // keys 0..8: unknown, material type + 1
+constexpr uint32_t kKeyMiss = 13u, kKeyLand = 14u, kKeyIdle = 15u;   // keys 0..8: unknown, material type + 1
 
 template <bool COUNT, bool SSS, bool TEX>
 __global__ void __launch_bounds__(64) PTR_SHADE_WAVES_ATTR k_shade_sorted(RenderParams rp, SceneView sc, PathPool pool, ShadeResets resets) {
     __shared__ uint16_t order[kSortWindow];    // sorted position -> slot of the window
     __shared__ uint32_t result[kSortWindow];   // per slot of the window: shadeSlot's result word
+    __shared__ float2 hits[kSortWindow];       // per slot of the window: its hit record, read once in slot order
     const uint32_t lane = threadIdx.x;         // a block is one wave
     const uint32_t base = blockIdx.x * kSortWindow;
     if (blockIdx.x == 0u) {
@@ -1665,33 +1667,31 @@ __global__ void __launch_bounds__(64) PTR_SHADE_WAVES_ATTR k_shade_sorted(Render
         if (pool.connectClear) pool.connectClear[lane * kConnectCountStride] = 0u;
         if (pool.busyCountClear) pool.busyCountClear[lane * kConnectCountStride] = 0u;
     }
-    // ---- 1. classify the window (lane l: slots base + 64 r + l) ----
+    // ---- 1. classify the window (lane l: slots base + 64 r + l) from the hit words alone: the slots' state is not touched here ----
     uint32_t keys = 0u;   // 4 bits per round
 #pragma unroll
     for (uint32_t r = 0; r < kSortRounds; ++r) {
         const uint32_t own = base + r * 64u + lane;
         const bool inRange = own < pool.slots;
-        const uint32_t at = inRange ? own : 0u;
-        const uint32_t flagsIn = inRange ? reinterpret_cast<const uint32_t*>(pool.ray1 + at)[3] : 0u;
-        const uint32_t primIn = reinterpret_cast<const uint32_t*>(pool.hit + at)[1];
+        const float2 hitv = pool.hit[inRange ? own : 0u];
+        const uint32_t primIn = inRange ? __float_as_uint(hitv.y) : kHitIdle;
+        hits[r * 64u + lane] = hitv;
         result[r * 64u + lane] = 0u;
-        const bool active = (flagsIn & kFlagAlive) != 0u;
-        const bool touched = active || ((flagsIn >> kFlagPendingShift) & kFlagPendingMask) != 0u || (flagsIn & kFlagFlush) != 0u;
-        uint32_t key = touched ? kKeyLand : kKeyIdle;
-        if (active) {
-            if (SSS && (flagsIn & kFlagWalk)) {
-                key = kKeyWalk;
-            } else if (primIn == kHitMiss) {
-                key = kKeyMiss;
-            } else if (primIn & kHitSphereBit) {
-                key = 0u;
-                if (sc.materialCount > 0u) {
-                    const uint32_t material = min(sc.sphereInfo[primIn & kHitIndexMask].y, sc.materialCount - 1u);
-                    key = min(static_cast<uint32_t>(sc.materials[static_cast<size_t>(material) * kMaterialVec4 + kMatTypeEta].x), 7u) + 1u;
-                }
-            } else {
-                key = (primIn >> kHitKeyShift) & kHitKeyMask;
+        uint32_t key;
+        if (primIn == kHitIdle) {
+            key = kKeyIdle;
+        } else if (primIn == kHitLand) {
+            key = kKeyLand;
+        } else if (primIn == kHitMiss) {
+            key = kKeyMiss;
+        } else if (primIn & kHitSphereBit) {
+            key = 0u;
+            if (sc.materialCount > 0u) {
+                const uint32_t material = min(sc.sphereInfo[primIn & kHitIndexMask].y, sc.materialCount - 1u);
+                key = min(static_cast<uint32_t>(sc.materials[static_cast<size_t>(material) * kMaterialVec4 + kMatTypeEta].x), 7u) + 1u;
             }
+        } else {
+            key = (primIn >> kHitKeyShift) & kHitKeyMask;
         }
         keys |= key << (4u * r);
     }
@@ -1740,7 +1740,7 @@ __global__ void __launch_bounds__(64) PTR_SHADE_WAVES_ATTR k_shade_sorted(Render
         const uint32_t pick = order[mine ? first + lane : 0u];
         // (connect list: visit `first / 64` of window w appends to the sub-list wave 8 w + first / 64 of the unsorted kernel would use -
         // at most 64 entries per visit, so the sub-lists' regions hold them)
-        const uint32_t word = shadeSlot<COUNT, SSS, TEX, kShadeSorted>(rp, sc, pool, base + pick, mine, false, blockIdx.x * kSortRounds + (first >> 6), counts);
+        const uint32_t word = shadeSlot<COUNT, SSS, TEX, kShadeSorted>(rp, sc, pool, base + pick, mine, false, blockIdx.x * kSortRounds + (first >> 6), counts, hits[pick]);
         if (mine) result[pick] = word;
     }
     __syncthreads();
@@ -1762,6 +1762,9 @@ __global__ void __launch_bounds__(64) PTR_SHADE_WAVES_ATTR k_shade_sorted(Render
             pool.thr[own] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng));
             reinterpret_cast<uint32_t*>(pool.accum + own)[3] = claimed;
             if (TEX && pool.cone) pool.cone[own] = primaryCone(rp);
+        } else if (word != 0u && !(flags & kFlagAlive)) {
+            // a slot left without a ray: what its next visit is for (see PathPool::hit)
+            reinterpret_cast<uint32_t*>(pool.hit + own)[1] = (flags & (kFlagFlush | (kFlagPendingMask << kFlagPendingShift))) != 0u ? kHitLand : kHitIdle;
         }
         if (pool.busyOut) {
             // end of the frame: the slots the next iteration has to visit (see shadeSlot)
@@ -1992,7 +1995,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_connect_chain(RenderParams rp, 
     uint32_t rays = 0u, raysClosest = 0u;
     const ClampCfg cc = clampCfg(rp);
     for (uint32_t slot = gtid; slot < pool.slots; slot += gridDim.x * kTraceBlock) {
-        if (!(pool.pending[slot] & (1u << 4))) continue;
+        if (!((__float_as_uint(pool.ray1[slot].w) >> kFlagPendingShift) & (1u << 4))) continue;
         const ShadowRecordView& r = pool.rec[4];
         const float4 d4 = r.dir[slot];
         if (__float_as_uint(d4.w) != 2u) continue;
@@ -2097,7 +2100,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_tail_run(RenderParams rp, Scene
                 shadeSlot<COUNT, SSS, TEX, kShadeTail>(rp, sc, pool, slot, true, false, 0u, counts);
                 __threadfence();
                 // k_connect's part: the records this visit queued
-                uint32_t bits = pool.pending[slot] & kFlagPendingMask;
+                uint32_t bits = (__float_as_uint(pool.ray1[slot].w) >> kFlagPendingShift) & kFlagPendingMask;
                 while (bits != 0u) {
                     const uint32_t rec = static_cast<uint32_t>(__ffs(static_cast<int>(bits))) - 1u;
                     bits &= bits - 1u;
