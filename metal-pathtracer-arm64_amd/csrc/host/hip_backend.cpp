@@ -140,7 +140,6 @@ struct PtrDeviceScene {
     uint64_t tailBelow = 512ull << 10;
     uint64_t poolSlots = 32ull << 20;        // resident path slots at most (PTR_POOL_SLOTS)
     uint32_t poolGroups = 4;   // the pool is split into this many independent groups, one HIP stream each
-    bool shadeSort = false;    // PTR_SHADE_SORT=1: k_shade_sorted (measured slower on configs 2-4, profiles/r3_ab_shade_sort.txt)
     uint32_t feederChunk = 256;   // slots per work-head claim while the pool is full (it grows as the pool drains)
     std::vector<hipStream_t> groupStreams;   // streams of groups 1.. (group 0 runs on the caller's stream)
     std::vector<hipEvent_t> groupEvents;
@@ -475,7 +474,6 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     if (knobs.tailBelow >= 0) ds.tailBelow = static_cast<uint64_t>(knobs.tailBelow);
     if (knobs.poolSlots != 0) ds.poolSlots = knobs.poolSlots;
     if (knobs.poolGroups != 0) ds.poolGroups = knobs.poolGroups;
-    ds.shadeSort = knobs.shadeSort > 0;
     // stack entries a ray of this tree can need: one per binary level for the two-box walk, three per pair of levels for the
     // four-wide walk, the root beside an oversize leaf, and a margin
     const uint32_t stackNeed = std::min<uint32_t>(kTraversalStackDepth, 3u * ((static_cast<uint32_t>(bvh.maxDepth) + 1u) / 2u) + 4u);
@@ -689,12 +687,10 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
 
     PathPool pool;
     std::memset(&pool, 0, sizeof(pool));
-    // four arrays of `slots` words, or one 64 B record per slot (kernels/device_types.h StateWord)
-    const size_t wordStride = PTR_POOL_AOS ? 1u : slots;
-    pool.ray0.base = ds.state.ptr;
-    pool.ray1.base = ds.state.ptr + wordStride;
-    pool.thr.base = ds.state.ptr + 2u * wordStride;
-    pool.accum.base = ds.state.ptr + 3u * wordStride;
+    pool.ray0 = ds.state.ptr;
+    pool.ray1 = ds.state.ptr + slots;
+    pool.thr = ds.state.ptr + 2ull * slots;
+    pool.accum = ds.state.ptr + 3ull * slots;
     pool.hit = ds.hit.ptr;
     pool.flushItem = ds.flushItem.ptr;
     pool.signature = count ? ds.signature.ptr : nullptr;
@@ -888,7 +884,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
             // it still walks the slots: it is launched once the last count of live slots says its list is about to pay
             PathPool shadePool = gr.pool;
             if (!gr.shadeListed) shadePool.busyIn = nullptr;
-            timedLaunch(1, gr.stream, [&] { launchShade(rp, ds.view, shadePool, resets, count, ds.shadeSort, gr.stream); });
+            timedLaunch(1, gr.stream, [&] { launchShade(rp, ds.view, shadePool, resets, count, gr.stream); });
             timedLaunch(2, gr.stream, [&] { launchConnect(rp, ds.view, gr.pool, gr.cfg, count, gr.stream); });
             if (gr.busyStage != 0u) {
                 gr.busyStage = 2u;

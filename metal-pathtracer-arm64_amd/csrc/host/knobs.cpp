@@ -41,7 +41,6 @@ Knobs readKnobs() {
     k.maxItems = static_cast<uint64_t>(std::max<long long>(numberOr("PTR_MAX_ITEMS", 0), 0));
     if (k.maxItems != 0 && k.maxItems < 1024) k.maxItems = 1024;
     k.refillBelow = static_cast<int>(std::min<long long>(std::max<long long>(numberOr("PTR_REFILL_BELOW", 0), 0), 64));
-    k.shadeSort = static_cast<int>(numberOr("PTR_SHADE_SORT", -1));
     k.buildThreads = static_cast<uint32_t>(std::min<long long>(std::max<long long>(numberOr("PTR_BUILD_THREADS", 0), 0), 256));
     k.noOversize = numberOr("PTR_NO_OVERSIZE", 0) != 0;
     const char* verbose = std::getenv("PTR_VERBOSE");

@@ -15,7 +15,6 @@ struct Knobs {
     int64_t tailBelow = -1;        // PTR_TAIL_BELOW        live slots below which the end-of-frame kernels take over (0: never; -1: default)
     uint64_t maxItems = 0;         // PTR_MAX_ITEMS         per-sample accumulators one pass may hold (0: from the device's memory)
     int refillBelow = 0;           // PTR_REFILL_BELOW      traversing lanes below which a persistent wave refills, 1..64 (0: default 40)
-    int shadeSort = -1;            // PTR_SHADE_SORT        1: k_shade visits the slots of a wave's window sorted by shading key (default: where they lie)
     uint32_t buildThreads = 0;     // PTR_BUILD_THREADS     BVH builder threads (0: all cores)
     bool noOversize = false;       // PTR_NO_OVERSIZE       keep every triangle in the tree
     // PTR_VERBOSE: comma-separated topics printed to stderr - build (BVH / upload timings), polls (live slots per host poll),

@@ -25,13 +25,12 @@ constexpr uint32_t kLdsStackLevels = 16u;        // stack levels kept in LDS; de
 #endif
 constexpr uint32_t kTraceBlock = PTR_TRACE_BLOCK;   // threads per block of the traversal kernels
 constexpr uint32_t kTraceGridUnit = 256u;           // the host sizes traversal grids (and the spill area) in units of this many threads
-// Hit word of a traced ray: kHitMiss, or  bit31 = sphere | bits 26..29 = shade key | bits 0..25 = leaf-order primitive index.
-// The shade key (0 = not known here, else material type + 1) rides in the triangle record (bits 26..29 of t[1].w, next to kind and
-// geometry index) and is copied into the hit word by the primitive test that accepts the hit: k_shade sorts the slots of a block
-// by it before shading them (wavefront.hip, k_shade_sorted) without a dependent fetch.
+// Hit word of a traced ray: kHitMiss, or  bit31 = sphere | bits 0..25 = leaf-order primitive index.
+// Meta word of a triangle record (t[1].w): bits 31:30 = kind (0 mesh triangle, 2 rectangle half), bits 26..29 = material class
+// (material type + 1, never 0), bits 0..25 = geometry index.  The class field makes a rectangle's meta word distinct from every hit word
+// (a sphere hit word has bit 31 set and zeros in bits 26..30): an any-hit query that must ignore a rectangle's own triangles starts
+// with that meta word in its hit word (wavefront.hip, kind-3 records; anyHitFound).
 constexpr uint32_t kHitMiss = 0xFFFFFFFFu;
-constexpr uint32_t kHitIdle = 0xFFFFFFFEu;   // a slot without a ray and with nothing outstanding (written by k_shade / k_generate, never by a trace)
-constexpr uint32_t kHitLand = 0xFFFFFFFDu;   // a slot without a ray whose connection records / finished item are still to be added up
 constexpr uint32_t kHitSphereBit = 0x80000000u;
 constexpr uint32_t kHitKeyShift = 26u;
 constexpr uint32_t kHitKeyMask = 0xFu;

@@ -156,41 +156,15 @@ constexpr uint32_t kItemHeadWords = kItemHeads * kItemHeadStride + 1u;   // + th
 // 3 specular-NEE rectangle lights, 4 MNEE two-bounce chain.
 constexpr uint32_t kRecSlots = 5u;
 
-// The four 16 B words of a slot's path state.  PTR_POOL_AOS=1 lays them out as ONE 64 B record per slot (word w of slot s at
-// state[4 s + w]): a kernel that visits slots out of order (k_shade_sorted, the busy-list launches) then moves exactly the 64 B
-// sector of each slot it visits, where four separate arrays share every 128 B line between eight slots.  0: four arrays.
-#ifndef PTR_POOL_AOS
-#define PTR_POOL_AOS 0
-#endif
-struct StateWord {
-    float4* base;
-#if PTR_POOL_AOS
-    __host__ __device__ float4& operator[](size_t slot) const { return base[slot * 4u]; }
-    __host__ __device__ float4* operator+(size_t slot) const { return base + slot * 4u; }
-    __host__ __device__ StateWord& operator+=(size_t slots) {
-        base += slots * 4u;
-        return *this;
-    }
-#else
-    __host__ __device__ float4& operator[](size_t slot) const { return base[slot]; }
-    __host__ __device__ float4* operator+(size_t slot) const { return base + slot; }
-    __host__ __device__ StateWord& operator+=(size_t slots) {
-        base += slots;
-        return *this;
-    }
-#endif
-};
-
 struct PathPool {
     // Per-slot path state.  Every field a kernel does not need stays out of its loads: k_extend reads the two ray
     // words and writes 8 B; k_connect reads the records that are pending (through the connect list); k_shade streams
     // 72 B in and 64 B out per live slot (it was 96 / 80 with one 16 B state word, a 16 B hit and padded rays).
-    StateWord ray0;        // (origin.xyz, direction.x)
-    StateWord ray1;        // (direction.y, direction.z, pdf of the last BSDF sample, bits(flags))
-    float2* hit;           // (t, bits(hit word)) - barycentrics are recomputed by k_shade from the same operands.  For a slot without a
-                           // ray the hit word says what its next visit is for (kHitIdle / kHitLand): k_shade_sorted classifies from it alone
-    StateWord thr;         // (throughput.xyz, bits(rng state))
-    StateWord accum;       // (radiance sum of the slot's current work item, bits(work item))
+    float4* ray0;          // (origin.xyz, direction.x)
+    float4* ray1;        // (direction.y, direction.z, pdf of the last BSDF sample, bits(flags))
+    float2* hit;           // (t, bits(hit word)) - barycentrics are recomputed by k_shade from the same operands
+    float4* thr;           // (throughput.xyz, bits(rng state))
+    float4* accum;         // (radiance sum of the slot's current work item, bits(work item))
     uint32_t* flushItem;   // valid while kFlagFlush: the finished item whose sum is published once its last records have landed
     uint4* medium;         // media mode only: stack of up to 8 dielectric material ids (16 bit each), depth in the flags
     float2* cone;          // textured scenes only: ray cone of the slot's path (width at the ray origin, spread), shaders/pathtrace.metal:129-160

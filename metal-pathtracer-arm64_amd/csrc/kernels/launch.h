@@ -26,8 +26,7 @@ struct ShadeResets {
     uint32_t* nextAlive;     // live-slot counter of the next k_extend
     uint32_t drained;        // nonzero once most slots are dead: waves look at the state word alone before loading the rest
 };
-// sorted: the block-sorted kernel (k_shade_sorted) for a launch that walks the slots; a launch that walks a busy list ignores it
-void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, bool count, bool sorted,
+void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, bool count,
                  hipStream_t stream);
 void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count,
                    hipStream_t stream);

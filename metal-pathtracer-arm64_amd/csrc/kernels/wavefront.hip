@@ -350,7 +350,6 @@ struct Surface {
 __device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 dir, float t, uint32_t prim) {
     Surface s;
     s.t = t;
-    prim &= kHitSphereBit | kHitIndexMask;   // (the shade key in bits 26..29 is k_shade's business)
     s.prim = prim;
     s.bu = 0.0f;
     s.bv = 0.0f;
@@ -412,17 +411,27 @@ __device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 d
 
 // Next-ray origin: pushed off the surface along the (hit record's) shading normal, to the side the
 // direction leaves on, plus half an epsilon along the direction.
-__device__ __forceinline__ f3 offsetOrigin(const Surface& s, f3 direction) {
+struct OffsetFrame {   // what offsetOrigin needs from the hit, whatever the direction: a visit offsets up to three rays from one hit
+    f3 position, n;
+    float distance;
+};
+__device__ __forceinline__ OffsetFrame offsetFrame(const Surface& s) {
+    OffsetFrame of;
     f3 n = s.hitShadingNormal;
     if (dot(n, n) <= 0.0f) n = s.normal;
     if (dot(n, n) <= 0.0f) n = mk3(0.0f, 1.0f, 0.0f);
-    n = normalize(n);
-    const float sign = dot(direction, n) >= 0.0f ? 1.0f : -1.0f;
-    const float distance = smax(fabsf(s.t) * 1.0e-4f, kEps);
-    f3 o = s.position + n * (sign * distance);
+    of.n = normalize(n);
+    of.distance = smax(fabsf(s.t) * 1.0e-4f, kEps);
+    of.position = s.position;
+    return of;
+}
+__device__ __forceinline__ f3 offsetOrigin(const OffsetFrame& of, f3 direction) {
+    const float sign = dot(direction, of.n) >= 0.0f ? 1.0f : -1.0f;
+    f3 o = of.position + of.n * (sign * of.distance);
     o += (direction * kEps) * 0.5f;
     return o;
 }
+__device__ __forceinline__ f3 offsetOrigin(const Surface& s, f3 direction) { return offsetOrigin(offsetFrame(s), direction); }
 
 // Origin of the ray that leaves a separable-subsurface exit point (shaders/pathtrace.metal:6740-6766): offset_surface_point
 // (:1210-1220), then 0.02 along the exit normal and 0.04 along the direction - the biases the reference uses to get clear
@@ -588,7 +597,6 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams rp, PathPool pool
     pool.ray1[slot] = make_float4(d.y, d.z, 1.0f, __uint_as_float(flags));
     pool.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng));
     pool.accum[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(slot));
-    pool.hit[slot] = make_float2(0.0f, __uint_as_float(kHitIdle));   // (a slot with a ray gets its hit word from k_extend)
     if (pool.signature) pool.signature[slot] = 0u;
     if (pool.cone) pool.cone[slot] = primaryCone(rp);
 }
@@ -869,17 +877,18 @@ __device__ __forceinline__ bool applyPbrTextures(const SceneView& sc, const Surf
 #endif
 // (the instantiation with the Metal-only subsurface / PBR models runs at 4 waves too)
 #define PTR_SHADE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SSS ? 4 : PTR_SHADE_WAVES, SSS ? 4 : PTR_SHADE_WAVES)))
-// Work items for the lanes of a converged wave whose lane l holds slot 64 w + l (dense k_shade; the claim pass of k_shade_sorted).
+// Work items for the lanes of a converged wave whose lane l holds slot 64 w + l (dense k_shade).
 // Each wave holds a reservation of kItemReserve consecutive items in HBM and refills it with ONE atomic on one of kItemHeads range
 // heads (a per-lane or even per-wave-per-bounce atomic on one address caps at ~88 ops/us chip-wide; so does one shared head once
 // items are single samples).  Returns the lane's item, or rp.itemCount when it wanted none / none is left.  Must be called by all
 // 64 lanes.
-__device__ __forceinline__ uint32_t claimItems(const RenderParams& rp, const PathPool& pool, const uint32_t slot, const bool needItem) {
+__device__ __forceinline__ uint32_t claimItems(const RenderParams& rp, const PathPool& pool, const uint32_t slot, const bool needItem, uint2 res) {
+    // res: the wave's reservation, pool.itemReserve[slot / 64] - requested at the top of the visit with the slot's state, because only
+    // this wave position ever changes it (a load here would be one more trip to memory that nothing overlaps)
     const unsigned long long mask = __ballot(needItem);
     if (mask == 0ull) return rp.itemCount;
     const uint32_t waveId = slot / 64u;     // slot >= pool.slots lanes never need items
     const uint32_t firstLane = static_cast<uint32_t>(__ffsll(static_cast<long long>(mask))) - 1u;
-    uint2 res = pool.itemReserve[__builtin_amdgcn_readfirstlane(waveId)];
     const uint32_t resOld = res.x;
     const uint32_t n = static_cast<uint32_t>(__popcll(mask));
     const uint32_t avail = res.y - res.x;
@@ -957,16 +966,13 @@ __device__ __forceinline__ void partEnd(ShadeCounts& counts, uint32_t part, long
 // work items are claimed lane by lane.  kShadeTail: the caller is the end-of-frame kernel (k_tail_run), whose lanes hold arbitrary
 // slots AND diverge - nothing in here may then rely on the wave (no ballots, no list appends).
 // `listWave`: which sub-list this wave appends to (wave-uniform; unused in kShadeTail).
-constexpr int kShadeDense = 0, kShadeListed = 1, kShadeTail = 2, kShadeSorted = 3;
-// kShadeSorted: the caller is k_shade_sorted - the lanes of the (converged) wave hold slots of the block's 256-slot window in the order
-// of their shading keys; work items are claimed afterwards by the slot's own thread, so a finished path is left dead here.
-// Returns the slot's new flags word, bit 31 set when the slot wants a new work item (0 for a slot that was not touched).
+constexpr int kShadeDense = 0, kShadeListed = 1, kShadeTail = 2;
 // TEX (only with SSS): the scene has material textures - the per-hit texture lookups and the path's ray cone are compiled in.  A
 // separate instantiation because they cost registers whether or not a scene uses them: with the texture code in, the Metal-model
 // kernel drops to 3 waves/SIMD and untextured Metal-semantics scenes ran 19-25 % slower than in round 1.
 template <bool COUNT, bool SSS, bool TEX, int MODE>
-__device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const uint32_t slot, const bool inRange,
-                                              const bool drained, const uint32_t listWave, ShadeCounts& counts, const float2 hitGiven = float2{0.0f, 0.0f}) {
+__device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const uint32_t slot, const bool inRange,
+                                          const bool drained, const uint32_t listWave, ShadeCounts& counts) {
     constexpr bool TAIL = MODE == kShadeTail;
     // Everything that depends only on the slot index is requested up front, and the record loads are pointed at a
     // zero word when the record is not pending, so the kernel has ~11 loads in flight per lane after ONE dependent
@@ -974,14 +980,16 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
     const long long tLoad = partBegin<COUNT>();
     const uint32_t at = inRange ? slot : 0u;
     float4 ray1v = pool.ray1[at];
-    if (!TAIL && MODE != kShadeSorted && drained) {
+    if (!TAIL && drained) {
         // end of the frame: most waves cover 64 dead slots, and the loads below would still stream 56 B per slot
         const uint32_t peek = __float_as_uint(ray1v.w);
         const bool busy = inRange && (peek & (kFlagAlive | kFlagFlush | (kFlagPendingMask << kFlagPendingShift))) != 0u;
-        if (__ballot(busy) == 0ull) return 0u;
+        if (__ballot(busy) == 0ull) return;
     }
     const float4 ray0v = pool.ray0[at];
-    const float2 hitv = MODE == kShadeSorted ? hitGiven : pool.hit[at];   // (the sorted kernel read the window's hit words in slot order)
+    uint2 reservation = make_uint2(0u, 0u);
+    if (MODE == kShadeDense && (slot & ~63u) < pool.slots) reservation = pool.itemReserve[__builtin_amdgcn_readfirstlane(slot / 64u)];   // (wave-uniform)
+    const float2 hitv = pool.hit[at];
     const float4 thr4 = pool.thr[at];
     const float4 acc4 = pool.accum[at];
     const uint32_t flagsIn = inRange ? __float_as_uint(ray1v.w) : 0u;
@@ -1143,6 +1151,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
             } else {
                 const long long tSurface = partBegin<COUNT>();
                 const Surface sf = reconstruct(sc, rayO, rayD, hitv.x, prim);
+                const OffsetFrame of = offsetFrame(sf);   // (the same operations offsetOrigin(sf, .) would repeat per ray)
                 if (COUNT) {
                     shadedHit = 1u;
                     if (COUNT) counts.stage[2] += 1u;
@@ -1197,7 +1206,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
                 partEnd<COUNT>(counts, kShadePartSurface, tSurface);
                 if (SSS && passThrough) {
                     // pathtrace.metal:6206-6216: the ray carries on through the surface; counts as a specular bounce
-                    nextO = offsetOrigin(sf, rayD);
+                    nextO = offsetOrigin(of, rayD);
                     nextD = rayD;
                     lastPdf = 1.0f;
                     lastDelta = true;
@@ -1264,7 +1273,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
                                                 // tfar is measured from the un-offset hit point (reference quirk Q9)
                                                 // (rp.shadowSlack is a test knob, 0 in every product render: x * 1.0f is x)
                                                 const float shadowMax = smax(distance * (1.0f - rp.shadowSlack) - kEps, kEps);
-                                                const f3 shadowOrg = offsetOrigin(sf, ldir);
+                                                const f3 shadowOrg = offsetOrigin(of, ldir);
                                                 // The shadow ray starts off the surface but its length is measured from the surface (quirk Q9), so from
                                                 // any surface that faces the light's plane it reaches the light's OWN rectangle and is occluded by it -
                                                 // after walking the whole scene on the way.  An any-hit query is occluded as soon as one primitive is
@@ -1314,7 +1323,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
                                 if (finite3(contrib)) {
                                     const f3 clamped = clampFirefly(thr, contrib, cc);
                                     if (clamped.x > 0.0f || clamped.y > 0.0f || clamped.z > 0.0f) {
-                                        storeRecord(pool, slot, 1u, 0u, offsetOrigin(sf, edir), INFINITY, edir, clamped, 0.0f, mk3(0.0f));
+                                        storeRecord(pool, slot, 1u, 0u, offsetOrigin(of, edir), INFINITY, edir, clamped, 0.0f, mk3(0.0f));
                                         want[1] = true;
                                     }
                                 }
@@ -1374,7 +1383,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
                         if (specNeeEligible || mneeEligible) {
                             // light reached straight along the specular direction
                             const f3 sdir = normalize(bs.dir);
-                            const f3 sorg = offsetOrigin(sf, sdir);
+                            const f3 sorg = offsetOrigin(of, sdir);
                             if (sc.envSampling) {
                                 const float envPdf = smax(envPdfOf(sc, sdir, rp.envRotation), kSpecNeePdfFloor);
                                 const float invEnvPdf = smin(1.0f / envPdf, kSpecNeeInvPdfClamp);
@@ -1412,7 +1421,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
                         }
                         if (mneeEligible && rp.enableMneeSecondary) {
                             const f3 sdir = normalize(bs.dir);
-                            storeRecord(pool, slot, 4u, 2u, offsetOrigin(sf, sdir), __uint_as_float(rng), sdir, bs.weight, bs.pdf, thr);
+                            storeRecord(pool, slot, 4u, 2u, offsetOrigin(of, sdir), __uint_as_float(rng), sdir, bs.weight, bs.pdf, thr);
                             want[4] = true;
                         }
 
@@ -1424,7 +1433,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
                         } else {
                             lastPdf = bs.pdf > 0.0f ? bs.pdf : lastPdf;
                             lastDelta = bs.isDelta;
-                            nextO = (SSS && bs.hasExit) ? sssExitOrigin(bs.exitPoint, n, bs.dir) : offsetOrigin(sf, bs.dir);
+                            nextO = (SSS && bs.hasExit) ? sssExitOrigin(bs.exitPoint, n, bs.dir) : offsetOrigin(of, bs.dir);
                             nextD = bs.dir;
                             if (TEX && pool.cone) {
                                 // the path's ray cone: width at this hit, spread widened by the sampled lobe (pathtrace.metal:7262-7267, 5703-5715)
@@ -1486,9 +1495,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
     if (COUNT) counts.stage[8] += needItem ? 1u : 0u;
     // ---- claim new work items ----
     const long long tItem = partBegin<COUNT>();
-    if (MODE == kShadeSorted) {
-        // the slot's own thread claims after the sorted pass (k_shade_sorted): the path is left dead here
-    } else if (MODE != kShadeDense) {
+    if (MODE != kShadeDense) {
         // end of the frame: the range heads are dry; what can be left is the unused part of the last reservation of this slot's
         // 64-slot group (csrc/host/hip_backend.cpp hands a group to the tail kernel only after the heads ran dry)
         if (needItem) {
@@ -1505,7 +1512,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
             }
         }
     } else {
-        const uint32_t claimed = claimItems(rp, pool, slot, needItem);
+        const uint32_t claimed = claimItems(rp, pool, slot, needItem, reservation);
         if (needItem && claimed < rp.itemCount) {
             item = claimed;
             beginSample(rp, pool.pixelOfLocal[claimed % rp.localPixels], claimed / rp.localPixels, rng, nextO, nextD);
@@ -1522,16 +1529,12 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
     for (uint32_t k = 0; k < kRecSlots; ++k) {
         if (want[k]) pendingMask |= 1u << k;
     }
-    uint32_t newFlags = 0u;
     if (touched) {
         const uint32_t flags = (stillAlive ? kFlagAlive : 0u) | (lastDelta ? kFlagLastDelta : 0u) | (flushNext ? kFlagFlush : 0u) |
                                (walkFlag ? kFlagWalk : 0u) | (depth << kFlagDepthShift) | (specDepth << kFlagSpecDepthShift) |
                                (mediumDepth << kFlagMediumShift) | (pendingMask << kFlagPendingShift);
-        newFlags = flags;
         pool.ray1[slot] = make_float4(nextD.y, nextD.z, lastPdf, __uint_as_float(flags));
         pool.accum[slot] = mk4(acc, __uint_as_float(item));
-        // a slot left without a ray tells its next visit what it is for (a sorted launch claims work items afterwards and writes it then)
-        if (MODE != kShadeSorted && !stillAlive) reinterpret_cast<uint32_t*>(pool.hit + slot)[1] = (pendingMask != 0u || flushNext) ? kHitLand : kHitIdle;
         if (stillAlive) {
             pool.ray0[slot] = mk4(nextO, nextD.x);
             pool.thr[slot] = mk4(thr, __uint_as_float(rng));
@@ -1554,7 +1557,7 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
         }
     }
 
-    if (!TAIL && MODE != kShadeSorted && pool.busyOut) {
+    if (!TAIL && pool.busyOut) {
         // end of the frame: the slots the next iteration has to visit (same scheme)
         const bool busy = touched && (stillAlive || pendingMask != 0u || flushNext);
         const unsigned long long mask = __ballot(busy);
@@ -1574,7 +1577,6 @@ __device__ __forceinline__ uint32_t shadeSlot(const RenderParams& rp, const Scen
         counts.triHit += triHit;
         counts.primary += primary;
     }
-    return touched ? (newFlags | (needItem && !stillAlive ? 0x80000000u : 0u)) : 0u;
 }
 
 // LISTED: the launch walks pool.busyIn instead of the slots (end of the frame, see PathPool)
@@ -1608,177 +1610,6 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
         shadeSlot<COUNT, SSS, TEX, kShadeListed>(rp, sc, pool, slot, inRange, drained, index >> 6, counts);
     } else {
         shadeSlot<COUNT, SSS, TEX, kShadeDense>(rp, sc, pool, index, index < pool.slots, resets.drained != 0u, index >> 6, counts);
-    }
-    if (COUNT) {
-        addCounter(pool.counters, kCntShadedHits, counts.shadedHit);
-        addCounter(pool.counters, kCntTriangleHits, counts.triHit);
-        addCounter(pool.counters, kCntPrimaryRays, counts.primary);
-        addCounter(pool.counters, kCntExtendRays, counts.settled);
-#pragma unroll
-        for (uint32_t k = 0; k < 9u; ++k) addCounter(pool.counters, kCntShadeWaves + k, counts.stage[k]);
-#pragma unroll
-        for (uint32_t k = 0; k < kShadeParts; ++k) {
-            addCounter(pool.counters, kCntShadeLaneTicks + k, counts.laneTicks[k]);
-            addCounter(pool.counters, kCntShadeWaveTicks + k, counts.waveTicks[k]);
-        }
-    }
-}
-
-// =====================================================================================================
-// k_shade_sorted: k_shade for a full pool, with the slots of a wave's window visited in the order of their shading keys
-// =====================================================================================================
-// What a visit does depends on what the slot's ray found: nothing to do / records to add up / the background / a light / a surface
-// of one of eight material models.  Visited where they lie, the 64 slots of a wave are a mix of all of these and every branch runs
-// with the lanes of its own kind only (config 2: 62 % of the lanes shade a surface, 26 % the background, 33 % start a new sample;
-// VALU lane utilisation 0.51, and 0.25 on the scene with car paint next to Lambertian walls).  Here ONE WAVE owns a window of
-// kSortWindow consecutive slots (kSortRounds per lane) and
-//   1. classifies them from two words that are read in slot order (flags, hit word: the shade key of the primitive rides in the hit
-//      word, kernels/bvh_layout.h) - no dependent fetch;
-//   2. sorts them by key: ballots give a slot its rank among the equal keys before it, lane k counts key k, one prefix sum over
-//      those counts places the keys, and the order goes to LDS (stable: within a key the slots keep their order, so the loads of a
-//      visit still fall into a few cache lines of the window);
-//   3. runs the ordinary visit (shadeSlot) on 64 slots of that order at a time: a visit is uniform in what it does except at the
-//      seams between two keys, idle slots sort to the end and are never visited (a window of 512 with 62 % Lambertian hits: five
-//      visits run the surface code instead of eight).  The window's state is read and written by this wave alone, so HBM traffic
-//      is what it was;
-//   4. back in slot order, claims a new work item for every slot whose path ended (the per-wave reservations want the dense
-//      order) and writes the camera rays.
-// No barriers and nothing shared between waves (a block-wide sort was built first: its waves waited for each other at the barriers
-// and the idle ones held wave slots - 7 % slower than no sort at all; profiles/r3_ab_shade_sort.txt).
-constexpr uint32_t kSortRounds = 8u;                      // slots per lane
-constexpr uint32_t kSortWindow = 64u * kSortRounds;       // slots per wave
-constexpr uint32_t kKeyMiss = 13u, kKeyLand = 14u, kKeyIdle = 15u;   // keys 0..8: unknown, material type + 1
-
-template <bool COUNT, bool SSS, bool TEX>
-__global__ void __launch_bounds__(64) PTR_SHADE_WAVES_ATTR k_shade_sorted(RenderParams rp, SceneView sc, PathPool pool, ShadeResets resets) {
-    __shared__ uint16_t order[kSortWindow];    // sorted position -> slot of the window
-    __shared__ uint32_t result[kSortWindow];   // per slot of the window: shadeSlot's result word
-    __shared__ float2 hits[kSortWindow];       // per slot of the window: its hit record, read once in slot order
-    const uint32_t lane = threadIdx.x;         // a block is one wave
-    const uint32_t base = blockIdx.x * kSortWindow;
-    if (blockIdx.x == 0u) {
-        if (lane == 0u) {
-            // k_shade runs between this iteration's k_extend and k_connect: it clears the work heads they will claim from next
-            if (resets.extendHead) *resets.extendHead = 0u;
-            if (resets.connectHead) *resets.connectHead = 0u;
-            if (resets.nextAlive) *resets.nextAlive = 0u;
-        }
-        // the next iteration's list counters (kConnectQueues == 64: one per lane)
-        if (pool.connectClear) pool.connectClear[lane * kConnectCountStride] = 0u;
-        if (pool.busyCountClear) pool.busyCountClear[lane * kConnectCountStride] = 0u;
-    }
-    // ---- 1. classify the window (lane l: slots base + 64 r + l) from the hit words alone: the slots' state is not touched here ----
-    uint32_t keys = 0u;   // 4 bits per round
-#pragma unroll
-    for (uint32_t r = 0; r < kSortRounds; ++r) {
-        const uint32_t own = base + r * 64u + lane;
-        const bool inRange = own < pool.slots;
-        const float2 hitv = pool.hit[inRange ? own : 0u];
-        const uint32_t primIn = inRange ? __float_as_uint(hitv.y) : kHitIdle;
-        hits[r * 64u + lane] = hitv;
-        result[r * 64u + lane] = 0u;
-        uint32_t key;
-        if (primIn == kHitIdle) {
-            key = kKeyIdle;
-        } else if (primIn == kHitLand) {
-            key = kKeyLand;
-        } else if (primIn == kHitMiss) {
-            key = kKeyMiss;
-        } else if (primIn & kHitSphereBit) {
-            key = 0u;
-            if (sc.materialCount > 0u) {
-                const uint32_t material = min(sc.sphereInfo[primIn & kHitIndexMask].y, sc.materialCount - 1u);
-                key = min(static_cast<uint32_t>(sc.materials[static_cast<size_t>(material) * kMaterialVec4 + kMatTypeEta].x), 7u) + 1u;
-            }
-        } else {
-            key = (primIn >> kHitKeyShift) & kHitKeyMask;
-        }
-        keys |= key << (4u * r);
-    }
-    // ---- 2. sort by key ----
-    uint32_t count = 0u;                      // lane k (< 16): slots of key k so far
-    uint32_t ranks[kSortRounds / 2u];         // rank of each of the lane's slots among the equal keys before it (two per word)
-#pragma unroll
-    for (uint32_t r = 0; r < kSortRounds; ++r) {
-        const uint32_t key = (keys >> (4u * r)) & 15u;
-        uint32_t rank = 0u;
-        unsigned long long remaining = ~0ull;
-        while (remaining != 0ull) {
-            const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(remaining))) - 1u;
-            const uint32_t k = __builtin_amdgcn_readlane(key, leader);
-            const unsigned long long same = __ballot(key == k);
-            const uint32_t before = __builtin_amdgcn_readlane(count, k);
-            if (key == k) rank = before + static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
-            if (lane == k) count += static_cast<uint32_t>(__popcll(same));
-            remaining &= ~same;
-        }
-        if (r & 1u) ranks[r / 2u] |= rank << 16; else ranks[r / 2u] = rank;
-    }
-    uint32_t firstOfKey;   // lane k: sorted position of the first slot of key k
-    {
-        uint32_t incl = count;
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-            const uint32_t up = __shfl_up(incl, off, 64);
-            if (static_cast<int>(lane) >= off) incl += up;
-        }
-        firstOfKey = incl - count;
-    }
-    const uint32_t touchedCount = __builtin_amdgcn_readlane(firstOfKey, kKeyIdle);   // everything before the idle slots
-    if (touchedCount == 0u) return;   // nothing in this window needs a visit
-#pragma unroll
-    for (uint32_t r = 0; r < kSortRounds; ++r) {
-        const uint32_t key = (keys >> (4u * r)) & 15u;
-        const uint32_t rank = (ranks[r / 2u] >> ((r & 1u) * 16u)) & 0xFFFFu;
-        order[__shfl(firstOfKey, static_cast<int>(key), 64) + rank] = static_cast<uint16_t>(r * 64u + lane);
-    }
-    __syncthreads();   // (a one-wave block: orders the LDS accesses, no s_barrier)
-    // ---- 3. the visits, 64 slots of the sorted order at a time ----
-    ShadeCounts counts;
-    for (uint32_t first = 0u; first < touchedCount; first += 64u) {
-        const bool mine = first + lane < touchedCount;
-        const uint32_t pick = order[mine ? first + lane : 0u];
-        // (connect list: visit `first / 64` of window w appends to the sub-list wave 8 w + first / 64 of the unsorted kernel would use -
-        // at most 64 entries per visit, so the sub-lists' regions hold them)
-        const uint32_t word = shadeSlot<COUNT, SSS, TEX, kShadeSorted>(rp, sc, pool, base + pick, mine, false, blockIdx.x * kSortRounds + (first >> 6), counts, hits[pick]);
-        if (mine) result[pick] = word;
-    }
-    __syncthreads();
-    // ---- 4. new work items, in slot order ----
-    for (uint32_t r = 0; r < kSortRounds; ++r) {
-        const uint32_t own = base + r * 64u + lane;
-        const uint32_t word = result[r * 64u + lane];
-        if (__ballot(word != 0u) == 0ull) continue;
-        const bool needItem = (word >> 31) != 0u;
-        uint32_t flags = word & 0x7FFFFFFFu;
-        const uint32_t claimed = claimItems(rp, pool, own, needItem);
-        if (needItem && claimed < rp.itemCount) {
-            uint32_t rng;
-            f3 o, d;
-            beginSample(rp, pool.pixelOfLocal[claimed % rp.localPixels], claimed / rp.localPixels, rng, o, d);
-            flags |= kFlagAlive;   // (a finished path left lastDelta set, depth 0, lastPdf 1)
-            pool.ray0[own] = mk4(o, d.x);
-            pool.ray1[own] = make_float4(d.y, d.z, 1.0f, __uint_as_float(flags));
-            pool.thr[own] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng));
-            reinterpret_cast<uint32_t*>(pool.accum + own)[3] = claimed;
-            if (TEX && pool.cone) pool.cone[own] = primaryCone(rp);
-        } else if (word != 0u && !(flags & kFlagAlive)) {
-            // a slot left without a ray: what its next visit is for (see PathPool::hit)
-            reinterpret_cast<uint32_t*>(pool.hit + own)[1] = (flags & (kFlagFlush | (kFlagPendingMask << kFlagPendingShift))) != 0u ? kHitLand : kHitIdle;
-        }
-        if (pool.busyOut) {
-            // end of the frame: the slots the next iteration has to visit (see shadeSlot)
-            const bool busy = (flags & (kFlagAlive | kFlagFlush | (kFlagPendingMask << kFlagPendingShift))) != 0u;
-            const unsigned long long mask = __ballot(busy);
-            if (mask != 0ull) {
-                const uint32_t queue = (blockIdx.x * kSortRounds + r) & (kConnectQueues - 1u);
-                uint32_t at = 0u;
-                if (lane == 0u) at = atomicAdd(pool.busyCountOut + queue * kConnectCountStride, static_cast<uint32_t>(__popcll(mask)));
-                at = __builtin_amdgcn_readfirstlane(at);
-                const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
-                if (busy) pool.busyOut[queue * pool.connectRegion + at + rank] = own | ((flags & kFlagAlive) ? kBusyAliveBit : 0u);
-            }
-        }
     }
     if (COUNT) {
         addCounter(pool.counters, kCntShadedHits, counts.shadedHit);
@@ -2416,21 +2247,11 @@ void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig&
     }
 }
 
-void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, bool count, bool sorted,
+void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, bool count,
                  hipStream_t stream) {
     const bool sss = (rp.mediaMode & (PTR_METAL_SSS | PTR_METAL_PBR | PTR_METAL_CLAMPS)) != 0u;   // the instantiation that carries those Metal-only models
     const bool listed = pool.busyIn != nullptr;   // the grid still covers every slot: waves beyond the list leave at once
     const bool tex = sss && sc.textureCount > 0u;   // the instantiation with the texture lookups and the ray cone
-    if (sorted && !listed) {
-        const uint32_t grid = ceilDiv(pool.slots, kSortWindow);
-        auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, stream, rp, sc, pool, resets); };
-        if (count) {
-            if (tex) launch(k_shade_sorted<true, true, true>); else if (sss) launch(k_shade_sorted<true, true, false>); else launch(k_shade_sorted<true, false, false>);
-        } else {
-            if (tex) launch(k_shade_sorted<false, true, true>); else if (sss) launch(k_shade_sorted<false, true, false>); else launch(k_shade_sorted<false, false, false>);
-        }
-        return;
-    }
     const uint32_t grid = ceilDiv(pool.slots, kShadeBlock);
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, resets); };
     auto pick = [&](auto countTag, auto listedTag) {

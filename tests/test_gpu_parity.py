@@ -643,7 +643,6 @@ def test_scheduling_knobs_do_not_change_the_image():
     for env in ({"PTR_POOL_GROUPS": "1"}, {"PTR_TAIL_BELOW": "0"}, {"PTR_POOL_SLOTS": str(3 << 20), "PTR_REFILL_BELOW": "24"},
                 {"PTR_WIDE_NODES": "0"},        # the binary walk instead of the four-wide nodes (same tree, one level at a time)
                 {"PTR_QUANTIZED_NODES": "0"},   # 64 B float nodes (box tests only prune: the hits are the same)
-                {"PTR_SHADE_SORT": "1"},        # k_shade visits the slots of a window sorted by shading key instead of where they lie
                 {"PTR_MAX_ITEMS": str(1920 * 1080 * 12)},   # the whole frame still fits one pass
                 {"PTR_BUILD_THREADS": "3", "PTR_VERBOSE": "build"},   # same tree from any number of builder threads
                 {"PTR_NO_OVERSIZE": "1"}):      # (this scene keeps every triangle in the tree anyway)
