@@ -346,7 +346,7 @@ __device__ __forceinline__ bool travPrimStep(const SceneView& sc, const SceneMem
         // meta word of the rectangle whose own two triangles a light connection ignores - wavefront.hip, kind-3 records)
         if (triangleTest(mk3(a), mk3(b), mk3(c), t.org, t.dir, t.tnear, t.hit.t, tt, u, v) && !(t.anyHit && __float_as_uint(b.w) == t.hit.prim)) {
             t.hit.t = tt;
-            t.hit.prim = index | (__float_as_uint(b.w) & (kHitKeyMask << kHitKeyShift));   // the triangle's shade key rides along
+            t.hit.prim = index;
             if (t.anyHit) return false;
         }
     }
