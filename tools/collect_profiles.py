@@ -21,7 +21,7 @@ def last_json_line(path):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
-    ap.add_argument("--round", type=int, default=2)
+    ap.add_argument("--round", type=int, default=3)
     args = ap.parse_args()
     out = os.path.join(ROOT, "gpurun_out")
     prof = os.path.join(ROOT, "profiles")
@@ -34,7 +34,7 @@ def main():
             shutil.copy(src, os.path.join(prof, dst))
             done.append(dst)
 
-    for cfg in ("cfg2", "cfg5"):
+    for cfg in ("cfg2", "cfg4", "cfg5"):
         copy(os.path.join(out, "solo_%s_%s.json" % (cfg, t)), r + "solo_%s.json" % cfg)
         copy(os.path.join(out, "solo_%s_%s_kernel_stats.csv" % (cfg, t)), r + "kernel_stats_solo_%s.csv" % cfg)
     bench = os.path.join(out, "bench_%s.json" % t)

@@ -9,6 +9,7 @@
 # copies the summaries into profiles/.  One GPU process at a time; --pmc passes carry only --kernel-trace.
 TAG=${1:-refresh}
 WHAT=${2:-solo}
+ROUND=${ROUND:-r3}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
@@ -17,9 +18,11 @@ case $WHAT in
 solo)
   python3 -c "
 from scenes.gen_assets import ensure_assets, ensure_large_asset
-ensure_assets(); ensure_large_asset('lucy_standin_28005128.ply'); ensure_large_asset('blob_1002528.ply')"
-  bash tools/measure_solo.sh solo_cfg2_$TAG > gpurun_out/solo_cfg2_$TAG.log 2>&1 && cp gpurun_out/solo_cfg2_$TAG.json profiles/r2_solo_cfg2.json
-  PTR_VERBOSE=build bash tools/measure_solo.sh solo_cfg5_$TAG $CFG5 > gpurun_out/solo_cfg5_$TAG.log 2>&1 && cp gpurun_out/solo_cfg5_$TAG.json profiles/r2_solo_cfg5.json
+ensure_assets(); [ensure_large_asset(a) for a in ('torus_knot_871200.ply', 'lucy_standin_28005128.ply', 'blob_1002528.ply')]"
+  # (bench.py quotes the solo records of this round: they are copied into place before the bench line is taken)
+  bash tools/measure_solo.sh solo_cfg2_$TAG > gpurun_out/solo_cfg2_$TAG.log 2>&1 && cp gpurun_out/solo_cfg2_$TAG.json profiles/${ROUND}_solo_cfg2.json
+  bash tools/measure_solo.sh solo_cfg4_$TAG --scene $R/scenes/knot_glass.scene --depth 16 --spp 128 > gpurun_out/solo_cfg4_$TAG.log 2>&1 && cp gpurun_out/solo_cfg4_$TAG.json profiles/${ROUND}_solo_cfg4.json
+  PTR_VERBOSE=build bash tools/measure_solo.sh solo_cfg5_$TAG $CFG5 > gpurun_out/solo_cfg5_$TAG.log 2>&1 && cp gpurun_out/solo_cfg5_$TAG.json profiles/${ROUND}_solo_cfg5.json
   timeout -k 10 300 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
   cut -c1-300 gpurun_out/bench_$TAG.json
   (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1)
