@@ -42,6 +42,11 @@ int ptr_debug_texture_sample(PtrDeviceScene* scene, uint32_t texture, const floa
  * shading normal xyz, front face (1/0), next origin xyz, 0}. */
 int ptr_debug_surface_hits(PtrDeviceScene* scene, const float* in, uint64_t n, float* out, char* err, size_t err_cap);
 
+/* Which k_shade instantiation a render of `scene` with `settings` launches: bit t (0..7) = material type t compiled in, bit 8 = the
+ * environment map, bit 9 = the Metal medium stack / face-normal rule; 0x3FF = the full kernel.  (The product picks the smallest
+ * compiled set that covers the scene: the tests check that every set renders what the full kernel renders.) */
+int ptr_debug_shade_kernel_set(const PtrDeviceScene* scene, const PtrSettings* settings, int count, uint32_t* out);
+
 /* ptr_render_multi on an explicit list of devices; an id may appear more than once, which lets a one-GPU box run the whole
  * multi-device path (threads, partitions, hand-over, interleave).  An id given as -(id + 1) routes that partition's bands through the
  * pinned-host staging copy ptr_render_multi falls back to when two devices cannot address each other (hipDeviceCanAccessPeer). */

@@ -218,7 +218,7 @@ ABI_SYMBOLS = (
 # include/ptr_debug.h (test-only device-function probes)
 DEBUG_SYMBOLS = ("ptr_debug_eval_bsdf", "ptr_debug_sample_bsdf", "ptr_debug_camera_rays", "ptr_debug_env_distribution",
                  "ptr_debug_scene_geometry", "ptr_debug_render_signatures", "ptr_debug_render_multi_on", "ptr_debug_texture_sample",
-                 "ptr_debug_generate_tangents", "ptr_debug_surface_hits")
+                 "ptr_debug_generate_tangents", "ptr_debug_surface_hits", "ptr_debug_shade_kernel_set")
 
 _lib: Optional[C.CDLL] = None
 
@@ -400,6 +400,15 @@ class DeviceScene:
         load_library().ptr_scene_info(self._h, out)
         keys = ("nodes", "leaves", "triangles", "spheres", "max_depth", "max_leaf", "sah_cost_x1000", "rect_lights")
         return dict(zip(keys, [int(v) for v in out]))
+
+    def shade_kernel_set(self, settings: PtrSettings, count: bool = False) -> int:
+        """ptr_debug_shade_kernel_set: the material / feature mask of the k_shade instantiation a render launches (0x3FF = full)."""
+        lib = load_library()
+        lib.ptr_debug_shade_kernel_set.argtypes = [C.c_void_p, C.POINTER(PtrSettings), C.c_int, C.POINTER(C.c_uint32)]
+        out = C.c_uint32(0)
+        if lib.ptr_debug_shade_kernel_set(self._h, C.byref(settings), int(count), C.byref(out)) != 0:
+            raise PtrError("ptr_debug_shade_kernel_set failed")
+        return int(out.value)
 
     def surface_hits(self, rays) -> np.ndarray:
         """ptr_debug_surface_hits: rays [n, 9] {origin, direction, next direction} -> [n, 16]."""

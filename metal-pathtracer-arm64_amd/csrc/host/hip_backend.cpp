@@ -416,6 +416,7 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     v.materialCount = desc.materialCount;
     v.rectCount = desc.rectCount;
     v.rectLightCount = lightCount;
+    for (uint32_t i = 0; i < desc.materialCount; ++i) v.materialTypes |= 1u << std::min(static_cast<uint32_t>(desc.materials[i].typeEta[0]), 7u);
     v.settleRectLights = (lightCount > 0u && lightCount <= 8u && ps.lightsHaveTriangles) ? 1u : 0u;   // kSettleLightsMax of wavefront.hip
 
     if (desc.envRgba && desc.envWidth > 0 && desc.envHeight > 0) {
@@ -1575,6 +1576,14 @@ int ptr_debug_surface_hits(PtrDeviceScene* scene, const float* in, uint64_t n, f
         return 0;
     }
     PTR_CATCH_ALL(err, err_cap)
+}
+
+int ptr_debug_shade_kernel_set(const PtrDeviceScene* scene, const PtrSettings* settings, int count, uint32_t* out) {
+    if (!scene || !settings || !out) return 1;
+    RenderParams rp;
+    fillRenderParams(*settings, 1, rp);
+    *out = shadeKernelSet(rp, scene->view, count != 0);
+    return 0;
 }
 
 int ptr_debug_eval_bsdf(const PtrMaterial* material, const PtrSettings* settings, const float* in, uint64_t n, float* out,

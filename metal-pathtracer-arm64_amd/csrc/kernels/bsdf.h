@@ -692,7 +692,13 @@ __device__ BsdfEvalResult evalPbrMetal(const Mat& m, f3 n, f3 wo, f3 wi, const C
 
 // SSS: compiled with the Metal subsurface semantics (PTR_METAL_SSS).  A template parameter, not a run-time flag: the extra
 // branch and the exit point it carries cost the default k_shade 3 % when they were merely predicated off.
-template <bool SSS = false>
+// MATS: bit t set = material type t can occur (the host knows a scene's materials: an instantiation compiled for the types of a
+// simple scene carries no registers or code for car paint, plastic or the metallic-roughness model).  A type outside the set cannot
+// reach these functions; it would fall through to the Lambert branch.
+constexpr uint32_t kFeatureEnvironment = 1u << 8;   // ... and two scene features k_shade compiles out with them: an environment map,
+constexpr uint32_t kFeatureMedia = 1u << 9;         // the Metal integrator's medium stack / face-normal rule
+constexpr uint32_t kAllMaterials = 0x3FFu;
+template <bool SSS = false, uint32_t MATS = kAllMaterials>
 __device__ BsdfEvalResult evalBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 wi, const ClampCfg& cc) {
     if (SSS && cc.metalPbr && m.type() == 7u) return evalPbrMetal(m, n, wo, wi, cc);   // before the same-side test below
     BsdfEvalResult r{mk3(0.0f), 0.0f, false};
@@ -702,6 +708,7 @@ __device__ BsdfEvalResult evalBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 wi
     if (SSS && type == 5u && cc.metalSss) return r;   // is_bssrdf: value 0, pdf 0 -> no next-event estimation (pathtrace.metal:5078-5084)
     switch (type) {
         case 7u: {  // PBR metallic-roughness
+            if (!(MATS & (1u << 7))) break;
             const Pbr p = loadPbr(m);
             const float alpha = smax(p.roughness * p.roughness, 1.0e-4f);
             const f3 wh = normalize(wo + wi);
@@ -718,6 +725,7 @@ __device__ BsdfEvalResult evalBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 wi
             return r;
         }
         case 4u: {  // plastic
+            if (!(MATS & (1u << 4))) break;
             const Coat c = loadCoat(m);
             f3 spec, diffuse;
             float specPdf;
@@ -731,6 +739,7 @@ __device__ BsdfEvalResult evalBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 wi
             return r;
         }
         case 1u: {  // metal
+            if (!(MATS & (1u << 1))) break;
             const float rough = m.roughness01();
             if (rough <= 1.0e-3f) {
                 r.isDelta = true;
@@ -751,6 +760,7 @@ __device__ BsdfEvalResult evalBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 wi
             return r;
         }
         case 6u: {  // car paint: probability-weighted mixture of base, flake and coat lobes
+            if (!(MATS & (1u << 6))) break;
             const CarPaint c = loadCarPaint(m);
             const Lobe coat = carpaintCoat(c, n, wo, wi, cc);
             const Lobe flake = carpaintFlake(c, position, n, wo, wi, cc);
@@ -762,11 +772,13 @@ __device__ BsdfEvalResult evalBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 wi
         case 2u:  // dielectric
             r.isDelta = true;
             return r;
-        default:  // Lambert, subsurface (Lambert on this path), anything unknown
-            r.value = m.baseColor() / kPi;
-            r.pdf = lambertPdf(n, wi);
-            return r;
+        default:
+            break;
     }
+    // Lambert, subsurface (Lambert on this path), anything unknown
+    r.value = m.baseColor() / kPi;
+    r.pdf = lambertPdf(n, wi);
+    return r;
 }
 
 struct BsdfSampleResult {
@@ -1124,7 +1136,7 @@ __device__ BsdfSampleResult samplePbrMetal(const Mat& m, f3 n, f3 wo, f3 inciden
     return r;
 }
 
-template <bool SSS = false>
+template <bool SSS = false, uint32_t MATS = kAllMaterials>
 __device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f3 incident, bool frontFace,
                                        uint32_t& rng, const ClampCfg& cc) {
     BsdfSampleResult r{mk3(0.0f), mk3(0.0f), 0.0f, false, 0, false, mk3(0.0f)};
@@ -1133,6 +1145,7 @@ __device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f
     if (SSS && type == 7u && cc.metalPbr) return samplePbrMetal(m, n, wo, incident, rng, cc);
     switch (type) {
         case 7u: {
+            if (!(MATS & (1u << 7))) break;
             const Pbr p = loadPbr(m);
             f3 wi, f;
             float pdfS = 0.0f, pdfD = 0.0f;
@@ -1171,6 +1184,7 @@ __device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f
             return r;
         }
         case 4u: {
+            if (!(MATS & (1u << 4))) break;
             const Coat c = loadCoat(m);
             const float alpha = c.roughness * c.roughness;
             const float pCoat = clampf(c.sampleWeight, 0.0f, 1.0f);
@@ -1198,6 +1212,7 @@ __device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f
             return r;
         }
         case 1u: {
+            if (!(MATS & (1u << 1))) break;
             const float rough = m.roughness01();
             const Conductor c = loadMetal(m);
             if (rough <= 1.0e-3f) {
@@ -1234,6 +1249,7 @@ __device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f
             return r;
         }
         case 6u: {
+            if (!(MATS & (1u << 6))) break;
             const CarPaint c = loadCarPaint(m);
             const float pick = rngNext(rng);
             uint32_t lobe = 0u;  // 0 base, 1 flake, 2 coat
@@ -1288,6 +1304,7 @@ __device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f
             return r;
         }
         case 2u: {  // smooth dielectric: Fresnel-weighted pick between mirror reflection and refraction
+            if (!(MATS & (1u << 2))) break;
             r.isDelta = true;
             const float refIdx = smax(m.ior(), 1.0f);
             // thin-walled glass (Metal semantics only, pathtrace.metal:5649-5659): both faces see air -> glass
@@ -1337,18 +1354,19 @@ __device__ BsdfSampleResult sampleBsdf(const Mat& m, f3 position, f3 n, f3 wo, f
             r.pdf = pdf;
             return r;
         }
-        default: {  // unknown type: cosine sampling with weight = albedo
-            float pdf = 0.0f;
-            const f3 wi = cosineHemisphere(rng, n, pdf);
-            if (pdf <= 0.0f) return r;
-            const f3 w = m.baseColor();
-            if (!finite3(w)) return r;
-            r.dir = wi;
-            r.weight = vmax0(w);
-            r.pdf = pdf;
-            return r;
-        }
+        default:
+            break;
     }
+    // unknown type: cosine sampling with weight = albedo
+    float pdf = 0.0f;
+    const f3 wi = cosineHemisphere(rng, n, pdf);
+    if (pdf <= 0.0f) return r;
+    const f3 w = m.baseColor();
+    if (!finite3(w)) return r;
+    r.dir = wi;
+    r.weight = vmax0(w);
+    r.pdf = pdf;
+    return r;
 }
 
 }  // namespace ptrk

@@ -65,7 +65,7 @@ struct SceneView {
     uint32_t textureCount;
     uint32_t settleRectLights;     // every rectangle light has its two triangles on record and there are few enough of them: k_shade settles
                                    // specular connections itself (wavefront.hip, kind-3 records)
-    uint32_t pad3;
+    uint32_t materialTypes;        // bit t set: some material of the scene has type t (k_shade instantiations for simple scenes)
     uint32_t stackLimit;           // traversal stack entries a ray of this scene can need at most (<= kTraversalStackDepth): LDS levels + spill levels
 };
 

@@ -56,6 +56,8 @@ void launchDebugSampleBsdf(const float4* dMaterial, const RenderParams& rp, cons
                            const uint32_t* dRng, uint64_t n, float* dOut, uint32_t* dRngOut, hipStream_t stream);
 void launchDebugTexSample(const SceneView& sc, uint32_t texture, const float* dIn, uint64_t n, float4* dOut, hipStream_t stream);
 // closest hit, surface record and next-ray origin per input ray: in n x 9 floats {origin, direction, next direction}, out n x 16 floats
+// the material / feature set of the k_shade instantiation launchShade picks (bsdf.h kAllMaterials = the full kernel)
+uint32_t shadeKernelSet(const RenderParams& rp, const SceneView& sc, bool count);
 void launchDebugSurfaceHits(const SceneView& sc, const float* dIn, uint64_t n, float* dOut, const LaunchConfig& cfg, hipStream_t stream);
 void launchDebugCameraRays(const RenderParams& rp, const uint32_t* dXys, uint64_t n, float* dOut, uint32_t* dRngOut,
                            hipStream_t stream);

@@ -877,6 +877,37 @@ __device__ __forceinline__ bool applyPbrTextures(const SceneView& sc, const Surf
 #endif
 // (the instantiation with the Metal-only subsurface / PBR models runs at 4 waves too)
 #define PTR_SHADE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SSS ? 4 : PTR_SHADE_WAVES, SSS ? 4 : PTR_SHADE_WAVES)))
+// Instantiations by material set.  The full kernel carries the registers of its heaviest branch (car paint, plastic, the metallic-
+// roughness model) for every scene: 128 VGPRs with 29 spilled, 4 waves per SIMD.  A scene's materials are known at upload
+// (SceneView::materialTypes), so launchShade picks the smallest compiled set that covers them; the lean sets need 94-96 registers
+// without spills and run 5 waves per SIMD, which hides more of the kernel's dependent loads (config 2: k_shade -12 % per launch,
+// frame +7.7 %; profiles/r3_ab_material_sets.txt).  6 waves (80 registers) spill into the hot path and lose 14 %.
+constexpr uint32_t kDiffuseMaterials = (1u << 0) | (1u << 3) | (1u << 5);                 // Lambert, light, subsurface-as-Lambert
+constexpr uint32_t kBasicMaterials = kDiffuseMaterials | (1u << 2);                       // ... and glass
+constexpr uint32_t kMetalMaterials = kBasicMaterials | (1u << 1);                         // ... and metals
+constexpr uint32_t kCarPaintMaterials = kBasicMaterials | (1u << 6);                      // car paint (+ the basic ones)
+constexpr uint32_t kPbrMaterials = kBasicMaterials | (1u << 7) | kFeatureEnvironment;     // glTF: metallic-roughness under an environment map
+// waves per SIMD of each set's instantiation (512 / waves = its register budget)
+#ifndef PTR_SHADE_WAVES_DIFFUSE
+#define PTR_SHADE_WAVES_DIFFUSE 5
+#endif
+#ifndef PTR_SHADE_WAVES_BASIC
+#define PTR_SHADE_WAVES_BASIC 5
+#endif
+#ifndef PTR_SHADE_WAVES_METAL
+#define PTR_SHADE_WAVES_METAL 4
+#endif
+#ifndef PTR_SHADE_WAVES_PBR
+#define PTR_SHADE_WAVES_PBR 5
+#endif
+constexpr int shadeWaves(bool sss, uint32_t mats) {
+    return mats == kDiffuseMaterials ? PTR_SHADE_WAVES_DIFFUSE
+           : mats == kBasicMaterials ? PTR_SHADE_WAVES_BASIC
+           : mats == kMetalMaterials ? PTR_SHADE_WAVES_METAL
+           : mats == kPbrMaterials   ? PTR_SHADE_WAVES_PBR
+                                     : (sss ? 4 : PTR_SHADE_WAVES);
+}
+#define PTR_SHADE_WAVES_ATTR_M __attribute__((amdgpu_waves_per_eu(shadeWaves(SSS, MATS), shadeWaves(SSS, MATS))))
 // Work items for the lanes of a converged wave whose lane l holds slot 64 w + l (dense k_shade).
 // Each wave holds a reservation of kItemReserve consecutive items in HBM and refills it with ONE atomic on one of kItemHeads range
 // heads (a per-lane or even per-wave-per-bounce atomic on one address caps at ~88 ops/us chip-wide; so does one shared head once
@@ -970,7 +1001,8 @@ constexpr int kShadeDense = 0, kShadeListed = 1, kShadeTail = 2;
 // TEX (only with SSS): the scene has material textures - the per-hit texture lookups and the path's ray cone are compiled in.  A
 // separate instantiation because they cost registers whether or not a scene uses them: with the texture code in, the Metal-model
 // kernel drops to 3 waves/SIMD and untextured Metal-semantics scenes ran 19-25 % slower than in round 1.
-template <bool COUNT, bool SSS, bool TEX, int MODE>
+// MATS: the material types the scene can contain (bsdf.h kAllMaterials, or the set of a simple scene: see launchShade)
+template <bool COUNT, bool SSS, bool TEX, int MODE, uint32_t MATS = kAllMaterials>
 __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const uint32_t slot, const bool inRange,
                                           const bool drained, const uint32_t listWave, ShadeCounts& counts) {
     constexpr bool TAIL = MODE == kShadeTail;
@@ -1021,6 +1053,11 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
     uint32_t sig = 0u;   // counting build: path signature of the slot's current item
     float2 cone = make_float2(0.0f, 0.0f);   // textured scenes: ray cone of the path (width at the ray origin, spread)
     bool haveCone = false, newSample = false;
+
+    // what the instantiation's scene cannot have is compiled out (kFeatureEnvironment, kFeatureMedia: see launchShade)
+    const uint32_t envWidth = (MATS & kFeatureEnvironment) ? sc.envWidth : 0u;
+    const bool envSampling = (MATS & kFeatureEnvironment) && sc.envSampling;
+    const uint32_t mediaMode = (MATS & kFeatureMedia) ? rp.mediaMode : 0u;
 
     if (touched) {
         const ClampCfg cc = clampCfg<SSS>(rp);
@@ -1129,14 +1166,14 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                 f3 bg;
                 if (rp.backgroundMode == PTR_BG_SOLID) {
                     bg = ld3(rp.backgroundColor);
-                } else if (rp.backgroundMode == PTR_BG_ENVIRONMENT && sc.envWidth > 0u) {
+                } else if (rp.backgroundMode == PTR_BG_ENVIRONMENT && envWidth > 0u) {
                     bg = envLookup(sc, rayD, rp.envRotation, rp.envIntensity);
                 } else {
                     bg = skyColor(rayD);
                 }
                 float mis = 1.0f;
                 const bool useMis = (!lastDelta) || rp.enableSpecularNee || rp.enableMnee;
-                if (useMis && sc.envSampling) {
+                if (useMis && envSampling) {
                     const float lightPdf = envPdfOf(sc, rayD, rp.envRotation);
                     const float denom = lastPdf + lightPdf;
                     if (denom > 0.0f) mis = lastPdf / denom;
@@ -1158,7 +1195,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                     triHit = sf.primType == 0u ? 1u : 0u;
                     sig = (sig & 0xFFFFu) | (sigHashStep(sig >> 16, sf.primType, sf.geomIndex, sf.primIndex) << 16);
                 }
-                if ((rp.mediaMode & PTR_METAL_MEDIA) && mediumDepth > 0u) {
+                if ((mediaMode & PTR_METAL_MEDIA) && mediumDepth > 0u) {
                     // Beer-Lambert over the segment just travelled inside the innermost medium (pathtrace.metal:5869-5876)
                     const uint32_t inside = mediumEntry(pool.medium[slot], mediumDepth - 1u);
                     const Mat mm{sc.materials + static_cast<size_t>(min(inside, sc.materialCount - 1u)) * kMaterialVec4};
@@ -1177,7 +1214,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                 if (dot(n, n) <= 0.0f) n = sf.normal;
                 if (type == 2u) {                   // dielectrics shade with the geometric normal
                     n = sf.normal;                  // (as stored: the Embree backend does not turn it towards the ray)
-                    if ((rp.mediaMode & PTR_METAL_FACE_NORMAL) && !sf.frontFace) n = -n;   // set_face_normal, pathtrace.metal:1187-1191
+                    if ((mediaMode & PTR_METAL_FACE_NORMAL) && !sf.frontFace) n = -n;   // set_face_normal, pathtrace.metal:1187-1191
                 }
                 n = normalize(n);
                 bool hitTwoSided = sf.twoSided;
@@ -1217,7 +1254,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                     // ---- emitter reached by a BSDF-sampled ray ----
                     const float4 em = mat.v(kMatEmission);
                     f3 emission = mk3(em) * rp.emissionScale;
-                    if (em.w > 0.0f && sc.envWidth > 0u && sf.frontFace) {
+                    if (em.w > 0.0f && envWidth > 0u && sf.frontFace) {
                         emission *= envLookup(sc, -n, rp.envRotation, rp.envIntensity);
                     }
                     if ((dot(emission, emission) > 0.0f) && (sf.frontFace || sf.twoSided)) {
@@ -1262,7 +1299,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                                 const float nDotL = smax(dot(n, ldir), 0.0f);
                                 if (pdf > 0.0f && isfinite(pdf) && (dot(emission, emission) > 0.0f) && nDotL > 0.0f) {
                                     if (COUNT) counts.stage[4] += 1u;
-                                    const BsdfEvalResult be = evalBsdf<SSS>(mat, sf.position, n, wo, ldir, cc);
+                                    const BsdfEvalResult be = evalBsdf<SSS, MATS>(mat, sf.position, n, wo, ldir, cc);
                                     if (neeContributes<SSS>(be, cc)) {
                                         const float w = neeWeight<SSS>(pdf, be.pdf, cc);
                                         f3 contrib = (emission * be.value) * nDotL;
@@ -1304,7 +1341,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                     }
 
                     // ---- environment NEE (3 random numbers: marginal, conditional, jitter) ----
-                    if (!surfaceDelta && sc.envSampling) {
+                    if (!surfaceDelta && envSampling) {
                         const long long tEnv = partBegin<COUNT>();
                         const float uM = rngNext(rng);
                         const float uC = rngNext(rng);
@@ -1315,7 +1352,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                         const float nDotL = smax(dot(n, edir), 0.0f);
                         if (epdf > 0.0f && nDotL > 0.0f) {
                             const f3 envRadiance = envLookup(sc, edir, rp.envRotation, rp.envIntensity);
-                            const BsdfEvalResult be = evalBsdf<SSS>(mat, sf.position, n, wo, edir, cc);
+                            const BsdfEvalResult be = evalBsdf<SSS, MATS>(mat, sf.position, n, wo, edir, cc);
                             if (neeContributes<SSS>(be, cc)) {
                                 const float w = neeWeight<SSS>(epdf, be.pdf, cc);
                                 f3 contrib = (envRadiance * be.value) * nDotL;
@@ -1358,13 +1395,13 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                         }
                     }
                     if (COUNT) counts.stage[7] += 1u;
-                    if (!SSS || (!haveSample && !walking)) bs = sampleBsdf<SSS>(mat, sf.position, n, wo, incident, sf.frontFace, rng, cc);
+                    if (!SSS || (!haveSample && !walking)) bs = sampleBsdf<SSS, MATS>(mat, sf.position, n, wo, incident, sf.frontFace, rng, cc);
                     if (SSS && walking) {
                         // nothing else this visit: the walk's first boundary query is the slot's next ray
                     } else if (bs.pdf <= 0.0f || dot(bs.dir, bs.dir) <= 0.0f || !finite3(bs.weight)) {
                         endPath = true;
                     } else {
-                        if ((rp.mediaMode & PTR_METAL_MEDIA) && bs.mediumEvent != 0) {
+                        if ((mediaMode & PTR_METAL_MEDIA) && bs.mediumEvent != 0) {
                             // refraction into / out of a dielectric: push its material, or pop (pathtrace.metal:6694-6709)
                             if (bs.mediumEvent > 0) {
                                 const uint32_t at = min(mediumDepth, kMaxMediumStack - 1u);   // a full stack overwrites its top
@@ -1384,7 +1421,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                             // light reached straight along the specular direction
                             const f3 sdir = normalize(bs.dir);
                             const f3 sorg = offsetOrigin(of, sdir);
-                            if (sc.envSampling) {
+                            if (envSampling) {
                                 const float envPdf = smax(envPdfOf(sc, sdir, rp.envRotation), kSpecNeePdfFloor);
                                 const float invEnvPdf = smin(1.0f / envPdf, kSpecNeeInvPdfClamp);
                                 const float bsdfPdf = smax(bs.pdf, kSpecNeePdfFloor);
@@ -1580,8 +1617,8 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
 }
 
 // LISTED: the launch walks pool.busyIn instead of the slots (end of the frame, see PathPool)
-template <bool COUNT, bool SSS, bool TEX, bool LISTED>
-__global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(RenderParams rp, SceneView sc, PathPool pool, ShadeResets resets) {
+template <bool COUNT, bool SSS, bool TEX, bool LISTED, uint32_t MATS = kAllMaterials>
+__global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR_M k_shade(RenderParams rp, SceneView sc, PathPool pool, ShadeResets resets) {
     const uint32_t index = blockIdx.x * kShadeBlock + threadIdx.x;
     if (index == 0u) {
         // k_shade runs between this iteration's k_extend and k_connect: it clears the work heads they will claim from
@@ -1607,9 +1644,9 @@ __global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR k_shade(Rend
             const uint32_t at = lists.position(inRange ? index : 0u, pool.connectRegion);
             slot = inRange ? (pool.busyIn[at] & ~kBusyAliveBit) : 0u;
         }
-        shadeSlot<COUNT, SSS, TEX, kShadeListed>(rp, sc, pool, slot, inRange, drained, index >> 6, counts);
+        shadeSlot<COUNT, SSS, TEX, kShadeListed, MATS>(rp, sc, pool, slot, inRange, drained, index >> 6, counts);
     } else {
-        shadeSlot<COUNT, SSS, TEX, kShadeDense>(rp, sc, pool, index, index < pool.slots, resets.drained != 0u, index >> 6, counts);
+        shadeSlot<COUNT, SSS, TEX, kShadeDense, MATS>(rp, sc, pool, index, index < pool.slots, resets.drained != 0u, index >> 6, counts);
     }
     if (COUNT) {
         addCounter(pool.counters, kCntShadedHits, counts.shadedHit);
@@ -2247,6 +2284,21 @@ void launchExtend(const SceneView& sc, const PathPool& pool, const LaunchConfig&
     }
 }
 
+
+// The k_shade instantiation a render of this scene launches: the smallest compiled set (materials + features) that covers it, or
+// kAllMaterials.  The Metal-semantics instantiations (SSS, TEX) and the counting ones are compiled for every material.
+uint32_t shadeKernelSet(const RenderParams& rp, const SceneView& sc, bool count) {
+    const bool sss = (rp.mediaMode & (PTR_METAL_SSS | PTR_METAL_PBR | PTR_METAL_CLAMPS)) != 0u;
+    if (sss || count || sc.materialTypes == 0u) return kAllMaterials;
+    // (an environment map and the Metal media / face-normal rules are features of the set like a material type is)
+    const uint32_t needs = sc.materialTypes | ((sc.envWidth > 0u || sc.envSampling) ? kFeatureEnvironment : 0u) |
+                           ((rp.mediaMode & (PTR_METAL_MEDIA | PTR_METAL_FACE_NORMAL)) ? kFeatureMedia : 0u);
+    for (uint32_t set : {kDiffuseMaterials, kBasicMaterials, kMetalMaterials, kCarPaintMaterials, kPbrMaterials}) {
+        if ((needs & ~set) == 0u) return set;
+    }
+    return kAllMaterials;
+}
+
 void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, bool count,
                  hipStream_t stream) {
     const bool sss = (rp.mediaMode & (PTR_METAL_SSS | PTR_METAL_PBR | PTR_METAL_CLAMPS)) != 0u;   // the instantiation that carries those Metal-only models
@@ -2254,9 +2306,18 @@ void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& po
     const bool tex = sss && sc.textureCount > 0u;   // the instantiation with the texture lookups and the ray cone
     const uint32_t grid = ceilDiv(pool.slots, kShadeBlock);
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, resets); };
+    const uint32_t set = shadeKernelSet(rp, sc, count);
     auto pick = [&](auto countTag, auto listedTag) {
         constexpr bool C = decltype(countTag)::value, L = decltype(listedTag)::value;
-        if (tex) launch(k_shade<C, true, true, L>); else if (sss) launch(k_shade<C, true, false, L>); else launch(k_shade<C, false, false, L>);
+        if (tex) launch(k_shade<C, true, true, L>);
+        else if (sss) launch(k_shade<C, true, false, L>);
+        else if (C) launch(k_shade<C, false, false, L>);
+        else if (set == kDiffuseMaterials) launch(k_shade<false, false, false, L, kDiffuseMaterials>);
+        else if (set == kBasicMaterials) launch(k_shade<false, false, false, L, kBasicMaterials>);
+        else if (set == kMetalMaterials) launch(k_shade<false, false, false, L, kMetalMaterials>);
+        else if (set == kCarPaintMaterials) launch(k_shade<false, false, false, L, kCarPaintMaterials>);
+        else if (set == kPbrMaterials) launch(k_shade<false, false, false, L, kPbrMaterials>);
+        else launch(k_shade<C, false, false, L>);
     };
     if (count) {
         if (listed) pick(std::true_type{}, std::true_type{}); else pick(std::true_type{}, std::false_type{});

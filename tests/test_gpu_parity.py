@@ -279,6 +279,54 @@ def test_config5_reduced_sss_and_carpaint_meshes():
     _image_parity(host, dev, osc, 160, 90, 12, 1, 32, 0.989)
 
 
+def test_material_set_instantiations_render_what_the_full_kernel_renders(tmp_path):
+    # k_shade is compiled per material / feature set (csrc/kernels/wavefront.hip shadeKernelSet); the counting render always runs
+    # the full kernel, so the two images of one scene must be the same bits whichever set the scene selects
+    from scenes.gen_assets import ensure_large_asset
+    ensure_large_asset("torus_knot_871200.ply")
+    ensure_large_asset("blob_125000.ply")
+    metals = tmp_path / "metals.scene"
+    metals.write_text("""camera target=0,0.6,0 distance=9 yaw=1.2 pitch=0.25 vfov=35
+renderer width=96 height=64 maxDepth=6 seed=1337
+background solid=0.1,0.1,0.15
+material type=lambert albedo=0.8,0.3,0.3 name=lambert
+material type=metal albedo=0.9,0.8,0.5 roughness=0.35 name=rough_metal
+material type=metal albedo=0.95,0.95,0.95 roughness=0.0 name=mirror
+material type=metal eta=0.2,0.9,1.1 k=3.9,2.4,2.2 roughness=0.2 name=gold_like
+material type=dielectric ior=1.5 name=glass
+material type=lambert albedo=0.5,0.5,0.5 name=floor
+material type=diffuse_light emit=9,9,9 name=light
+sphere center=-2.4,0.6,0 radius=0.6 material=0
+sphere center=-1.2,0.6,0 radius=0.6 material=1
+sphere center=0,0.6,0 radius=0.6 material=2
+sphere center=1.2,0.6,0 radius=0.6 material=3
+sphere center=2.4,0.6,0 radius=0.6 material=4
+rectangle x=-8,8 y=0 z=-8,8 normal=1 material=5
+rectangle x=-2,2 y=5 z=-2,2 normal=-1 material=6
+""")
+    D, G, M, CP, P7 = 0b101001, 0b101101, 0b101111, 0b1101101, 0b10101101
+    cases = [(os.path.join(GOLDEN, "cornell_small_mesh.scene"), D, 6), (os.path.join(SCENES, "knot_glass.scene"), G, 12),
+             (str(metals), M, 6), (os.path.join(GOLDEN, "lucy_small.scene"), CP, 8), (os.path.join(SCENES, "helmet_env.scene"), P7 | 0x100, 6),
+             (os.path.join(GOLDEN, "materials.scene"), 0x3FF, 6), (os.path.join(GOLDEN, "env_materials.scene"), 0x3FF, 6)]
+    for path, expected, depth in cases:
+        host = pt.HostScene.load(path, SCENES)
+        dev = pt.DeviceScene(host.desc, 0, keepalive=host)
+        s = host.settings_for(width=160, height=96, max_depth=depth, seed=77)
+        assert dev.shade_kernel_set(s) == expected, (path, bin(dev.shade_kernel_set(s)))
+        assert dev.shade_kernel_set(s, count=True) == 0x3FF
+        lean, _ = dev.render_image(s, 8)
+        full, st = dev.render_image(s, 8, count=True)
+        assert np.array_equal(lean.view(np.uint32), full.view(np.uint32)), path
+        assert st.shadedHits > 0
+        # the Metal medium rules are a feature of the set: with them the scene falls back to a set that has them
+        s2 = host.settings_for(width=64, height=48, max_depth=depth, seed=77, metalSemantics=5)   # PTR_METAL_MEDIA | PTR_METAL_FACE_NORMAL
+        assert dev.shade_kernel_set(s2) == 0x3FF
+        lean2, _ = dev.render_image(s2, 4)
+        full2, _ = dev.render_image(s2, 4, count=True)
+        assert np.array_equal(lean2.view(np.uint32), full2.view(np.uint32)), path
+        dev.close()
+
+
 def test_metal_media_semantics(tmp_path):
     # Metal-only integrator semantics (PtrSettings.metalSemantics): Beer-Lambert media with the 8-deep stack, thin-walled
     # glass, ray-facing glass normals.  Checked against the oracle's restatement of shaders/pathtrace.metal:1187-1191,
