@@ -992,6 +992,83 @@ __device__ __forceinline__ void partEnd(ShadeCounts& counts, uint32_t part, long
     }
 }
 
+// A wave-uniform read of scene data: through the scalar cache into scalar registers (the constant address space is what makes the
+// compiler choose s_load; the scene arrays are not written while a render runs).
+typedef float NativeFloat4 __attribute__((ext_vector_type(4)));
+struct UniformRows {
+    const __attribute__((address_space(4))) NativeFloat4* p;
+    __device__ __forceinline__ float4 operator[](uint32_t i) const {
+        const NativeFloat4 v = p[i];
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+};
+__device__ __forceinline__ UniformRows uniformRows(const float4* p) {
+    return UniformRows{reinterpret_cast<const __attribute__((address_space(4))) NativeFloat4*>(reinterpret_cast<uintptr_t>(p))};
+}
+
+// Rectangle-light next-event estimation at a non-delta hit: picks a light and a point on it, weighs the sample against the BSDF and
+// queues the shadow ray (record 0).  3 random numbers, drawn even if the sample is rejected.  Returns whether a ray was queued.
+// ONE: the scene has a single rectangle light (the pick still draws its random number).
+template <bool COUNT, bool SSS, uint32_t MATS, bool ONE>
+__device__ __forceinline__ bool rectLightNee(const RenderParams& rp, const SceneView& sc, const PathPool& pool, uint32_t slot, const Mat& mat,
+                                             const Surface& sf, const OffsetFrame& of, f3 n, f3 wo, f3 thr, const ClampCfg& cc, uint32_t depth,
+                                             uint32_t& rng, ShadeCounts& counts) {
+    const uint32_t nL = ONE ? 1u : sc.rectLightCount;
+    const uint32_t sel = min(static_cast<uint32_t>(rngNext(rng) * static_cast<float>(nL)), nL - 1u);
+    const float lu = rngNext(rng);
+    const float lv = rngNext(rng);
+    const float4* Lv = sc.rectLights + static_cast<size_t>(sel) * kRectLightVec4;
+    const UniformRows Lu = uniformRows(sc.rectLights);
+    auto row = [&](uint32_t i) { return ONE ? Lu[i] : Lv[i]; };
+    const float4 l0 = row(0), l1 = row(1), l2 = row(2), l3 = row(3);
+    const f3 samplePoint = (mk3(l0) + lu * mk3(l1)) + lv * mk3(l2);
+    const f3 toLight = samplePoint - sf.position;
+    const float distSq = dot(toLight, toLight);
+    if (!(distSq > 0.0f && l0.w > 0.0f)) return false;
+    const float distance = sqrtf(distSq);
+    const f3 ldir = toLight / distance;
+    float cosLight = dot(-ldir, mk3(l3));
+    if (l1.w != 0.0f) cosLight = fabsf(cosLight);
+    if (!(cosLight > 0.0f)) return false;
+    const float pdfArea = 1.0f / l0.w;
+    const float pdfDir = pdfArea * distSq / smax(cosLight, 1.0e-6f);
+    const float pdf = pdfDir * (1.0f / static_cast<float>(nL));
+    const f3 emission = mk3(row(4)) * rp.emissionScale;
+    const float nDotL = smax(dot(n, ldir), 0.0f);
+    if (!(pdf > 0.0f && isfinite(pdf) && (dot(emission, emission) > 0.0f) && nDotL > 0.0f)) return false;
+    if (COUNT) counts.stage[4] += 1u;
+    const BsdfEvalResult be = evalBsdf<SSS, MATS>(mat, sf.position, n, wo, ldir, cc);
+    if (!neeContributes<SSS>(be, cc)) return false;
+    const float w = neeWeight<SSS>(pdf, be.pdf, cc);
+    f3 contrib = (emission * be.value) * nDotL;
+    contrib *= w / pdf;
+    if (!finite3(contrib)) return false;
+    const f3 clamped = clampFirefly(thr, contrib, cc);
+    if (!(clamped.x > 0.0f || clamped.y > 0.0f || clamped.z > 0.0f)) return false;
+    // tfar is measured from the un-offset hit point (reference quirk Q9)
+    // (rp.shadowSlack is a test knob, 0 in every product render: x * 1.0f is x)
+    const float shadowMax = smax(distance * (1.0f - rp.shadowSlack) - kEps, kEps);
+    const f3 shadowOrg = offsetOrigin(of, ldir);
+    // The shadow ray starts off the surface but its length is measured from the surface (quirk Q9), so from any surface that faces the
+    // light's plane it reaches the light's OWN rectangle and is occluded by it - after walking the whole scene on the way.  An any-hit
+    // query is occluded as soon as one primitive is hit: test the light's two triangles first (the same test on the same operands as
+    // the traversal's), and queue a shadow ray only when they do not settle it.  Half of config 2's shadow rays end here.
+    // The light's own two triangles ride in its record (rows 5..10, l3.w says so); they are read here, where few registers are live,
+    // not with the rest of the record.
+    float tt, tu, tv;
+    bool occludedByLight = false;
+    if (COUNT) counts.stage[5] += 1u;
+    if (PTR_LIGHT_PRETEST != 0 && l3.w != 0.0f) {
+        occludedByLight = triangleTest(mk3(row(5)), mk3(row(6)), mk3(row(7)), shadowOrg, ldir, kEps, shadowMax, tt, tu, tv) ||
+                          triangleTest(mk3(row(8)), mk3(row(9)), mk3(row(10)), shadowOrg, ldir, kEps, shadowMax, tt, tu, tv);
+    }
+    if (occludedByLight) return false;
+    // a.w: depth of this vertex, for the path signature of the counting build
+    if (COUNT) counts.stage[6] += 1u;
+    storeRecord(pool, slot, 0u, 0u, shadowOrg, shadowMax, ldir, clamped, static_cast<float>(depth), mk3(0.0f));
+    return true;
+}
+
 // One visit of a path slot: what k_shade does for its thread's slot.  MODE kShadeDense: lane l of wave w holds slot 64 w + l.
 // kShadeListed: the lanes hold the slots of a busy list (end of the frame) - the wave is converged but its slots are arbitrary, so
 // work items are claimed lane by lane.  kShadeTail: the caller is the end-of-frame kernel (k_tail_run), whose lanes hold arbitrary
@@ -1277,66 +1354,11 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                     // ---- rectangle-light NEE (3 random numbers, drawn even if the sample is rejected) ----
                     if (!surfaceDelta && sc.rectLightCount > 0u) {
                         const long long tLight = partBegin<COUNT>();
-                        const uint32_t nL = sc.rectLightCount;
-                        const uint32_t sel = min(static_cast<uint32_t>(rngNext(rng) * static_cast<float>(nL)), nL - 1u);
-                        const float lu = rngNext(rng);
-                        const float lv = rngNext(rng);
-                        const float4* L = sc.rectLights + static_cast<size_t>(sel) * kRectLightVec4;
-                        const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3];
-                        const f3 samplePoint = (mk3(l0) + lu * mk3(l1)) + lv * mk3(l2);
-                        const f3 toLight = samplePoint - sf.position;
-                        const float distSq = dot(toLight, toLight);
-                        if (distSq > 0.0f && l0.w > 0.0f) {
-                            const float distance = sqrtf(distSq);
-                            const f3 ldir = toLight / distance;
-                            float cosLight = dot(-ldir, mk3(l3));
-                            if (l1.w != 0.0f) cosLight = fabsf(cosLight);
-                            if (cosLight > 0.0f) {
-                                const float pdfArea = 1.0f / l0.w;
-                                const float pdfDir = pdfArea * distSq / smax(cosLight, 1.0e-6f);
-                                const float pdf = pdfDir * (1.0f / static_cast<float>(nL));
-                                const f3 emission = mk3(L[4]) * rp.emissionScale;
-                                const float nDotL = smax(dot(n, ldir), 0.0f);
-                                if (pdf > 0.0f && isfinite(pdf) && (dot(emission, emission) > 0.0f) && nDotL > 0.0f) {
-                                    if (COUNT) counts.stage[4] += 1u;
-                                    const BsdfEvalResult be = evalBsdf<SSS, MATS>(mat, sf.position, n, wo, ldir, cc);
-                                    if (neeContributes<SSS>(be, cc)) {
-                                        const float w = neeWeight<SSS>(pdf, be.pdf, cc);
-                                        f3 contrib = (emission * be.value) * nDotL;
-                                        contrib *= w / pdf;
-                                        if (finite3(contrib)) {
-                                            const f3 clamped = clampFirefly(thr, contrib, cc);
-                                            if (clamped.x > 0.0f || clamped.y > 0.0f || clamped.z > 0.0f) {
-                                                // tfar is measured from the un-offset hit point (reference quirk Q9)
-                                                // (rp.shadowSlack is a test knob, 0 in every product render: x * 1.0f is x)
-                                                const float shadowMax = smax(distance * (1.0f - rp.shadowSlack) - kEps, kEps);
-                                                const f3 shadowOrg = offsetOrigin(of, ldir);
-                                                // The shadow ray starts off the surface but its length is measured from the surface (quirk Q9), so from
-                                                // any surface that faces the light's plane it reaches the light's OWN rectangle and is occluded by it -
-                                                // after walking the whole scene on the way.  An any-hit query is occluded as soon as one primitive is
-                                                // hit: test the light's two triangles first (the same test on the same operands as the traversal's),
-                                                // and queue a shadow ray only when they do not settle it.  Half of config 2's shadow rays end here.
-                                                // The light's own two triangles ride in its record (rows 5..10, l3.w says so); they are read here, where few
-                                                // registers are live, not with the rest of the record.
-                                                float tt, tu, tv;
-                                                bool occludedByLight = false;
-                                                if (COUNT) counts.stage[5] += 1u;
-                                                if (PTR_LIGHT_PRETEST != 0 && l3.w != 0.0f) {
-                                                    occludedByLight = triangleTest(mk3(L[5]), mk3(L[6]), mk3(L[7]), shadowOrg, ldir, kEps, shadowMax, tt, tu, tv) ||
-                                                                      triangleTest(mk3(L[8]), mk3(L[9]), mk3(L[10]), shadowOrg, ldir, kEps, shadowMax, tt, tu, tv);
-                                                }
-                                                if (!occludedByLight) {
-                                                    // a.w: depth of this vertex, for the path signature of the counting build
-                                                    if (COUNT) counts.stage[6] += 1u;
-                                                    storeRecord(pool, slot, 0u, 0u, shadowOrg, shadowMax, ldir, clamped, static_cast<float>(depth), mk3(0.0f));
-                                                    want[0] = true;
-                                                }
-                                            }
-                                        }
-                                    }
-                                }
-                            }
-                        }
+                        // one light (every Cornell-type scene): its record is the same for the whole wave and comes through scalar loads
+                        const bool queued = sc.rectLightCount == 1u
+                                                ? rectLightNee<COUNT, SSS, MATS, true>(rp, sc, pool, slot, mat, sf, of, n, wo, thr, cc, depth, rng, counts)
+                                                : rectLightNee<COUNT, SSS, MATS, false>(rp, sc, pool, slot, mat, sf, of, n, wo, thr, cc, depth, rng, counts);
+                        if (queued) want[0] = true;
                         partEnd<COUNT>(counts, kShadePartLightNee, tLight);
                     }
 
