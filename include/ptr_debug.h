@@ -42,6 +42,9 @@ int ptr_debug_texture_sample(PtrDeviceScene* scene, uint32_t texture, const floa
  * shading normal xyz, front face (1/0), next origin xyz, 0}. */
 int ptr_debug_surface_hits(PtrDeviceScene* scene, const float* in, uint64_t n, float* out, char* err, size_t err_cap);
 
+/* The kernels' exact division by a per-render divisor (csrc/kernels/device_types.h DivU32), evaluated on the host: out[i] = n[i] / d. */
+int ptr_debug_exact_division(uint32_t d, const uint32_t* n, uint64_t count, uint32_t* out);
+
 /* Which k_shade instantiation a render of `scene` with `settings` launches: bit t (0..7) = material type t compiled in, bit 8 = the
  * environment map, bit 9 = the Metal medium stack / face-normal rule; 0x3FF = the full kernel.  (The product picks the smallest
  * compiled set that covers the scene: the tests check that every set renders what the full kernel renders.) */

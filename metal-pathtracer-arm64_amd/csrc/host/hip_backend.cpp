@@ -543,6 +543,7 @@ void fillRenderParams(const PtrSettings& s, uint32_t spp, RenderParams& rp) {
     std::memset(&rp, 0, sizeof(rp));
     buildCamera(s, rp.cam);
     rp.width = s.width;
+    rp.byWidth = makeDivU32(s.width);
     rp.height = s.height;
     rp.maxDepth = std::min(s.maxDepth, kFlagFieldMask);
     rp.shadowSlack = (s.debugShadowSlack > 0.0f && s.debugShadowSlack < 1.0f) ? s.debugShadowSlack : 0.0f;
@@ -656,6 +657,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
     // cost 12 % on config 2 - so a frame whose per-sample accumulators do not fit is rendered in passes instead, see
     // renderBands.)
     rp.localPixels = localPixels;
+    rp.byLocalPixels = makeDivU32(localPixels);
     const uint64_t itemCount64 = static_cast<uint64_t>(localPixels) * rp.spp;
     if (itemCount64 > 0xFFFF0000ull) throw HipError{"too many work items for one pass (reduce spp or resolution)"};
     rp.itemCount = static_cast<uint32_t>(itemCount64);
@@ -1576,6 +1578,13 @@ int ptr_debug_surface_hits(PtrDeviceScene* scene, const float* in, uint64_t n, f
         return 0;
     }
     PTR_CATCH_ALL(err, err_cap)
+}
+
+int ptr_debug_exact_division(uint32_t d, const uint32_t* n, uint64_t count, uint32_t* out) {
+    if (d == 0u || (!n && count) || (!out && count)) return 1;
+    const DivU32 by = makeDivU32(d);
+    for (uint64_t i = 0; i < count; ++i) out[i] = by.quotient(n[i]);
+    return 0;
 }
 
 int ptr_debug_shade_kernel_set(const PtrDeviceScene* scene, const PtrSettings* settings, int count, uint32_t* out) {

@@ -103,6 +103,31 @@ struct CameraParams {
     float lensRadius;
 };
 
+// Exact n / d for a divisor fixed per render (Granlund & Montgomery, "Division by invariant integers using multiplication", fig. 4.1,
+// N = 32): the two divisors of a camera ray - item -> (sample, local pixel) and pixel -> (x, y) - cost the generic 32-bit division's
+// ~30 VALU instructions each in every k_shade visit; this is five.
+struct DivU32 {
+    uint32_t d, magic, shift1, shift2;
+    __host__ __device__ __forceinline__ uint32_t quotient(uint32_t n) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t t = __umulhi(magic, n);
+#else
+        const uint32_t t = static_cast<uint32_t>((static_cast<uint64_t>(magic) * n) >> 32);
+#endif
+        return (t + ((n - t) >> shift1)) >> shift2;
+    }
+};
+inline DivU32 makeDivU32(uint32_t d) {
+    DivU32 r{d, 0u, 0u, 0u};
+    if (d == 0u) return r;   // (never divided by: a render without pixels returns before any launch)
+    uint32_t l = 0u;         // ceil(log2 d)
+    while (l < 32u && (1ull << l) < d) ++l;
+    r.magic = static_cast<uint32_t>(((1ull << 32) * ((1ull << l) - d)) / d + 1ull);
+    r.shift1 = l < 1u ? l : 1u;
+    r.shift2 = l > 1u ? l - 1u : 0u;
+    return r;
+}
+
 struct RenderParams {
     CameraParams cam;
     uint32_t width, height;
@@ -114,6 +139,7 @@ struct RenderParams {
     uint32_t passFlags;            // bit 0: first pass (the output is overwritten), bit 1: last pass (divide by sppTotal)
     uint32_t itemCount;            // localPixels * spp; work item w = sample * localPixels + localPixel (one sample each)
     uint32_t localPixels;          // pixels owned by this partition
+    DivU32 byWidth, byLocalPixels; // width and localPixels as divisors
     uint32_t mediaMode;            // PTR_METAL_* bits (0 = Embree-parity integrator)
     uint32_t sssMode;              // RenderSettings::SssMode, read only with PTR_METAL_SSS
     uint32_t sssMaxSteps;          // closest-hit queries per random walk (>= 1)

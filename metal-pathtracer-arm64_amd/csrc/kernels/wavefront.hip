@@ -242,7 +242,13 @@ __device__ __forceinline__ void cameraRay(const RenderParams& rp, uint32_t x, ui
 // Start sample `s` of the slot's pixel: seed, primary ray, fresh path state.
 __device__ __forceinline__ void beginSample(const RenderParams& rp, uint32_t pixel, uint32_t s, uint32_t& rng, f3& org, f3& dir) {
     rng = rngHash(rp.seedBase ^ pixel ^ ((rp.sampleBase + s) * 0x9e3779b9u));
-    cameraRay(rp, pixel % rp.width, pixel / rp.width, rng, org, dir);
+    const uint32_t y = rp.byWidth.quotient(pixel);
+    cameraRay(rp, pixel - y * rp.width, y, rng, org, dir);
+}
+// ... of work item `item` (= sample * localPixels + local pixel)
+__device__ __forceinline__ void beginItem(const RenderParams& rp, const PathPool& pool, uint32_t item, uint32_t& rng, f3& org, f3& dir) {
+    const uint32_t s = rp.byLocalPixels.quotient(item);
+    beginSample(rp, pool.pixelOfLocal[item - s * rp.localPixels], s, rng, org, dir);
 }
 
 // make_primary_ray_cone (shaders/pathtrace.metal:141-152): the cone a textured scene's paths start with
@@ -590,7 +596,7 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams rp, PathPool pool
     uint32_t flags = 0u, rng = 0u;
     f3 o = mk3(0.0f), d = mk3(0.0f);
     if (slot < rp.itemCount && rp.maxDepth > 0u) {
-        beginSample(rp, pool.pixelOfLocal[slot % rp.localPixels], slot / rp.localPixels, rng, o, d);
+        beginItem(rp, pool, slot, rng, o, d);
         flags = kFlagAlive | kFlagLastDelta;
     }
     pool.ray0[slot] = mk4(o, d.x);
@@ -869,14 +875,12 @@ __device__ __forceinline__ bool applyPbrTextures(const SceneView& sc, const Surf
 // =====================================================================================================
 // k_shade
 // =====================================================================================================
-// 4 waves/SIMD (<= 128 VGPRs, no spills).  Round 1 ran it at 5 waves / 96 VGPRs with ~230 spilled registers in cold branches; with
-// the slot body shared with the end-of-frame kernel the allocation at 96 spilled into the hot path (k_shade 372 -> 468 ms per
-// frame), and measured on one box: 4 waves 1664, 5 waves 1570, 6 waves 1374 Msamples/s (profiles/r2_ab_shade_waves.txt).
+// The full kernel runs at 4 waves/SIMD (<= 128 VGPRs).  Round 1 ran it at 5 waves / 96 VGPRs with ~230 spilled registers in cold
+// branches; with the slot body shared with the end-of-frame kernel the allocation at 96 spilled into the hot path (k_shade 372 -> 468 ms
+// per frame), and measured on one box: 4 waves 1664, 5 waves 1570, 6 waves 1374 Msamples/s (profiles/r2_ab_shade_waves.txt).
 #ifndef PTR_SHADE_WAVES
 #define PTR_SHADE_WAVES 4
 #endif
-// (the instantiation with the Metal-only subsurface / PBR models runs at 4 waves too)
-#define PTR_SHADE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SSS ? 4 : PTR_SHADE_WAVES, SSS ? 4 : PTR_SHADE_WAVES)))
 // Instantiations by material set.  The full kernel carries the registers of its heaviest branch (car paint, plastic, the metallic-
 // roughness model) for every scene: 128 VGPRs with 29 spilled, 4 waves per SIMD.  A scene's materials are known at upload
 // (SceneView::materialTypes), so launchShade picks the smallest compiled set that covers them; the lean sets need 94-96 registers
@@ -887,6 +891,13 @@ constexpr uint32_t kBasicMaterials = kDiffuseMaterials | (1u << 2);             
 constexpr uint32_t kMetalMaterials = kBasicMaterials | (1u << 1);                         // ... and metals
 constexpr uint32_t kCarPaintMaterials = kBasicMaterials | (1u << 6);                      // car paint (+ the basic ones)
 constexpr uint32_t kPbrMaterials = kBasicMaterials | (1u << 7) | kFeatureEnvironment;     // glTF: metallic-roughness under an environment map
+// The light-connection records (device_types.h kRecSlots) a set's scenes can queue: 0 always; 1 needs an environment map; 2 and 3 a
+// material that samples delta directions (smooth metal, glass, the metallic-roughness model), 2 the environment as well; 4 glass.
+constexpr uint32_t shadeRecords(uint32_t mats) {
+    const bool env = (mats & kFeatureEnvironment) != 0u;
+    const bool delta = (mats & ((1u << 1) | (1u << 2) | (1u << 7))) != 0u;
+    return 1u | (env ? 2u : 0u) | ((env && delta) ? 4u : 0u) | (delta ? 8u : 0u) | ((mats & (1u << 2)) ? 16u : 0u);
+}
 // waves per SIMD of each set's instantiation (512 / waves = its register budget)
 #ifndef PTR_SHADE_WAVES_DIFFUSE
 #define PTR_SHADE_WAVES_DIFFUSE 5
@@ -900,14 +911,22 @@ constexpr uint32_t kPbrMaterials = kBasicMaterials | (1u << 7) | kFeatureEnviron
 #ifndef PTR_SHADE_WAVES_PBR
 #define PTR_SHADE_WAVES_PBR 5
 #endif
-constexpr int shadeWaves(bool sss, uint32_t mats) {
-    return mats == kDiffuseMaterials ? PTR_SHADE_WAVES_DIFFUSE
-           : mats == kBasicMaterials ? PTR_SHADE_WAVES_BASIC
-           : mats == kMetalMaterials ? PTR_SHADE_WAVES_METAL
-           : mats == kPbrMaterials   ? PTR_SHADE_WAVES_PBR
-                                     : (sss ? 4 : PTR_SHADE_WAVES);
+// the instantiations with the Metal-only subsurface / PBR models (and textures) need 161-171 registers: at 4 waves they spilled ~150
+// (3 waves: +20 % on the Metal variants of configs 3 and 4, +8 % on config 5's; 2 waves: as slow as 4; profiles/r3_ab_metal_waves.txt)
+#ifndef PTR_SHADE_WAVES_SSS
+#define PTR_SHADE_WAVES_SSS 3
+#endif
+// (the counting build - stage counters, per-part clocks, path signatures - gets 256 registers: it is a diagnostic, and with its extra
+// state at 128 the allocator spilled around divergent regions)
+constexpr int shadeWaves(bool count, bool sss, uint32_t mats) {
+    return count ? 2
+           : mats == kDiffuseMaterials ? PTR_SHADE_WAVES_DIFFUSE
+           : mats == kBasicMaterials   ? PTR_SHADE_WAVES_BASIC
+           : mats == kMetalMaterials   ? PTR_SHADE_WAVES_METAL
+           : mats == kPbrMaterials     ? PTR_SHADE_WAVES_PBR
+                                       : (sss ? PTR_SHADE_WAVES_SSS : PTR_SHADE_WAVES);
 }
-#define PTR_SHADE_WAVES_ATTR_M __attribute__((amdgpu_waves_per_eu(shadeWaves(SSS, MATS), shadeWaves(SSS, MATS))))
+#define PTR_SHADE_WAVES_ATTR_M __attribute__((amdgpu_waves_per_eu(shadeWaves(COUNT, SSS, MATS), shadeWaves(COUNT, SSS, MATS))))
 // Work items for the lanes of a converged wave whose lane l holds slot 64 w + l (dense k_shade).
 // Each wave holds a reservation of kItemReserve consecutive items in HBM and refills it with ONE atomic on one of kItemHeads range
 // heads (a per-lane or even per-wave-per-bounce atomic on one address caps at ~88 ops/us chip-wide; so does one shared head once
@@ -1103,14 +1122,22 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
     const float4 acc4 = pool.accum[at];
     const uint32_t flagsIn = inRange ? __float_as_uint(ray1v.w) : 0u;
     const uint32_t pendingIn = (flagsIn >> kFlagPendingShift) & kFlagPendingMask;
+    // (the records the instantiation's scenes never queue are not read: kRecords)
+    constexpr uint32_t kRecords = SSS ? 0x1Fu : shadeRecords(MATS);
     float4 landed[kRecSlots];
 #pragma unroll
     for (uint32_t k = 0; k < kRecSlots; ++k) {
-        const float4* src = (pendingIn & (1u << k)) ? pool.rec[k].a + at : pool.zero;
-        landed[k] = *src;
+        landed[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (kRecords & (1u << k)) {
+            const float4* src = (pendingIn & (1u << k)) ? pool.rec[k].a + at : pool.zero;
+            landed[k] = *src;
+        }
     }
-    asm volatile("" ::"v"(acc4.x), "v"(ray0v.x), "v"(hitv.x), "v"(thr4.x), "v"(landed[0].x), "v"(landed[1].x), "v"(landed[2].x),
-                 "v"(landed[3].x), "v"(landed[4].x));   // keep the loads here: the compiler would sink each one next to its use
+    asm volatile("" ::"v"(acc4.x), "v"(ray0v.x), "v"(hitv.x), "v"(thr4.x));   // keep the loads here: the compiler would sink each one next to its use
+#pragma unroll
+    for (uint32_t k = 0; k < kRecSlots; ++k) {
+        if (kRecords & (1u << k)) asm volatile("" ::"v"(landed[k].x));
+    }
     const bool active = inRange && (flagsIn & kFlagAlive);
     const bool touched = inRange && (active || pendingIn != 0u || (flagsIn & kFlagFlush));   // state/accum rewritten
     if (COUNT) {
@@ -1142,7 +1169,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
         // light connections queued last bounce have been resolved by k_connect: add them in slot order
 #pragma unroll
         for (uint32_t k = 0; k < kRecSlots; ++k) {
-            if (pendingIn & (1u << k)) acc += mk3(landed[k]);
+            if ((kRecords & (1u << k)) && (pendingIn & (1u << k))) acc += mk3(landed[k]);
         }
         if (COUNT && pool.signature) {
             sig = pool.signature[slot];
@@ -1564,7 +1591,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                 const uint32_t got = atomicAdd(&res->x, 1u);
                 if (got < end && got < rp.itemCount) {
                     item = got;
-                    beginSample(rp, pool.pixelOfLocal[got % rp.localPixels], got / rp.localPixels, rng, nextO, nextD);
+                    beginItem(rp, pool, got, rng, nextO, nextD);
                     stillAlive = true;
                     newSample = true;
                 }
@@ -1574,7 +1601,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
         const uint32_t claimed = claimItems(rp, pool, slot, needItem, reservation);
         if (needItem && claimed < rp.itemCount) {
             item = claimed;
-            beginSample(rp, pool.pixelOfLocal[claimed % rp.localPixels], claimed / rp.localPixels, rng, nextO, nextD);
+            beginItem(rp, pool, claimed, rng, nextO, nextD);
             stillAlive = true;
             newSample = true;
         }

@@ -53,6 +53,26 @@ def test_device_path_fails_loudly_without_gpu():
     assert rc != 0 and b"no CPU fallback" in err.value and not out.any()
 
 
+def test_division_by_a_render_constant_is_exact():
+    # csrc/kernels/device_types.h DivU32 (item -> sample / local pixel, pixel -> x / y in the kernels): same quotient as n // d for
+    # every divisor class (1, powers of two, 2^k +- 1, image widths, 2^32 - 1) at the ends of the range and at multiples +- 1
+    import ctypes as C
+    lib = pt.load_library()
+    lib.ptr_debug_exact_division.argtypes = [C.c_uint32, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32)]
+    rng = np.random.default_rng(3)
+    divisors = [1, 2, 3, 5, 7, 64, 641, 1920, 1080, 3840, 2073600, 8294400, 65535, 65536, 65537, 2**31 - 1, 2**31, 2**31 + 1, 2**32 - 1]
+    divisors += [int(v) for v in rng.integers(1, 2**32, 40)] + [int(v) for v in rng.integers(1, 5000, 40)]
+    for d in divisors:
+        n = np.concatenate([np.array([0, 1, d - 1, d, min(d + 1, 2**32 - 1), 2**32 - 1, 2**32 - 2, 2**31, 2**31 - 1], dtype=np.uint64),
+                            rng.integers(0, 2**32, 4000, dtype=np.uint64),
+                            np.clip(rng.integers(0, max(2**32 // d, 1) + 1, 2000, dtype=np.uint64) * d + rng.integers(0, 3, 2000, dtype=np.uint64) - 1, 0, 2**32 - 1)])
+        n32 = np.ascontiguousarray(n.astype(np.uint32))
+        out = np.zeros(n32.shape[0], dtype=np.uint32)
+        assert lib.ptr_debug_exact_division(d, n32.ctypes.data_as(C.POINTER(C.c_uint32)), n32.shape[0], out.ctypes.data_as(C.POINTER(C.c_uint32))) == 0
+        assert np.array_equal(out.astype(np.uint64), n32.astype(np.uint64) // d), d
+    assert lib.ptr_debug_exact_division(0, None, 0, None) == 1
+
+
 def test_band_partition_counts():
     src = open(os.path.join(ROOT, "include", "ptr_abi.h")).read()
     assert "#define PTR_BAND_ROWS %du" % pt.BAND_ROWS in src
