@@ -42,6 +42,11 @@ int ptr_debug_texture_sample(PtrDeviceScene* scene, uint32_t texture, const floa
  * shading normal xyz, front face (1/0), next origin xyz, 0}. */
 int ptr_debug_surface_hits(PtrDeviceScene* scene, const float* in, uint64_t n, float* out, char* err, size_t err_cap);
 
+/* Host-side count of what a closest-hit walk of the scene's BVH costs with 1, 2 or 3 binary levels collapsed per step (2-, 4-, 8-wide nodes,
+ * children in order of entry distance): rays n x 8 {origin, tmin, direction, tmax}; out = {node steps, box tests, primitive tests, rays that
+ * hit}.  No GPU involved. */
+int ptr_debug_walk_counts(const PtrSceneDesc* scene, const float* rays, uint64_t n, uint32_t levels, uint64_t out[4], char* err, size_t err_cap);
+
 /* The kernels' exact division by a per-render divisor (csrc/kernels/device_types.h DivU32), evaluated on the host: out[i] = n[i] / d. */
 int ptr_debug_exact_division(uint32_t d, const uint32_t* n, uint64_t count, uint32_t* out);
 

@@ -218,7 +218,7 @@ ABI_SYMBOLS = (
 # include/ptr_debug.h (test-only device-function probes)
 DEBUG_SYMBOLS = ("ptr_debug_eval_bsdf", "ptr_debug_sample_bsdf", "ptr_debug_camera_rays", "ptr_debug_env_distribution",
                  "ptr_debug_scene_geometry", "ptr_debug_render_signatures", "ptr_debug_render_multi_on", "ptr_debug_texture_sample",
-                 "ptr_debug_generate_tangents", "ptr_debug_surface_hits", "ptr_debug_shade_kernel_set", "ptr_debug_exact_division")
+                 "ptr_debug_generate_tangents", "ptr_debug_surface_hits", "ptr_debug_shade_kernel_set", "ptr_debug_exact_division", "ptr_debug_walk_counts")
 
 _lib: Optional[C.CDLL] = None
 

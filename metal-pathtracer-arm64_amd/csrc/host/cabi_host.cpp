@@ -1,11 +1,13 @@
 // Host-side (no GPU) entry points of the C-ABI: scene loading and image output.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <exception>
 #include <filesystem>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "env_importance_sampler.h"
 #include "headless.h"
@@ -14,6 +16,7 @@
 #include "ptr_abi.h"
 #include "ptr_debug.h"
 #include "scene_geometry.h"
+#include "bvh_layout.h"
 #include "tangent_space.h"
 #include "scene_manager.h"
 
@@ -263,6 +266,128 @@ int ptr_debug_scene_geometry(const PtrSceneDesc* scene, uint32_t leaf_max, uint6
                                    ((geo.bvh.nodeCount > 0 && maxCell * 8.0f <= geo.bvh.meanPrimExtent) ? 1u : 0u) | (c.oversize << 8) |
                                        (std::min<uint64_t>(c.wideNodes, 0xFFFFFFFFull) << 16) | (c.wideProblems ? 1ull << 63 : 0ull)};
         std::memcpy(out, vals, sizeof(vals));
+        return 0;
+    });
+}
+
+// Host-side walk of the scene's BVH with 1, 2 or 3 binary levels collapsed per step (two-, four-, eight-wide nodes the way
+// BuildWideNodes collapses them: a child that is a leaf keeps its place), children visited in order of entry distance: how many node
+// steps, box tests and primitive tests a closest-hit query costs at each width.  Counts only - the product walks four-wide nodes on
+// the device; this is the measurement behind DESIGN.md section 4.3c.
+int ptr_debug_walk_counts(const PtrSceneDesc* scene, const float* rays, uint64_t n, uint32_t levels, uint64_t out[4], char* err, size_t err_cap) {
+    return guarded(err, err_cap, [&]() -> int {
+        if (!scene || (!rays && n) || !out || levels < 1u || levels > 3u) {
+            setErr(err, err_cap, "ptr_debug_walk_counts: bad argument");
+            return 1;
+        }
+        ptr::SceneGeometry geo;
+        std::string error;
+        if (!ptr::BuildSceneGeometry(*scene, 0, geo, error)) {
+            setErr(err, err_cap, error);
+            return 1;
+        }
+        const ptr::FlatBvh& bvh = geo.bvh;
+        auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+        struct Child { const float* lo; const float* hi; uint32_t ref; };
+        uint64_t steps = 0, boxes = 0, prims = 0, hits = 0;
+        std::vector<uint32_t> stack;
+        for (uint64_t r = 0; r < n; ++r) {
+            const float* q = rays + r * 8;
+            const double o[3] = {q[0], q[1], q[2]}, d[3] = {q[4], q[5], q[6]};
+            const double tmin = q[3];
+            double tfar = q[7];
+            bool hit = false;
+            double inv[3];
+            for (int a = 0; a < 3; ++a) inv[a] = 1.0 / (d[a] != 0.0 ? d[a] : 1e-300);
+            auto testLeaf = [&](uint32_t ref) {
+                const uint32_t first = ref & ptrk::kRefOffsetMask, count = ((ref >> ptrk::kRefCountShift) & 0xFu) % ptrk::kMaxLeafPrims + 1u;
+                for (uint32_t k = 0; k < count; ++k) {
+                    ++prims;
+                    if (ref & ptrk::kRefSphereBit) {
+                        const float* sp = &geo.sphereData[static_cast<size_t>(first + k) * 4];
+                        double c[3], dd = 0, b = 0, cc = 0;
+                        for (int a = 0; a < 3; ++a) { c[a] = sp[a] - o[a]; dd += d[a] * d[a]; b += c[a] * d[a]; cc += c[a] * c[a]; }
+                        const double disc = b * b - dd * (cc - static_cast<double>(sp[3]) * sp[3]);
+                        if (disc < 0) continue;
+                        const double sq = std::sqrt(disc);
+                        double t = (b - sq) / dd;
+                        if (t < tmin) t = (b + sq) / dd;
+                        if (t >= tmin && t <= tfar) { tfar = t; hit = true; }
+                    } else {
+                        const float* t3 = &geo.triData[static_cast<size_t>(first + k) * 12];
+                        const double v0[3] = {t3[0], t3[1], t3[2]}, e1[3] = {t3[4], t3[5], t3[6]}, e2[3] = {t3[8], t3[9], t3[10]};   // e1 = v0 - v1, e2 = v2 - v0
+                        const double ng[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]};
+                        const double c[3] = {v0[0] - o[0], v0[1] - o[1], v0[2] - o[2]};
+                        const double rr[3] = {c[1] * d[2] - c[2] * d[1], c[2] * d[0] - c[0] * d[2], c[0] * d[1] - c[1] * d[0]};
+                        const double den = ng[0] * d[0] + ng[1] * d[1] + ng[2] * d[2];
+                        if (den == 0.0) continue;
+                        const double sgn = den < 0 ? -1.0 : 1.0, ad = std::fabs(den);
+                        const double U = (rr[0] * e2[0] + rr[1] * e2[1] + rr[2] * e2[2]) * sgn, V = (rr[0] * e1[0] + rr[1] * e1[1] + rr[2] * e1[2]) * sgn;
+                        if (U < 0 || V < 0 || U + V > ad) continue;
+                        const double T = (ng[0] * c[0] + ng[1] * c[1] + ng[2] * c[2]) * sgn;
+                        if (!(ad * tmin < T && T <= ad * tfar)) continue;
+                        tfar = T / ad;
+                        hit = true;
+                    }
+                }
+            };
+            stack.clear();
+            if (bvh.oversizeRef != ptrk::kRefEmpty) testLeaf(bvh.oversizeRef);
+            if (bvh.rootRef != ptrk::kRefEmpty) stack.push_back(bvh.rootRef);
+            while (!stack.empty()) {
+                const uint32_t ref = stack.back();
+                stack.pop_back();
+                if (ref & ptrk::kRefLeafBit) {
+                    testLeaf(ref);
+                    continue;
+                }
+                ++steps;
+                Child kids[8];
+                uint32_t kn = 0;
+                auto children = [&](uint32_t node, Child* dst) {
+                    const float* nd = &bvh.nodes[static_cast<size_t>(node) * 16];
+                    uint32_t c = 0;
+                    for (int sl = 0; sl < 2; ++sl) {
+                        const uint32_t cref = bits(nd[sl == 0 ? 3 : 7]);
+                        if (cref != ptrk::kRefEmpty) dst[c++] = Child{nd + sl * 8, nd + sl * 8 + 4, cref};
+                    }
+                    return c;
+                };
+                kn = children(ref, kids);
+                for (uint32_t l = 1; l < levels; ++l) {   // replace every internal child by its own children
+                    Child next[8];
+                    uint32_t nn = 0;
+                    for (uint32_t k = 0; k < kn; ++k) {
+                        if (kids[k].ref & ptrk::kRefLeafBit) next[nn++] = kids[k];
+                        else nn += children(kids[k].ref, next + nn);
+                    }
+                    std::memcpy(kids, next, sizeof(Child) * nn);
+                    kn = nn;
+                }
+                double entry[8];
+                uint32_t order[8], on = 0;
+                for (uint32_t k = 0; k < kn; ++k) {
+                    ++boxes;
+                    double t0 = tmin, t1 = tfar;
+                    for (int a = 0; a < 3; ++a) {
+                        const double ta = (kids[k].lo[a] - o[a]) * inv[a], tb = (kids[k].hi[a] - o[a]) * inv[a];
+                        t0 = std::max(t0, std::min(ta, tb));
+                        t1 = std::min(t1, std::max(ta, tb));
+                    }
+                    if (t0 <= t1) {
+                        entry[k] = t0;
+                        order[on++] = k;
+                    }
+                }
+                std::sort(order, order + on, [&](uint32_t a, uint32_t b) { return entry[a] > entry[b]; });   // far first: the nearest is popped next
+                for (uint32_t k = 0; k < on; ++k) stack.push_back(kids[order[k]].ref);
+            }
+            hits += hit ? 1u : 0u;
+        }
+        out[0] = steps;
+        out[1] = boxes;
+        out[2] = prims;
+        out[3] = hits;
         return 0;
     });
 }

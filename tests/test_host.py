@@ -73,6 +73,34 @@ def test_division_by_a_render_constant_is_exact():
     assert lib.ptr_debug_exact_division(0, None, 0, None) == 1
 
 
+def test_walk_counts_of_collapsed_levels(tmp_path):
+    # ptr_debug_walk_counts (host only): the same rays hit the same things whatever the node width; a wider node takes
+    # fewer steps and never fewer box tests than the binary walk
+    from scenes.gen_assets import ensure_assets
+    ensure_assets()
+    scenes = os.path.join(ROOT, "scenes")
+    host = pt.HostScene.load(os.path.join(scenes, "cornell_mesh.scene"), scenes)
+    lib = pt.load_library()
+    lib.ptr_debug_walk_counts.argtypes = [C.POINTER(pt.PtrSceneDesc), C.POINTER(C.c_float), C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+    rng = np.random.default_rng(2)
+    n = 4000
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.ascontiguousarray(np.concatenate([rng.uniform(50, 500, (n, 3)), np.full((n, 1), 1e-3), d, np.full((n, 1), np.inf)], axis=1).astype(np.float32))
+    res = []
+    for levels in (1, 2, 3):
+        out = (C.c_uint64 * 4)()
+        err = C.create_string_buffer(256)
+        assert lib.ptr_debug_walk_counts(C.byref(host.desc), rays.ctypes.data_as(C.POINTER(C.c_float)), n, levels, out, err, len(err)) == 0, err.value
+        res.append([int(v) for v in out])
+    assert res[0][3] == res[1][3] == res[2][3] > 0.4 * n          # the same rays hit
+    assert res[0][0] > res[1][0] > res[2][0]                      # fewer steps per level collapsed
+    assert res[0][1] == 2 * res[0][0]                             # a binary step tests its two boxes
+    assert res[2][1] > res[1][1] >= 0.95 * res[0][1]              # the third level costs box tests
+    err = C.create_string_buffer(256)
+    assert lib.ptr_debug_walk_counts(C.byref(host.desc), None, 0, 4, (C.c_uint64 * 4)(), err, len(err)) == 1
+
+
 def test_band_partition_counts():
     src = open(os.path.join(ROOT, "include", "ptr_abi.h")).read()
     assert "#define PTR_BAND_ROWS %du" % pt.BAND_ROWS in src
