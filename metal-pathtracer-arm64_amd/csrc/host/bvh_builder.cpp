@@ -903,7 +903,12 @@ uint32_t BuildWideNodes(const FlatBvh& bvh, bool compact, std::unique_ptr<uint32
                 }
             }
             for (; filled < 4u; ++filled) {
-                for (uint32_t k = 0; k < 4u; ++k) w[4u * filled + k] = ptrk::kRefEmpty;
+                // an unused place holds an inverted box (lo = 65535, hi = 0 on every axis): the wide step's ordered slab test (near plane
+                // by the sign of the direction) can never pass it, so the step needs no test of the reference
+                w[4u * filled + 0u] = 0xFFFFFFFFu;
+                w[4u * filled + 1u] = 0x0000FFFFu;
+                w[4u * filled + 2u] = 0x00000000u;
+                w[4u * filled + 3u] = ptrk::kRefEmpty;
             }
         }
     };

@@ -8,7 +8,7 @@ namespace ptr {
 
 namespace {
 
-constexpr uint64_t kMagic = 0x3130454743525450ull;   // "PTRCGE01"
+constexpr uint64_t kMagic = 0x3230454743525450ull;   // "PTRCGE02" (02: unused places of a wide node hold an inverted box)
 
 struct Header {
     uint64_t magic, fingerprint;

@@ -464,7 +464,12 @@ void ValidateSceneGeometry(const SceneGeometry& g, GeometryCheck& out) {
                 continue;
             }
             for (uint32_t c = 0; c < 4u; ++c) {
-                const uint32_t ref = wide[static_cast<size_t>(n) * 16u + c * 4u + 3u];
+                const uint32_t* rec = &wide[static_cast<size_t>(n) * 16u + c * 4u];
+                const uint32_t ref = rec[3];
+                // a used place holds an ordered box, an unused one the inverted box the wide step relies on (it does not read the reference)
+                const bool inverted = (rec[0] & 0xFFFFu) > (rec[1] >> 16) && (rec[0] >> 16) > (rec[2] & 0xFFFFu) && (rec[1] & 0xFFFFu) > (rec[2] >> 16);
+                const bool ordered = (rec[0] & 0xFFFFu) <= (rec[1] >> 16) && (rec[0] >> 16) <= (rec[2] & 0xFFFFu) && (rec[1] & 0xFFFFu) <= (rec[2] >> 16);
+                if ((ref == ptrk::kRefEmpty) ? !inverted : !ordered) out.wideProblems += 1;
                 if (ref == ptrk::kRefEmpty) continue;
                 if (!(ref & ptrk::kRefLeafBit)) {
                     stack.push_back(ref);

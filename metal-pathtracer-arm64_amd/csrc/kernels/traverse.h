@@ -115,6 +115,19 @@ __device__ __forceinline__ bool slabTest(f3 lo, f3 hi, f3 oi, f3 inv, float tnea
     return t0 <= t1 * 1.0000004f;
 }
 
+// The same test with the planes already in ray order (near = the plane the ray meets first on that axis, by the sign of its
+// direction): for an ordered box min(a, b) / max(a, b) of slabTest ARE the near / far values (the fma is monotonic), so the result is
+// the same bits - without the six min / max per box - and an inverted box (an unused place of a wide node) fails it on every axis.
+__device__ __forceinline__ bool slabTestOrdered(f3 nearQ, f3 farQ, f3 oi, f3 inv, float tnear, float tfar, float& entry) {
+    const v2f tx = __builtin_elementwise_fma((v2f){nearQ.x, farQ.x}, (v2f){inv.x, inv.x}, (v2f){-oi.x, -oi.x});
+    const v2f ty = __builtin_elementwise_fma((v2f){nearQ.y, farQ.y}, (v2f){inv.y, inv.y}, (v2f){-oi.y, -oi.y});
+    const v2f tz = __builtin_elementwise_fma((v2f){nearQ.z, farQ.z}, (v2f){inv.z, inv.z}, (v2f){-oi.z, -oi.z});
+    const float t0 = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tnear));
+    const float t1 = fminf(fminf(tx.y, ty.y), fminf(tz.y, tfar));
+    entry = t0;
+    return t0 <= t1 * 1.0000004f;
+}
+
 __device__ __forceinline__ bool triangleTest(f3 v0, f3 e1, f3 e2, f3 org, f3 dir, float tnear, float tfar,
                                              float& t, float& u, float& v) {
     const f3 Ng = cross(e2, e1);
@@ -177,6 +190,7 @@ __device__ __forceinline__ bool sphereTest(float4 s, f3 org, f3 dir, float tnear
 struct Trav {
     f3 org, dir, inv;    // inv = 1/dir, or cell/dir when the scene uses quantised nodes
     f3 oi;               // org*inv in the space of the node boxes (world, or grid cells for quantised nodes)
+    uint32_t selX, selY, selZ;   // four-wide nodes: v_perm selectors that put a child box's planes in ray order (travWideStep)
     float tnear;
     TraceHit hit;
     uint32_t cur;        // internal node index, or leaf reference while primitives remain
@@ -210,6 +224,11 @@ __device__ __forceinline__ bool travBegin(const SceneView& sc, Trav& t, f3 org, 
     } else {
         t.oi = org * t.inv;
     }
+    // the child record is {lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, reference}: one v_perm_b32 per axis picks the
+    // (near | far << 16) pair out of two of its words - which plane is near depends on the sign of the direction alone
+    t.selX = t.inv.x < 0.0f ? 0x01000706u : 0x07060100u;   // perm(c.y, c.x): lo.x = bytes 0,1 of c.x; hi.x = bytes 2,3 of c.y
+    t.selY = t.inv.y < 0.0f ? 0x03020504u : 0x05040302u;   // perm(c.z, c.x): lo.y = bytes 2,3 of c.x; hi.y = bytes 0,1 of c.z
+    t.selZ = t.inv.z < 0.0f ? 0x01000706u : 0x07060100u;   // perm(c.z, c.y): lo.z = bytes 0,1 of c.y; hi.z = bytes 2,3 of c.z
     t.tnear = tnear;
     t.hit.t = tfar;
     t.hit.prim = kHitMiss;
@@ -249,10 +268,14 @@ __device__ __forceinline__ bool travWideStep(const SceneMem& mem, Trav& t, LaneS
     const uint32_t at = t.cur * 64u;
     const uint4 c0 = load16u(mem.wide, at), c1 = load16u(mem.wide, at + 16u), c2 = load16u(mem.wide, at + 32u), c3 = load16u(mem.wide, at + 48u);
     float k0, k1, k2, k3;
-    const bool h0 = slabTest(gridLo(c0.x, c0.y), gridHi(c0.y, c0.z), t.oi, t.inv, t.tnear, t.hit.t, k0) & (c0.w != kRefEmpty);
-    const bool h1 = slabTest(gridLo(c1.x, c1.y), gridHi(c1.y, c1.z), t.oi, t.inv, t.tnear, t.hit.t, k1) & (c1.w != kRefEmpty);
-    const bool h2 = slabTest(gridLo(c2.x, c2.y), gridHi(c2.y, c2.z), t.oi, t.inv, t.tnear, t.hit.t, k2) & (c2.w != kRefEmpty);
-    const bool h3 = slabTest(gridLo(c3.x, c3.y), gridHi(c3.y, c3.z), t.oi, t.inv, t.tnear, t.hit.t, k3) & (c3.w != kRefEmpty);
+    // (an unused place holds an inverted box, bvh_builder.cpp BuildWideNodes: it fails the ordered test, its reference is not looked at)
+    auto boxTest = [&](const uint4& c, float& k) {
+        const uint32_t wx = __builtin_amdgcn_perm(c.y, c.x, t.selX), wy = __builtin_amdgcn_perm(c.z, c.x, t.selY), wz = __builtin_amdgcn_perm(c.z, c.y, t.selZ);
+        const f3 nearQ = mk3(static_cast<float>(wx & 0xFFFFu), static_cast<float>(wy & 0xFFFFu), static_cast<float>(wz & 0xFFFFu));
+        const f3 farQ = mk3(static_cast<float>(wx >> 16), static_cast<float>(wy >> 16), static_cast<float>(wz >> 16));
+        return slabTestOrdered(nearQ, farQ, t.oi, t.inv, t.tnear, t.hit.t, k);
+    };
+    const bool h0 = boxTest(c0, k0), h1 = boxTest(c1, k1), h2 = boxTest(c2, k2), h3 = boxTest(c3, k3);
     k0 = h0 ? k0 : INFINITY;
     k1 = h1 ? k1 : INFINITY;
     k2 = h2 ? k2 : INFINITY;
