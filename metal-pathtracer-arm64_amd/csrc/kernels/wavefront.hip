@@ -353,6 +353,11 @@ struct Surface {
     bool frontFace, twoSided;
 };
 
+template <typename T>
+__device__ __forceinline__ const T* byteOffset(const T* base, uint32_t bytes) {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + bytes);
+}
+
 __device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 dir, float t, uint32_t prim) {
     Surface s;
     s.t = t;
@@ -377,8 +382,11 @@ __device__ __forceinline__ Surface reconstruct(const SceneView& sc, f3 org, f3 d
         s.material = info.y;
         return s;
     }
-    const float4* tp = sc.tris + static_cast<size_t>(prim) * 3u;
-    const float4* np = sc.triNormals + static_cast<size_t>(prim) * 3u;
+    // (32-bit byte offsets from the arrays' bases - a primitive index has 26 bits - so that the loads take the scalar base + vector
+    // offset form: the 64-bit multiply-add of a pointer + index costs four instruction slots and an address register pair per array)
+    const uint32_t triOffset = prim * 48u;
+    const float4* tp = byteOffset(sc.tris, triOffset);
+    const float4* np = byteOffset(sc.triNormals, triOffset);
     const float4 a = tp[0], b = tp[1], c = tp[2];
     const float4 n0 = np[0], n1 = np[1], n2 = np[2];   // all six loads of the hit in flight together
     asm volatile("" ::"v"(a.x), "v"(b.x), "v"(c.x), "v"(n0.x), "v"(n1.x), "v"(n2.x));
@@ -1310,7 +1318,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                     }
                 }
                 const uint32_t materialIndex = min(sf.material, sc.materialCount - 1u);
-                Mat mat{sc.materials + static_cast<size_t>(materialIndex) * kMaterialVec4};
+                Mat mat{byteOffset(sc.materials, materialIndex * (kMaterialVec4 * 16u))};
                 const uint32_t type = mat.type();
                 const f3 incident = normalize(rayD);
                 const f3 wo = -incident;
