@@ -135,7 +135,6 @@ struct PtrDeviceScene {
     DeviceBuffer<uint32_t> flushItem, signature, tailList, tailWords;
     DeviceBuffer<uint32_t> connectList, connectCounts;   // PathPool::connectList: per group a list and two sets of sub-list counters
     DeviceBuffer<uint32_t> busyLists, busyCounts;        // PathPool::busyIn / busyOut: per group two lists and three sets of counters
-    DeviceBuffer<uint32_t> phaseLists, phaseCounts;      // PathPool::hitList / restList: per group a hit list, a rest list (twice as long) and two sets of their counters
     // end of the frame: once the item queue is dry and at most this many slots are still alive, the remaining paths are finished by
     // k_tail_run (one lane per path, no launches between bounces) instead of further extend / shade / connect rounds; 0 = never
     uint64_t tailBelow = 512ull << 10;
@@ -737,8 +736,6 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         uint32_t* busyCounts = nullptr;
         uint32_t busyStage = 0, busyTurn = 0;
         bool shadeListed = false;
-        uint32_t* phaseLists = nullptr;      // hit list, then the rest list
-        uint32_t* phaseCounts = nullptr;     // two sets of (hit counters, rest counters), used in turn
     };
     uint32_t groupCount = std::min<uint32_t>(soloGroup ? 1u : ds.poolGroups, std::max<uint32_t>(1u, slots >> 20));   // >= 1 Mi slots per group
     const uint32_t groupSlots = ((slots + groupCount - 1u) / groupCount + 255u) & ~255u;
@@ -763,14 +760,6 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
     ds.connectCounts.ensure(connectCountWords * 2u * kMaxPoolGroups);
     ds.busyLists.ensure(connectListWords * 2u * groupCount);
     ds.busyCounts.ensure(connectCountWords * 3u * kMaxPoolGroups);
-    // phased shading: while work items remain, on the instantiations that have the two visits (kernels/launch.h)
-    const bool phased = ptr::readKnobs().phasedShade != 0 && shadePhasedAvailable(rp, count) && slots < itemCount64;
-    const uint32_t phaseRegion = shadePhaseRegion(groupSlots);
-    const size_t phaseListWords = static_cast<size_t>(phaseRegion) * kConnectQueues;   // the hit list; the rest list is twice as long
-    if (phased) {
-        ds.phaseLists.ensure(phaseListWords * 3u * groupCount);
-        ds.phaseCounts.ensure(connectCountWords * 4u * kMaxPoolGroups);
-    }
     std::vector<Group> groups(groupCount);
     for (uint32_t g = 0; g < groupCount; ++g) {
         Group& gr = groups[g];
@@ -798,11 +787,6 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         gr.connectCounts = ds.connectCounts.ptr + connectCountWords * 2u * g;
         gr.busyLists = ds.busyLists.ptr + connectListWords * 2u * g;
         gr.busyCounts = ds.busyCounts.ptr + connectCountWords * 3u * g;
-        if (phased) {
-            gr.phaseLists = ds.phaseLists.ptr + phaseListWords * 3u * g;
-            gr.pool.phaseRegion = phaseRegion;
-            gr.phaseCounts = ds.phaseCounts.ptr + connectCountWords * 4u * g;
-        }
         gr.scalars = ds.scalars.ptr + static_cast<size_t>(g) * kScalarCount;
         const bool sideBySide = groupCount > 1 && gr.pool.slots >= kHalfGridGroupSlots;
         gr.cfg = LaunchConfig{sideBySide ? ds.traceGridHalf : ds.traceGrid, ds.spill.ptr + g * spillWords, gr.scalars + 1, ds.refillBelow};
@@ -835,7 +819,6 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
     HIP_CHECK(hipMemsetAsync(ds.scalars.ptr, 0, sizeof(uint32_t) * kScalarCount * kMaxPoolGroups, stream));
     HIP_CHECK(hipMemsetAsync(ds.connectCounts.ptr, 0, sizeof(uint32_t) * connectCountWords * 2u * kMaxPoolGroups, stream));
     HIP_CHECK(hipMemsetAsync(ds.busyCounts.ptr, 0, sizeof(uint32_t) * connectCountWords * 3u * kMaxPoolGroups, stream));
-    if (phased) HIP_CHECK(hipMemsetAsync(ds.phaseCounts.ptr, 0, sizeof(uint32_t) * connectCountWords * 4u * kMaxPoolGroups, stream));
     {
         uint32_t* heads = ds.pinnedAlive + kPinnedHeadsOffset;
         for (uint32_t k = 0; k < kItemHeads; ++k) {
@@ -904,18 +887,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
             // it still walks the slots: it is launched once the last count of live slots says its list is about to pay
             PathPool shadePool = gr.pool;
             if (!gr.shadeListed) shadePool.busyIn = nullptr;
-            if (phased && !queueDry) {
-                // every slot's path goes on or starts anew: the surface hits are visited with full waves, the new samples start together
-                uint32_t* const set = gr.phaseCounts + connectCountWords * 2u * (iterations & 1u);
-                shadePool.hitList = gr.phaseLists;
-                shadePool.restList = gr.phaseLists + phaseListWords;
-                shadePool.hitCount = set;
-                shadePool.restCount = set + connectCountWords;
-                shadePool.phaseClear = gr.phaseCounts + connectCountWords * 2u * ((iterations + 1u) & 1u);
-                timedLaunch(1, gr.stream, [&] { launchShadePhased(rp, ds.view, shadePool, resets, gr.stream); });
-            } else {
-                timedLaunch(1, gr.stream, [&] { launchShade(rp, ds.view, shadePool, resets, count, gr.stream); });
-            }
+            timedLaunch(1, gr.stream, [&] { launchShade(rp, ds.view, shadePool, resets, count, gr.stream); });
             timedLaunch(2, gr.stream, [&] { launchConnect(rp, ds.view, gr.pool, gr.cfg, count, gr.stream); });
             if (gr.busyStage != 0u) {
                 gr.busyStage = 2u;

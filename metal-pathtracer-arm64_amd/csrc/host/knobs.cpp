@@ -43,7 +43,6 @@ Knobs readKnobs() {
     k.refillBelow = static_cast<int>(std::min<long long>(std::max<long long>(numberOr("PTR_REFILL_BELOW", 0), 0), 64));
     k.buildThreads = static_cast<uint32_t>(std::min<long long>(std::max<long long>(numberOr("PTR_BUILD_THREADS", 0), 0), 256));
     k.noOversize = numberOr("PTR_NO_OVERSIZE", 0) != 0;
-    k.phasedShade = static_cast<int>(numberOr("PTR_PHASED_SHADE", -1));
     const char* verbose = std::getenv("PTR_VERBOSE");
     k.verboseBuild = hasTopic(verbose, "build");
     k.verbosePolls = hasTopic(verbose, "polls");

@@ -17,7 +17,6 @@ struct Knobs {
     int refillBelow = 0;           // PTR_REFILL_BELOW      traversing lanes below which a persistent wave refills, 1..64 (0: default 40)
     uint32_t buildThreads = 0;     // PTR_BUILD_THREADS     BVH builder threads (0: all cores)
     bool noOversize = false;       // PTR_NO_OVERSIZE       keep every triangle in the tree
-    int phasedShade = -1;          // PTR_PHASED_SHADE      0: one k_shade per iteration throughout (-1: default, phased while work items remain)
     // PTR_VERBOSE: comma-separated topics printed to stderr - build (BVH / upload timings), polls (live slots per host poll),
     // launches (when each kernel ran), steps (lane-utilisation counters of a counting render)
     bool verboseBuild = false, verbosePolls = false, verboseLaunches = false, verboseSteps = false;

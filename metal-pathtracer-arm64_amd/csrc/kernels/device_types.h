@@ -222,26 +222,7 @@ struct PathPool {
     uint32_t* busyOut;             // list k_shade fills for the next iteration (null: none)
     uint32_t* busyCountOut;
     uint32_t* busyCountClear;
-    // Phased shading (while work items remain; launchShadePhased): k_classify lists, in slot order, the slots whose ray hit a surface
-    // (hit list) and the other slots that need a visit (rest list: rays that left the scene, dead slots with records or a finished item
-    // outstanding).  k_shade_hits visits the hit list with every lane on a surface and appends the slots whose path ended to the rest
-    // list (kRestClaimOnly: nothing to visit, they only want a work item); k_shade_rest visits the rest list and hands out the work
-    // items, a whole wave of camera rays at a time.  Same sub-list layout as the connect list (the rest list's regions are twice as
-    // long: k_classify's wave w and k_shade_hits' wave w both append to sub-list w % 64); counters double-buffered by iteration parity.
-    uint32_t* hitList;
-    uint32_t* hitCount;
-    uint32_t* restList;
-    uint32_t* restCount;
-    uint32_t phaseRegion;          // entries per sub-list of the hit list (the rest list: twice as many); phaseRegionFor()
-    uint32_t* phaseClear;          // the next iteration's hit and rest counters (2 sets back to back; k_shade_hits zeroes them)
 };
-constexpr uint32_t kRestClaimOnly = 1u << 31;
-// Runs of 2^runShift consecutive waves append to the same sub-list of a phase list (sub-list (w >> runShift) % 64): what one sub-list
-// can then receive from the waves of `slots` slots, 64 entries each
-inline uint32_t phaseRegionFor(uint32_t slots, uint32_t runShift) {
-    const uint32_t waves = (slots + 63u) / 64u, run = 1u << runShift;
-    return ((waves + run * 64u - 1u) / (run * 64u)) * run * 64u;
-}
 constexpr uint32_t kBusyAliveBit = 1u << 31;
 constexpr uint32_t kConnectQueues = 64u;
 constexpr uint32_t kConnectCountStride = 64u;    // words: 256 B between counters

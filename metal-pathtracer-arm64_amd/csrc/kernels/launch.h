@@ -28,11 +28,6 @@ struct ShadeResets {
 };
 void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, bool count,
                  hipStream_t stream);
-// Phased shading (PathPool::hitList ...): k_classify, k_shade_hits, k_shade_rest instead of one k_shade; for the launches of a frame
-// that still has unclaimed work items, on the Embree-semantics instantiations of a timed render.
-bool shadePhasedAvailable(const RenderParams& rp, bool count);
-uint32_t shadePhaseRegion(uint32_t slots);   // PathPool::phaseRegion for a group of `slots` slots
-void launchShadePhased(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, hipStream_t stream);
 void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfg, bool count,
                    hipStream_t stream);
 // End of the frame: every busy slot of `pool` (the WHOLE pool) is run to the end of its path by one lane (k_tail_collect + k_tail_run).

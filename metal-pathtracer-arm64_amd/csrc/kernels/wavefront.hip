@@ -194,20 +194,6 @@ struct SubLists {
     }
 };
 
-// One wave appends the values of its lanes that `want` to sub-list `wave % kConnectQueues` of a list laid out like the connect list
-// (PathPool::connectList): one atomic per wave that appends anything.  Must be called by all 64 lanes (converged).
-__device__ __forceinline__ void appendToSubList(const bool want, uint32_t* list, uint32_t* counts, const uint32_t wave, const uint32_t region,
-                                                const uint32_t value) {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return;
-    const uint32_t queue = __builtin_amdgcn_readfirstlane(wave) & (kConnectQueues - 1u);
-    uint32_t base = 0u;
-    if (laneId() == 0u) base = atomicAdd(counts + queue * kConnectCountStride, static_cast<uint32_t>(__popcll(mask)));
-    base = __builtin_amdgcn_readfirstlane(base);
-    const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << laneId()) - 1ull)));
-    if (want) list[queue * region + base + rank] = value;
-}
-
 // Busy lists (PathPool::busyIn) exist from the moment the work items run out; a launch walks the list instead of the slots once the
 // list is short enough to pay: k_extend as soon as half the slots are off it (a list entry costs one more dependent load, a dead
 // slot a wasted probe), k_shade only below a quarter (its slot state is 16 B words in nine arrays: out of slot order every word
@@ -1009,36 +995,6 @@ __device__ __forceinline__ uint32_t claimItems(const RenderParams& rp, const Pat
     return needItem ? claimed : rp.itemCount;
 }
 
-// Work items for the lanes of a converged wave that holds the slots of a list (k_shade_rest): nearly all of its lanes start a sample,
-// so the wave keeps no reservation - it takes exactly what its lanes need, consecutive items (consecutive pixels) in lane order, with
-// one atomic on a range head, and moves on to the next head for what an exhausted range could not give.  Returns the lane's item, or
-// rp.itemCount when it wanted none / none is left.  Must be called by all 64 lanes.
-__device__ __forceinline__ uint32_t claimItemsDirect(const RenderParams& rp, const PathPool& pool, const bool needItem, const uint32_t waveIndex) {
-    const unsigned long long mask = __ballot(needItem);
-    if (mask == 0ull || rp.itemsPerHead == 0u) return rp.itemCount;
-    uint32_t* const dry = pool.nextItem + kItemHeads * kItemHeadStride;
-    if (__builtin_amdgcn_readfirstlane(*dry) != 0u) return rp.itemCount;
-    const uint32_t need = static_cast<uint32_t>(__popcll(mask));
-    const uint32_t rank = static_cast<uint32_t>(__popcll(mask & ((1ull << laneId()) - 1ull)));
-    uint32_t head = __builtin_amdgcn_readfirstlane(waveIndex) % kItemHeads;
-    uint32_t served = 0u, claimed = rp.itemCount;
-    for (uint32_t tries = 0; tries < kItemHeads && served < need; ++tries) {
-        const uint32_t headEnd = min(rp.itemHeadFirst + (head + 1u) * rp.itemsPerHead, rp.itemCount);
-        uint32_t* const counter = pool.nextItem + head * kItemHeadStride;
-        uint32_t base = headEnd;
-        if (laneId() == 0u && *counter < headEnd) base = atomicAdd(counter, need - served);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base < headEnd) {
-            const uint32_t n = min(need - served, headEnd - base);
-            if (needItem && rank >= served && rank < served + n) claimed = base + (rank - served);
-            served += n;
-        }
-        if (served < need) head = (head + 1u) % kItemHeads;
-    }
-    if (served < need && laneId() == 0u) *dry = 1u;   // every range was tried and is exhausted
-    return claimed;
-}
-
 // SSS: the instantiation with the Metal subsurface semantics (launched when PTR_METAL_SSS is set)
 struct ShadeCounts {
     uint32_t shadedHit = 0u, triHit = 0u, primary = 0u;   // counting build
@@ -1145,24 +1101,15 @@ __device__ __forceinline__ bool rectLightNee(const RenderParams& rp, const Scene
 // work items are claimed lane by lane.  kShadeTail: the caller is the end-of-frame kernel (k_tail_run), whose lanes hold arbitrary
 // slots AND diverge - nothing in here may then rely on the wave (no ballots, no list appends).
 // `listWave`: which sub-list this wave appends to (wave-uniform; unused in kShadeTail).
-// kShadeHits / kShadeRest: the two visits of phased shading (PathPool::hitList): the lanes hold the slots of a list, the wave is
-// converged.  kShadeHits: every slot's ray hit a surface; a path that ends asks for its work item through the rest list.  kShadeRest:
-// no slot's ray hit a surface (it left the scene, or the slot is dead with something outstanding), or - `claimOnly` - the slot was
-// visited by kShadeHits in this iteration and only wants a work item; the wave's lanes take their items with one atomic.
-constexpr int kShadeDense = 0, kShadeListed = 1, kShadeTail = 2, kShadeHits = 3, kShadeRest = 4;
-#ifndef PTR_PHASE_RUN_SHIFT
-#define PTR_PHASE_RUN_SHIFT 4
-#endif
-constexpr uint32_t kPhaseRunShift = PTR_PHASE_RUN_SHIFT;   // log2 of the consecutive waves that append to the same sub-list of a phase list
+constexpr int kShadeDense = 0, kShadeListed = 1, kShadeTail = 2;
 // TEX (only with SSS): the scene has material textures - the per-hit texture lookups and the path's ray cone are compiled in.  A
 // separate instantiation because they cost registers whether or not a scene uses them: with the texture code in, the Metal-model
 // kernel drops to 3 waves/SIMD and untextured Metal-semantics scenes ran 19-25 % slower than in round 1.
 // MATS: the material types the scene can contain (bsdf.h kAllMaterials, or the set of a simple scene: see launchShade)
 template <bool COUNT, bool SSS, bool TEX, int MODE, uint32_t MATS = kAllMaterials>
 __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const uint32_t slot, const bool inRange,
-                                          const bool drained, const uint32_t listWave, ShadeCounts& counts, const bool claimOnlyIn = false) {
+                                          const bool drained, const uint32_t listWave, ShadeCounts& counts) {
     constexpr bool TAIL = MODE == kShadeTail;
-    const bool claimOnly = MODE == kShadeRest && inRange && claimOnlyIn;   // nothing of the slot's state is visited: records queued a moment ago are still outstanding
     // Everything that depends only on the slot index is requested up front, and the record loads are pointed at a
     // zero word when the record is not pending, so the kernel has ~11 loads in flight per lane after ONE dependent
     // step (the state word) instead of walking a chain of ten load-wait pairs at 5 waves per SIMD.
@@ -1175,15 +1122,14 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
         const bool busy = inRange && (peek & (kFlagAlive | kFlagFlush | (kFlagPendingMask << kFlagPendingShift))) != 0u;
         if (__ballot(busy) == 0ull) return;
     }
-    const uint32_t atState = claimOnly ? 0u : at;   // (a claim-only lane reads one shared sector it never uses)
-    const float4 ray0v = pool.ray0[atState];
+    const float4 ray0v = pool.ray0[at];
     uint2 reservation = make_uint2(0u, 0u);
     if (MODE == kShadeDense && (slot & ~63u) < pool.slots) reservation = pool.itemReserve[__builtin_amdgcn_readfirstlane(slot / 64u)];   // (wave-uniform)
-    const float2 hitv = pool.hit[atState];
-    const float4 thr4 = pool.thr[atState];
-    const float4 acc4 = pool.accum[atState];
+    const float2 hitv = pool.hit[at];
+    const float4 thr4 = pool.thr[at];
+    const float4 acc4 = pool.accum[at];
     const uint32_t flagsIn = inRange ? __float_as_uint(ray1v.w) : 0u;
-    const uint32_t pendingIn = claimOnly ? 0u : (flagsIn >> kFlagPendingShift) & kFlagPendingMask;
+    const uint32_t pendingIn = (flagsIn >> kFlagPendingShift) & kFlagPendingMask;
     // (the records the instantiation's scenes never queue are not read: kRecords)
     constexpr uint32_t kRecords = SSS ? 0x1Fu : shadeRecords(MATS);
     float4 landed[kRecSlots];
@@ -1200,8 +1146,8 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
     for (uint32_t k = 0; k < kRecSlots; ++k) {
         if (kRecords & (1u << k)) asm volatile("" ::"v"(landed[k].x));
     }
-    const bool active = inRange && (flagsIn & kFlagAlive) && !claimOnly;
-    const bool touched = inRange && !claimOnly && (active || pendingIn != 0u || (flagsIn & kFlagFlush));   // state/accum rewritten
+    const bool active = inRange && (flagsIn & kFlagAlive);
+    const bool touched = inRange && (active || pendingIn != 0u || (flagsIn & kFlagFlush));   // state/accum rewritten
     if (COUNT) {
         counts.stage[0] += 1u;   // every lane counts its wave: the sum is 64 x the waves
         counts.stage[1] += active ? 1u : 0u;
@@ -1326,7 +1272,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                     }
                 }
                 partEnd<COUNT>(counts, kShadePartWalk, tWalk);
-            } else if (MODE != kShadeHits && prim == kHitMiss) {
+            } else if (prim == kHitMiss) {
                 // ---- escaped: background, MIS-weighted against environment sampling ----
                 const long long tMiss = partBegin<COUNT>();
                 f3 bg;
@@ -1349,8 +1295,8 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
                 if (COUNT) sig = (sig & 0xFFFFu) | (sigHashStep(sig >> 16, 7u, 0u, 0u) << 16);
                 endPath = true;
                 partEnd<COUNT>(counts, kShadePartMiss, tMiss);
-            } else if (MODE == kShadeRest || sc.materialCount == 0u) {
-                endPath = true;   // (kShadeRest: k_classify sends no surface hit here)
+            } else if (sc.materialCount == 0u) {
+                endPath = true;
             } else {
                 const long long tSurface = partBegin<COUNT>();
                 const Surface sf = reconstruct(sc, rayO, rayD, hitv.x, prim);
@@ -1643,18 +1589,7 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
     if (COUNT) counts.stage[8] += needItem ? 1u : 0u;
     // ---- claim new work items ----
     const long long tItem = partBegin<COUNT>();
-    if (MODE == kShadeHits) {
-        // the slot joins the rest list below: k_shade_rest starts its next sample
-    } else if (MODE == kShadeRest) {
-        const bool wantItem = needItem || claimOnly;
-        const uint32_t claimed = claimItemsDirect(rp, pool, wantItem, listWave);
-        if (wantItem && claimed < rp.itemCount) {
-            item = claimed;
-            beginItem(rp, pool, claimed, rng, nextO, nextD);
-            stillAlive = true;
-            newSample = true;
-        }
-    } else if (MODE != kShadeDense) {
+    if (MODE != kShadeDense) {
         // end of the frame: the range heads are dry; what can be left is the unused part of the last reservation of this slot's
         // 64-slot group (csrc/host/hip_backend.cpp hands a group to the tail kernel only after the heads ran dry)
         if (needItem) {
@@ -1700,20 +1635,9 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
         }
         if (COUNT && pool.signature) pool.signature[slot] = sig;
         if (TEX && pool.cone && stillAlive && (haveCone || newSample)) pool.cone[slot] = newSample ? primaryCone(rp) : cone;
-    } else if (MODE == kShadeRest && claimOnly && stillAlive) {
-        // the slot as k_shade_hits left it (path ended: depth 0, last-delta; a finished item / records may be outstanding) + its new sample
-        pool.ray1[slot] = make_float4(nextD.y, nextD.z, 1.0f, __uint_as_float(flagsIn | kFlagAlive));
-        reinterpret_cast<float*>(pool.accum + slot)[3] = __uint_as_float(item);
-        pool.ray0[slot] = mk4(nextO, nextD.x);
-        pool.thr[slot] = mk4(mk3(1.0f), __uint_as_float(rng));
     }
 
-    if (MODE == kShadeHits) {
-        // paths that ended here: k_shade_rest gives the slot its next work item (a whole wave of camera rays at a time)
-        appendToSubList(needItem, pool.restList, pool.restCount, listWave >> kPhaseRunShift, 2u * pool.phaseRegion, slot | kRestClaimOnly);
-    }
-
-    if (!TAIL && MODE != kShadeRest && pool.connectList) {
+    if (!TAIL && pool.connectList) {
         // one atomic per wave that queued anything, on the sub-list of this wave (see PathPool::connectList)
         const bool queued = touched && pendingMask != 0u;
         const unsigned long long mask = __ballot(queued);
@@ -1747,63 +1671,6 @@ __device__ __forceinline__ void shadeSlot(const RenderParams& rp, const SceneVie
         counts.triHit += triHit;
         counts.primary += primary;
     }
-}
-
-// ---- phased shading (PathPool::hitList; launchShadePhased) ----
-// k_classify: one pass over the slots in slot order (12 B per slot) that lists which visit each slot needs.
-__global__ void __launch_bounds__(256) k_classify(PathPool pool) {
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-    uint32_t flags = 0u, prim = kHitMiss;
-    if (slot < pool.slots) {
-        flags = __float_as_uint(reinterpret_cast<const float*>(pool.ray1 + slot)[3]);
-        prim = __float_as_uint(pool.hit[slot].y);
-    }
-    const bool hit = (flags & kFlagAlive) != 0u && prim != kHitMiss;
-    const bool rest = !hit && (flags & (kFlagAlive | kFlagFlush | (kFlagPendingMask << kFlagPendingShift))) != 0u;
-    // runs of kPhaseRun consecutive waves share a sub-list: a list is then made of stretches of 64 kPhaseRun consecutive slots (in
-    // nearly their own order), so the visits still move through each state array in long contiguous pieces
-    appendToSubList(hit, pool.hitList, pool.hitCount, slot >> (6u + kPhaseRunShift), pool.phaseRegion, slot);
-    appendToSubList(rest, pool.restList, pool.restCount, slot >> (6u + kPhaseRunShift), 2u * pool.phaseRegion, slot);
-}
-
-#define PTR_SHADE_WAVES_ATTR_P __attribute__((amdgpu_waves_per_eu(shadeWaves(false, false, MATS), shadeWaves(false, false, MATS))))
-// k_shade_hits: the slots of the hit list - every lane of a wave reconstructs a surface, samples the lights and the BSDF
-template <uint32_t MATS>
-__global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR_P k_shade_hits(RenderParams rp, SceneView sc, PathPool pool, ShadeResets resets) {
-    const uint32_t index = blockIdx.x * kShadeBlock + threadIdx.x;
-    if (index == 0u) {   // (as k_shade)
-        if (resets.extendHead) *resets.extendHead = 0u;
-        if (resets.connectHead) *resets.connectHead = 0u;
-        if (resets.nextAlive) *resets.nextAlive = 0u;
-    }
-    if (index < kConnectQueues) {
-        if (pool.connectClear) pool.connectClear[index * kConnectCountStride] = 0u;
-        if (pool.busyCountClear) pool.busyCountClear[index * kConnectCountStride] = 0u;
-    }
-    if (index < 2u * kConnectQueues) pool.phaseClear[index * kConnectCountStride] = 0u;   // the next iteration's hit and rest counters
-    SubLists lists;
-    lists.init(pool.hitCount, pool.phaseRegion);
-    if ((index & ~63u) >= lists.total) return;   // the whole wave lies beyond the list
-    const bool inRange = index < lists.total;
-    const uint32_t at = lists.position(inRange ? index : 0u, pool.phaseRegion);
-    const uint32_t slot = inRange ? pool.hitList[at] : 0u;
-    ShadeCounts counts;
-    shadeSlot<false, false, false, kShadeHits, MATS>(rp, sc, pool, slot, inRange, false, index >> 6, counts);
-}
-
-// k_shade_rest: the slots of the rest list - rays that left the scene, slots with something outstanding, and the slots k_shade_hits
-// sent for a work item; the lanes that start a sample generate their camera rays together
-template <uint32_t MATS>
-__global__ void __launch_bounds__(kShadeBlock) PTR_SHADE_WAVES_ATTR_P k_shade_rest(RenderParams rp, SceneView sc, PathPool pool) {
-    const uint32_t index = blockIdx.x * kShadeBlock + threadIdx.x;
-    SubLists lists;
-    lists.init(pool.restCount, 2u * pool.phaseRegion);
-    if ((index & ~63u) >= lists.total) return;
-    const bool inRange = index < lists.total;
-    const uint32_t at = lists.position(inRange ? index : 0u, 2u * pool.phaseRegion);
-    const uint32_t entry = inRange ? pool.restList[at] : 0u;
-    ShadeCounts counts;
-    shadeSlot<false, false, false, kShadeRest, MATS>(rp, sc, pool, entry & ~kRestClaimOnly, inRange, false, index >> 6, counts, (entry & kRestClaimOnly) != 0u);
 }
 
 // LISTED: the launch walks pool.busyIn instead of the slots (end of the frame, see PathPool)
@@ -2514,28 +2381,6 @@ void launchShade(const RenderParams& rp, const SceneView& sc, const PathPool& po
     } else {
         if (listed) pick(std::false_type{}, std::true_type{}); else pick(std::false_type{}, std::false_type{});
     }
-}
-
-bool shadePhasedAvailable(const RenderParams& rp, bool count) {
-    return !count && (rp.mediaMode & (PTR_METAL_SSS | PTR_METAL_PBR | PTR_METAL_CLAMPS)) == 0u;
-}
-
-uint32_t shadePhaseRegion(uint32_t slots) { return phaseRegionFor(slots, kPhaseRunShift); }
-
-void launchShadePhased(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const ShadeResets& resets, hipStream_t stream) {
-    hipLaunchKernelGGL(k_classify, dim3(ceilDiv(pool.slots, 256u)), dim3(256), 0, stream, pool);
-    const uint32_t grid = ceilDiv(pool.slots, kShadeBlock);   // a list holds a slot at most once
-    const uint32_t set = shadeKernelSet(rp, sc, false);
-    auto launch = [&](auto hits, auto rest) {
-        hipLaunchKernelGGL(hits, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool, resets);
-        hipLaunchKernelGGL(rest, dim3(grid), dim3(kShadeBlock), 0, stream, rp, sc, pool);
-    };
-    if (set == kDiffuseMaterials) launch(k_shade_hits<kDiffuseMaterials>, k_shade_rest<kDiffuseMaterials>);
-    else if (set == kBasicMaterials) launch(k_shade_hits<kBasicMaterials>, k_shade_rest<kBasicMaterials>);
-    else if (set == kMetalMaterials) launch(k_shade_hits<kMetalMaterials>, k_shade_rest<kMetalMaterials>);
-    else if (set == kCarPaintMaterials) launch(k_shade_hits<kCarPaintMaterials>, k_shade_rest<kCarPaintMaterials>);
-    else if (set == kPbrMaterials) launch(k_shade_hits<kPbrMaterials>, k_shade_rest<kPbrMaterials>);
-    else launch(k_shade_hits<kAllMaterials>, k_shade_rest<kAllMaterials>);
 }
 
 void launchConnect(const RenderParams& rp, const SceneView& sc, const PathPool& pool, const LaunchConfig& cfgIn, bool count, hipStream_t stream) {

@@ -325,20 +325,6 @@ rectangle x=-2,2 y=5 z=-2,2 normal=-1 material=6
         full2, _ = dev.render_image(s2, 4, count=True)
         assert np.array_equal(lean2.view(np.uint32), full2.view(np.uint32)), path
         dev.close()
-        # phased shading (k_classify / k_shade_hits / k_shade_rest while work items remain: a pool much smaller than the frame keeps it
-        # in that state for nearly all of the frame) against the one-kernel visit, per set
-        os.environ["PTR_POOL_SLOTS"] = "4096"
-        try:
-            small = pt.DeviceScene(host.desc, 0, keepalive=host)
-            phased, _ = small.render_image(s, 8)
-            os.environ["PTR_PHASED_SHADE"] = "0"
-            plain, _ = small.render_image(s, 8)
-            small.close()
-        finally:
-            del os.environ["PTR_POOL_SLOTS"]
-            os.environ.pop("PTR_PHASED_SHADE", None)
-        assert np.array_equal(plain.view(np.uint32), full.view(np.uint32)), path
-        assert np.array_equal(phased.view(np.uint32), full.view(np.uint32)), path
 
 
 def test_metal_media_semantics(tmp_path):
@@ -707,7 +693,6 @@ def test_scheduling_knobs_do_not_change_the_image():
                 {"PTR_QUANTIZED_NODES": "0"},   # 64 B float nodes (box tests only prune: the hits are the same)
                 {"PTR_MAX_ITEMS": str(1920 * 1080 * 12)},   # the whole frame still fits one pass
                 {"PTR_BUILD_THREADS": "3", "PTR_VERBOSE": "build"},   # same tree from any number of builder threads
-                {"PTR_PHASED_SHADE": "0"},      # one k_shade per iteration from the first to the last
                 {"PTR_NO_OVERSIZE": "1"}):      # (this scene keeps every triangle in the tree anyway)
         image, counts = render(env)
         assert np.array_equal(image, base), env
