@@ -861,55 +861,113 @@ void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t th
     lap("quantise");
 }
 
-uint32_t BuildWideNodes(const FlatBvh& bvh, bool compact, std::unique_ptr<uint32_t[]>& wide) {
+namespace {
+
+// the unused place of a wide node: an inverted box (lo = 65535, hi = 0 on every axis) - the wide step's ordered slab test (near plane
+// by the sign of the direction) can never pass it, so the step needs no test of the reference
+void emptyWidePlace(uint32_t* rec) {
+    rec[0] = 0xFFFFFFFFu;
+    rec[1] = 0x0000FFFFu;
+    rec[2] = 0x00000000u;
+    rec[3] = ptrk::kRefEmpty;
+}
+
+// The (at most four) child records of the wide node rooted at binary node n, as pointers into the quantised binary array.
+// byArea: the internal child with the largest box is opened until four children stand (or only leaves do); otherwise both children of
+// n are opened (every second level of the binary tree is collapsed).
+struct WideChoice {
+    const uint32_t* rec[4];
+    uint32_t count = 0;
+};
+inline bool internalRef(uint32_t ref, uint32_t nodeCount) { return ref != ptrk::kRefEmpty && !(ref & ptrk::kRefLeafBit) && ref < nodeCount; }
+inline double quantArea(const uint32_t* rec, const float* cell) {
+    const double x = (static_cast<double>(rec[1] >> 16) - (rec[0] & 0xFFFFu)) * cell[0];
+    const double y = (static_cast<double>(rec[2] & 0xFFFFu) - (rec[0] >> 16)) * cell[1];
+    const double z = (static_cast<double>(rec[2] >> 16) - (rec[1] & 0xFFFFu)) * cell[2];
+    return x * y + y * z + z * x;
+}
+WideChoice chooseWideChildren(const uint32_t* q, uint32_t nodeCount, const float* cell, uint32_t n, bool byArea) {
+    WideChoice c;
+    auto childrenOf = [&](uint32_t node, const uint32_t** dst) {
+        uint32_t got = 0;
+        for (uint32_t side = 0; side < 2u; ++side) {
+            const uint32_t* rec = q + static_cast<size_t>(node) * 8u + side * 4u;
+            if (rec[3] != ptrk::kRefEmpty) dst[got++] = rec;
+        }
+        return got;
+    };
+    c.count = childrenOf(n, c.rec);
+    if (!byArea) {
+        WideChoice g;
+        for (uint32_t k = 0; k < c.count; ++k) {
+            if (internalRef(c.rec[k][3], nodeCount)) g.count += childrenOf(c.rec[k][3], g.rec + g.count);
+            else g.rec[g.count++] = c.rec[k];
+        }
+        return g;
+    }
+    while (c.count < 4u) {
+        int best = -1;
+        double bestArea = -1.0;
+        for (uint32_t k = 0; k < c.count; ++k) {
+            if (!internalRef(c.rec[k][3], nodeCount)) continue;
+            const double a = quantArea(c.rec[k], cell);
+            if (a > bestArea) {
+                bestArea = a;
+                best = static_cast<int>(k);
+            }
+        }
+        if (best < 0) break;
+        const uint32_t* two[2];
+        const uint32_t got = childrenOf(c.rec[best][3], two);
+        if (got == 0u) break;   // (a node without children: not produced by the builder)
+        c.rec[best] = two[0];
+        if (got > 1u) c.rec[c.count++] = two[1];
+    }
+    return c;
+}
+
+}  // namespace
+
+uint32_t BuildWideNodes(const FlatBvh& bvh, WideCollapse how, std::unique_ptr<uint32_t[]>& wide, uint32_t* depthOut) {
     const uint32_t* q = bvh.qnodes.data();
     const uint32_t nodeCount = bvh.nodeCount;
     constexpr uint32_t kNotWide = 0xFFFFFFFFu;
+    if (depthOut) *depthOut = 0u;
     if (nodeCount == 0 || bvh.qnodes.size() < static_cast<size_t>(nodeCount) * 8u) return 0;
-    // depth parity: a parent precedes its children in preorder, so one forward pass settles it
+    const bool byArea = how == WideCollapse::ByArea;
+    // Which binary nodes root a wide node, and how deep the wide tree gets: the root does, and every internal child a wide node keeps.
+    // A parent precedes its children in the (preorder) binary array, so one forward pass settles it.
     std::unique_ptr<uint32_t[]> wideIndex(new uint32_t[nodeCount]);
-    std::vector<uint8_t> odd(nodeCount, 0);
-    if (compact) {
-        for (uint32_t n = 0; n < nodeCount; ++n) {
-            for (uint32_t side = 0; side < 2u; ++side) {
-                const uint32_t ref = q[static_cast<size_t>(n) * 8u + side * 4u + 3u];
-                if (ref != ptrk::kRefEmpty && !(ref & ptrk::kRefLeafBit) && ref < nodeCount) odd[ref] = odd[n] ^ 1u;
+    std::vector<uint8_t> depth(nodeCount, 0);   // depth of the wide node rooted here (1 = the root), 0: not a wide root
+    depth[0] = 1u;
+    uint32_t maxDepth = 1u;
+    for (uint32_t n = 0; n < nodeCount; ++n) {
+        if (depth[n] == 0u) continue;
+        const WideChoice c = chooseWideChildren(q, nodeCount, bvh.gridCell, n, byArea);
+        for (uint32_t k = 0; k < c.count; ++k) {
+            const uint32_t ref = c.rec[k][3];
+            if (internalRef(ref, nodeCount)) {
+                depth[ref] = static_cast<uint8_t>(std::min<uint32_t>(depth[n] + 1u, 255u));
+                maxDepth = std::max<uint32_t>(maxDepth, depth[ref]);
             }
         }
     }
+    if (depthOut) *depthOut = maxDepth;
     uint32_t wideCount = 0;
-    for (uint32_t n = 0; n < nodeCount; ++n) wideIndex[n] = odd[n] ? kNotWide : wideCount++;
+    for (uint32_t n = 0; n < nodeCount; ++n) wideIndex[n] = depth[n] ? wideCount++ : kNotWide;
     wide.reset(new uint32_t[static_cast<size_t>(wideCount) * 16u]);
     const uint32_t workers = nodeCount >= (1u << 16) ? std::min(32u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
     auto collapse = [&](uint32_t begin, uint32_t end) {
         for (uint32_t n = begin; n < end; ++n) {
             if (wideIndex[n] == kNotWide) continue;
             uint32_t* w = wide.get() + static_cast<size_t>(wideIndex[n]) * 16u;
-            uint32_t filled = 0;
-            for (uint32_t side = 0; side < 2u; ++side) {
-                const uint32_t* rec = q + static_cast<size_t>(n) * 8u + side * 4u;
-                const uint32_t ref = rec[3];
-                if (ref == ptrk::kRefEmpty) continue;
-                if ((ref & ptrk::kRefLeafBit) || ref >= nodeCount) {
-                    std::memcpy(w + 4u * filled++, rec, 16);
-                } else {
-                    for (uint32_t g = 0; g < 2u; ++g) {
-                        const uint32_t* grand = q + static_cast<size_t>(ref) * 8u + g * 4u;
-                        if (grand[3] == ptrk::kRefEmpty) continue;
-                        uint32_t* dst = w + 4u * filled++;
-                        std::memcpy(dst, grand, 16);
-                        if (!(grand[3] & ptrk::kRefLeafBit) && grand[3] < nodeCount) dst[3] = wideIndex[grand[3]];   // its wide node
-                    }
-                }
+            const WideChoice c = chooseWideChildren(q, nodeCount, bvh.gridCell, n, byArea);
+            for (uint32_t k = 0; k < c.count; ++k) {
+                uint32_t* dst = w + 4u * k;
+                std::memcpy(dst, c.rec[k], 16);
+                if (internalRef(dst[3], nodeCount)) dst[3] = wideIndex[dst[3]];   // its wide node
             }
-            for (; filled < 4u; ++filled) {
-                // an unused place holds an inverted box (lo = 65535, hi = 0 on every axis): the wide step's ordered slab test (near plane
-                // by the sign of the direction) can never pass it, so the step needs no test of the reference
-                w[4u * filled + 0u] = 0xFFFFFFFFu;
-                w[4u * filled + 1u] = 0x0000FFFFu;
-                w[4u * filled + 2u] = 0x00000000u;
-                w[4u * filled + 3u] = ptrk::kRefEmpty;
-            }
+            for (uint32_t k = c.count; k < 4u; ++k) emptyWidePlace(w + 4u * k);
         }
     };
     const uint32_t chunk = (nodeCount + workers - 1u) / workers;

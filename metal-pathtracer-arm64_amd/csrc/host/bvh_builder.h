@@ -43,11 +43,16 @@ struct FlatBvh {
 // triangle / n-th sphere of the input in input order.
 void BuildFlatBvh(const std::vector<BuildPrim>& prims, FlatBvh& out, uint32_t threads = 0, uint32_t leafMax = 4);
 
-// Four-wide nodes for the persistent traversal kernels (kernels/traverse.h travWideStep): every second level of the binary tree is
-// collapsed.  A wide node is 16 words: the 16 B child records (quantised box + reference, as in FlatBvh::qnodes) of a binary node's
-// children's children - a child that is a leaf keeps its own record, unused places are kRefEmpty.  compact: only the binary nodes at
-// even depth become wide nodes, numbered in the order of their binary (preorder) indices, internal references renumbered to match;
-// otherwise every binary node gets a wide node at its own index.  Returns the number of wide nodes.
-uint32_t BuildWideNodes(const FlatBvh& bvh, bool compact, std::unique_ptr<uint32_t[]>& wide);
+// Four-wide nodes for the persistent traversal kernels (kernels/traverse.h travWideStep).  A wide node is 16 words: four 16 B child
+// records (quantised box + reference, as in FlatBvh::qnodes); unused places hold an inverted box and kRefEmpty.  The wide node rooted
+// at a binary node keeps as children
+//   ByArea:   what is left after opening, again and again, the internal child with the largest box until four children stand - the
+//             children a ray is most likely to enter anyway are the ones opened, small ones stay closed and are culled whole (counted on
+//             the BASELINE scenes' own trees, profiles/r3_wide_walk_counts.txt: 10-17 % fewer steps per ray than ByLevel);
+//   ByLevel:  the children's children (every second level of the binary tree collapsed; a child that is a leaf keeps its record).
+// Wide nodes are numbered in the order of the binary (preorder) indices of their roots, internal references renumbered to match.
+// Returns the number of wide nodes; depthOut (nullable): levels of the wide tree (a step pushes at most three entries per level).
+enum class WideCollapse { ByArea, ByLevel };
+uint32_t BuildWideNodes(const FlatBvh& bvh, WideCollapse how, std::unique_ptr<uint32_t[]>& wide, uint32_t* depthOut = nullptr);
 
 }  // namespace ptr

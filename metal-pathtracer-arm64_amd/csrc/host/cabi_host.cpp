@@ -276,7 +276,7 @@ int ptr_debug_scene_geometry(const PtrSceneDesc* scene, uint32_t leaf_max, uint6
 // the device; this is the measurement behind DESIGN.md section 4.3c.
 int ptr_debug_walk_counts(const PtrSceneDesc* scene, const float* rays, uint64_t n, uint32_t levels, uint64_t out[4], char* err, size_t err_cap) {
     return guarded(err, err_cap, [&]() -> int {
-        if (!scene || (!rays && n) || !out || levels < 1u || levels > 3u) {
+        if (!scene || (!rays && n) || !out || levels < 1u || levels > 4u) {
             setErr(err, err_cap, "ptr_debug_walk_counts: bad argument");
             return 1;
         }
@@ -354,7 +354,25 @@ int ptr_debug_walk_counts(const PtrSceneDesc* scene, const float* rays, uint64_t
                     return c;
                 };
                 kn = children(ref, kids);
-                for (uint32_t l = 1; l < levels; ++l) {   // replace every internal child by its own children
+                if (levels == 4u) {
+                    // four-wide by area: the internal child with the largest box is opened until four children stand (or only leaves do)
+                    auto area = [](const Child& c) {
+                        const double x = double(c.hi[0]) - c.lo[0], y = double(c.hi[1]) - c.lo[1], z = double(c.hi[2]) - c.lo[2];
+                        return x * y + y * z + z * x;
+                    };
+                    while (kn < 4u) {
+                        int best = -1;
+                        for (uint32_t k = 0; k < kn; ++k) {
+                            if (!(kids[k].ref & ptrk::kRefLeafBit) && (best < 0 || area(kids[k]) > area(kids[best]))) best = static_cast<int>(k);
+                        }
+                        if (best < 0) break;
+                        Child two[2];
+                        const uint32_t got = children(kids[best].ref, two);
+                        kids[best] = two[0];
+                        if (got > 1u) kids[kn++] = two[1];
+                    }
+                }
+                for (uint32_t l = 1; l < levels && levels != 4u; ++l) {   // replace every internal child by its own children
                     Child next[8];
                     uint32_t nn = 0;
                     for (uint32_t k = 0; k < kn; ++k) {

@@ -8,13 +8,13 @@ namespace ptr {
 
 namespace {
 
-constexpr uint64_t kMagic = 0x3230454743525450ull;   // "PTRCGE02" (02: unused places of a wide node hold an inverted box)
+constexpr uint64_t kMagic = 0x3330454743525450ull;   // "PTRCGE03" (02: unused places of a wide node hold an inverted box; 03: wide nodes collapsed by area, their depth on record)
 
 struct Header {
     uint64_t magic, fingerprint;
     uint64_t nodes, qnodes, triOrder, sphereOrder, triData, triNormals, sphereData, sphereInfo, triUv, triTangent, rectTriLeaf, wideWords;   // element counts
     float gridOrigin[3], gridCell[3], meanPrimExtent;
-    uint32_t rootRef, oversizeRef, nodeCount, leafCount, maxDepth, maxLeafSize, triCount, sphereCount, useQuantized, wideCount;
+    uint32_t rootRef, oversizeRef, nodeCount, leafCount, maxDepth, maxLeafSize, triCount, sphereCount, useQuantized, wideCount, wideDepth, pad0;
     double sahCost, gatherSeconds, buildSeconds, flattenSeconds;
 };
 
@@ -113,6 +113,8 @@ bool WriteGeometryCache(const std::string& path, const PreparedGeometry& pg, uin
     hd.sphereCount = g.sphereCount;
     hd.useQuantized = pg.useQuantized ? 1u : 0u;
     hd.wideCount = pg.wideCount;
+    hd.wideDepth = pg.wideDepth;
+    hd.pad0 = 0u;
     hd.sahCost = b.sahCost;
     hd.gatherSeconds = g.gatherSeconds;
     hd.buildSeconds = g.buildSeconds;
@@ -186,6 +188,7 @@ bool ReadGeometryCache(const std::string& path, uint64_t fingerprint, PreparedGe
     g.flattenSeconds = hd.flattenSeconds;
     pg.useQuantized = hd.useQuantized != 0u;
     pg.wideCount = hd.wideCount;
+    pg.wideDepth = hd.wideDepth;
     return true;
 }
 

@@ -18,6 +18,7 @@ struct PreparedGeometry {
     bool useQuantized = false;           // node format of the persistent kernels (decided from the grid's cell size)
     std::unique_ptr<uint32_t[]> wide;    // four-wide nodes (16 words each) when the scene uses them
     uint32_t wideCount = 0;
+    uint32_t wideDepth = 0;              // levels of the wide tree (BuildWideNodes): sizes the traversal stack
 };
 
 // what the geometry depends on: primitive counts, transforms, material types, and samples of the vertex / index data

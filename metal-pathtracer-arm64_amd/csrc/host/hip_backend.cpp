@@ -270,7 +270,10 @@ void prepareGeometry(const PtrSceneDesc& desc, ptr::PreparedGeometry& pg) {
     if (knobs.quantizedNodes >= 0) pg.useQuantized = bvh.nodeCount > 0 && knobs.quantizedNodes != 0;
     // four-wide nodes for the persistent traversal kernels; the binary array stays for the cold kernels and the counting build
     if (pg.useQuantized && knobs.wideNodes != 0) {
-        pg.wideCount = ptr::BuildWideNodes(bvh, true, pg.wide);
+        // (a tree so lopsided that the by-area wide tree would outgrow the traversal stack keeps the by-level collapse, whose depth is half
+        // the binary tree's)
+        pg.wideCount = ptr::BuildWideNodes(bvh, knobs.wideNodes == 2 ? ptr::WideCollapse::ByLevel : ptr::WideCollapse::ByArea, pg.wide, &pg.wideDepth);
+        if (3u * pg.wideDepth + 4u > kTraversalStackDepth) pg.wideCount = ptr::BuildWideNodes(bvh, ptr::WideCollapse::ByLevel, pg.wide, &pg.wideDepth);
         if (static_cast<uint64_t>(pg.wideCount) * 64u > 0xFFFFFFFFull) throw HipError{"scene exceeds the 4 GiB node array limit"};
     }
 }
@@ -475,9 +478,10 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     if (knobs.tailBelow >= 0) ds.tailBelow = static_cast<uint64_t>(knobs.tailBelow);
     if (knobs.poolSlots != 0) ds.poolSlots = knobs.poolSlots;
     if (knobs.poolGroups != 0) ds.poolGroups = knobs.poolGroups;
-    // stack entries a ray of this tree can need: one per binary level for the two-box walk, three per pair of levels for the
-    // four-wide walk, the root beside an oversize leaf, and a margin
-    const uint32_t stackNeed = std::min<uint32_t>(kTraversalStackDepth, 3u * ((static_cast<uint32_t>(bvh.maxDepth) + 1u) / 2u) + 4u);
+    // stack entries a ray of this tree can need: one per binary level for the two-box walk, three per level of the wide tree for the
+    // four-wide walk (prepareGeometry keeps 3 x depth + 4 within the stack), the root beside an oversize leaf, and a margin
+    const uint32_t wideLevels = ps.pg.wideCount > 0u ? ps.pg.wideDepth : 0u;
+    const uint32_t stackNeed = std::min<uint32_t>(kTraversalStackDepth, std::max(3u * wideLevels, static_cast<uint32_t>(bvh.maxDepth)) + 4u);
     v.stackLimit = std::max(stackNeed, kLdsStackLevels);
     ds.spillLevels = v.stackLimit - kLdsStackLevels;
     ds.spill.ensure(std::max<size_t>(spillWordsPerGroup(ds) * ds.poolGroups, 1u));

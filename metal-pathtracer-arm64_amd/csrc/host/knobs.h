@@ -10,7 +10,7 @@ namespace ptr {
 struct Knobs {
     uint64_t poolSlots = 0;        // PTR_POOL_SLOTS        resident path slots at most (0: default 32 Mi; capped at 64 Mi)
     uint32_t poolGroups = 0;       // PTR_POOL_GROUPS       concurrent groups of the pool, 1..8 (0: default 4)
-    int wideNodes = -1;            // PTR_WIDE_NODES        0: the persistent kernels walk the binary nodes (-1: default, four-wide)
+    int wideNodes = -1;            // PTR_WIDE_NODES        0: the persistent kernels walk the binary nodes; 2: four-wide nodes collapsed by level (-1: default, four-wide by area)
     int quantizedNodes = -1;       // PTR_QUANTIZED_NODES   0 / 1: force 64 B float / 32 B quantised nodes (-1: decided by the scene's grid)
     int64_t tailBelow = -1;        // PTR_TAIL_BELOW        live slots below which the end-of-frame kernels take over (0: never; -1: default)
     uint64_t maxItems = 0;         // PTR_MAX_ITEMS         per-sample accumulators one pass may hold (0: from the device's memory)

@@ -450,10 +450,15 @@ void ValidateSceneGeometry(const SceneGeometry& g, GeometryCheck& out) {
     for (uint8_t s : sphSeen) out.unreferenced += (s == 0);
 
     // the four-wide nodes of the persistent kernels: walked from the root, every primitive of the tree must turn up exactly once
-    if (nodeCount > 0 && !bvh.qnodes.empty()) {
+    // (both ways of collapsing: by area - the default - and by level)
+    for (int pass = 0; pass < 2 && nodeCount > 0 && !bvh.qnodes.empty(); ++pass) {
         std::unique_ptr<uint32_t[]> wide;
-        const uint32_t wideCount = BuildWideNodes(bvh, true, wide);
-        out.wideNodes = wideCount;
+        uint32_t wideDepth = 0;
+        const uint32_t wideCount = BuildWideNodes(bvh, pass == 0 ? WideCollapse::ByArea : WideCollapse::ByLevel, wide, &wideDepth);
+        if (pass == 0) {
+            out.wideNodes = wideCount;
+            out.wideDepth = wideDepth;
+        }
         std::vector<uint8_t> triWide(g.triCount, 0), sphWide(g.sphereCount, 0), visited(wideCount, 0);
         std::vector<uint32_t> stack{0u};
         while (!stack.empty()) {

@@ -42,7 +42,8 @@ struct GeometryCheck {
     uint64_t quantViolations = 0;     // float child boxes sticking out of their quantised twin
     uint64_t badRefs = 0;             // child references pointing outside the arrays / cycles
     uint64_t oversize = 0;            // triangles kept out of the tree (FlatBvh::oversizeRef)
-    uint64_t wideNodes = 0;           // four-wide nodes (BuildWideNodes, compact)
+    uint64_t wideNodes = 0;           // four-wide nodes (BuildWideNodes, by area)
+    uint64_t wideDepth = 0;           // levels of that wide tree
     uint64_t wideProblems = 0;        // bad references in them + primitives not reached exactly once through them
 };
 

@@ -690,6 +690,7 @@ def test_scheduling_knobs_do_not_change_the_image():
     # every environment variable the library reads (csrc/host/knobs.h) appears here
     for env in ({"PTR_POOL_GROUPS": "1"}, {"PTR_TAIL_BELOW": "0"}, {"PTR_POOL_SLOTS": str(3 << 20), "PTR_REFILL_BELOW": "24"},
                 {"PTR_WIDE_NODES": "0"},        # the binary walk instead of the four-wide nodes (same tree, one level at a time)
+                {"PTR_WIDE_NODES": "2"},        # four-wide nodes collapsed by level instead of by box area (same tree, other groupings)
                 {"PTR_QUANTIZED_NODES": "0"},   # 64 B float nodes (box tests only prune: the hits are the same)
                 {"PTR_MAX_ITEMS": str(1920 * 1080 * 12)},   # the whole frame still fits one pass
                 {"PTR_BUILD_THREADS": "3", "PTR_VERBOSE": "build"},   # same tree from any number of builder threads

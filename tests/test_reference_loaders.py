@@ -157,8 +157,9 @@ f 1/1/2 3/3/1 2/2/1
 
 
 def test_ply_reader_matches_tinyply(tmp_path):
-    from scenes.gen_assets import ensure_assets
+    from scenes.gen_assets import ensure_assets, ensure_large_asset
     ensure_assets()
+    ensure_large_asset("blob_125000.ply")   # (generated on demand: a fresh checkout does not have it)
     path = os.path.join(SCENES, "assets", "blob_125000.ply")      # generated asset: binary little endian, float positions, int faces
     _same_mesh(_own_mesh(tmp_path, path), ref.load_mesh(path), True)
     # ASCII, double precision, normals, uchar list counts

@@ -60,7 +60,7 @@ def main():
         rays = rays_for(host, args.rays, 5)
         print("== scenes/%s" % name)
         base = None
-        for levels in (1, 2, 3):
+        for levels in (1, 2, 3, 4):   # 4 = four-wide, children chosen by box area (not a level count)
             out = (C.c_uint64 * 4)()
             err = C.create_string_buffer(512)
             rc = lib.ptr_debug_walk_counts(C.byref(host.desc), rays.ctypes.data_as(C.POINTER(C.c_float)), rays.shape[0], levels, out, err, len(err))
