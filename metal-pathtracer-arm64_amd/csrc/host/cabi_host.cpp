@@ -270,13 +270,14 @@ int ptr_debug_scene_geometry(const PtrSceneDesc* scene, uint32_t leaf_max, uint6
     });
 }
 
-// Host-side walk of the scene's BVH with 1, 2 or 3 binary levels collapsed per step (two-, four-, eight-wide nodes the way
-// BuildWideNodes collapses them: a child that is a leaf keeps its place), children visited in order of entry distance: how many node
+// Host-side walk of the scene's BVH with 1, 2 or 3 binary levels collapsed per step (two-, four-, eight-wide nodes: a child that is a
+// leaf keeps its place), with four-wide nodes whose children are chosen by box area (levels = 4: chosen on the fly; levels = 5: the
+// array BuildWideNodes ships, quantised boxes), children visited in order of entry distance: how many node
 // steps, box tests and primitive tests a closest-hit query costs at each width.  Counts only - the product walks four-wide nodes on
 // the device; this is the measurement behind DESIGN.md section 4.3c.
 int ptr_debug_walk_counts(const PtrSceneDesc* scene, const float* rays, uint64_t n, uint32_t levels, uint64_t out[4], char* err, size_t err_cap) {
     return guarded(err, err_cap, [&]() -> int {
-        if (!scene || (!rays && n) || !out || levels < 1u || levels > 4u) {
+        if (!scene || (!rays && n) || !out || levels < 1u || levels > 5u) {
             setErr(err, err_cap, "ptr_debug_walk_counts: bad argument");
             return 1;
         }
@@ -291,6 +292,9 @@ int ptr_debug_walk_counts(const PtrSceneDesc* scene, const float* rays, uint64_t
         struct Child { const float* lo; const float* hi; uint32_t ref; };
         uint64_t steps = 0, boxes = 0, prims = 0, hits = 0;
         std::vector<uint32_t> stack;
+        // levels 5: the walk goes through the four-wide array BuildWideNodes makes (what the device walks), boxes as quantised
+        std::unique_ptr<uint32_t[]> wideNodes;
+        if (levels >= 5u) ptr::BuildWideNodes(bvh, ptr::WideCollapse::ByArea, wideNodes);
         for (uint64_t r = 0; r < n; ++r) {
             const float* q = rays + r * 8;
             const double o[3] = {q[0], q[1], q[2]}, d[3] = {q[4], q[5], q[6]};
@@ -342,6 +346,34 @@ int ptr_debug_walk_counts(const PtrSceneDesc* scene, const float* rays, uint64_t
                     continue;
                 }
                 ++steps;
+                if (levels >= 5u) {
+                    const uint32_t* w = wideNodes.get() + static_cast<size_t>(ref) * 16u;
+                    double entry[4];
+                    uint32_t order[4], on = 0, refs[4];
+                    for (uint32_t k = 0; k < 4u; ++k) {
+                        const uint32_t* rec = w + 4u * k;
+                        refs[k] = rec[3];
+                        if (rec[3] == ptrk::kRefEmpty) continue;
+                        ++boxes;
+                        const double lo[3] = {bvh.gridOrigin[0] + double(rec[0] & 0xFFFFu) * bvh.gridCell[0], bvh.gridOrigin[1] + double(rec[0] >> 16) * bvh.gridCell[1],
+                                              bvh.gridOrigin[2] + double(rec[1] & 0xFFFFu) * bvh.gridCell[2]};
+                        const double hi[3] = {bvh.gridOrigin[0] + double(rec[1] >> 16) * bvh.gridCell[0], bvh.gridOrigin[1] + double(rec[2] & 0xFFFFu) * bvh.gridCell[1],
+                                              bvh.gridOrigin[2] + double(rec[2] >> 16) * bvh.gridCell[2]};
+                        double t0 = tmin, t1 = tfar;
+                        for (int a = 0; a < 3; ++a) {
+                            const double ta = (lo[a] - o[a]) * inv[a], tb = (hi[a] - o[a]) * inv[a];
+                            t0 = std::max(t0, std::min(ta, tb));
+                            t1 = std::min(t1, std::max(ta, tb));
+                        }
+                        if (t0 <= t1) {
+                            entry[k] = t0;
+                            order[on++] = k;
+                        }
+                    }
+                    std::sort(order, order + on, [&](uint32_t a, uint32_t b) { return entry[a] > entry[b]; });
+                    for (uint32_t k = 0; k < on; ++k) stack.push_back(refs[order[k]]);
+                    continue;
+                }
                 Child kids[8];
                 uint32_t kn = 0;
                 auto children = [&](uint32_t node, Child* dst) {

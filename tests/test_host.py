@@ -88,18 +88,19 @@ def test_walk_counts_of_collapsed_levels(tmp_path):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     rays = np.ascontiguousarray(np.concatenate([rng.uniform(50, 500, (n, 3)), np.full((n, 1), 1e-3), d, np.full((n, 1), np.inf)], axis=1).astype(np.float32))
     res = []
-    for levels in (1, 2, 3, 4):   # 4: four-wide nodes whose children are chosen by box area (what BuildWideNodes ships)
+    for levels in (1, 2, 3, 4, 5):   # 4: four-wide nodes whose children are chosen by box area; 5: the array BuildWideNodes ships
         out = (C.c_uint64 * 4)()
         err = C.create_string_buffer(256)
         assert lib.ptr_debug_walk_counts(C.byref(host.desc), rays.ctypes.data_as(C.POINTER(C.c_float)), n, levels, out, err, len(err)) == 0, err.value
         res.append([int(v) for v in out])
-    assert res[0][3] == res[1][3] == res[2][3] == res[3][3] > 0.4 * n          # the same rays hit
+    assert res[0][3] == res[1][3] == res[2][3] == res[3][3] == res[4][3] > 0.4 * n          # the same rays hit
+    assert abs(res[4][0] - res[3][0]) <= 0.01 * res[3][0]                      # the shipped array is that collapse (boxes quantised)
     assert res[3][0] < 0.95 * res[1][0] and res[3][1] <= 4 * res[3][0]         # by area: fewer four-wide steps than by level
     assert res[0][0] > res[1][0] > res[2][0]                      # fewer steps per level collapsed
     assert res[0][1] == 2 * res[0][0]                             # a binary step tests its two boxes
     assert res[2][1] > res[1][1] >= 0.95 * res[0][1]              # the third level costs box tests
     err = C.create_string_buffer(256)
-    assert lib.ptr_debug_walk_counts(C.byref(host.desc), None, 0, 5, (C.c_uint64 * 4)(), err, len(err)) == 1
+    assert lib.ptr_debug_walk_counts(C.byref(host.desc), None, 0, 6, (C.c_uint64 * 4)(), err, len(err)) == 1
 
 
 def test_band_partition_counts():

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""What a closest-hit walk costs per ray with two-, four- and eight-wide nodes (1, 2, 3 binary levels collapsed per step) on the BASELINE
+"""What a closest-hit walk costs per ray with two-, four- and eight-wide nodes (1, 2, 3 binary levels collapsed per step; four-wide nodes
+whose children are chosen by box area, the way BuildWideNodes ships them) on the BASELINE
 scenes' own trees: node steps, box tests, primitive tests (ptr_debug_walk_counts: host only, no GPU).  DESIGN.md section 4.3c.
 
   python tools/wide_walk_counts.py [--rays 200000] > profiles/r3_wide_walk_counts.txt
@@ -60,7 +61,7 @@ def main():
         rays = rays_for(host, args.rays, 5)
         print("== scenes/%s" % name)
         base = None
-        for levels in (1, 2, 3, 4):   # 4 = four-wide, children chosen by box area (not a level count)
+        for levels in (1, 2, 3, 5):   # 4 = four-wide, children chosen by box area (not a level count)
             out = (C.c_uint64 * 4)()
             err = C.create_string_buffer(512)
             rc = lib.ptr_debug_walk_counts(C.byref(host.desc), rays.ctypes.data_as(C.POINTER(C.c_float)), rays.shape[0], levels, out, err, len(err))
@@ -68,8 +69,9 @@ def main():
                 raise RuntimeError(err.value.decode())
             steps, boxes, prims, hits = [int(v) / rays.shape[0] for v in out]
             base = base or (steps, boxes)
-            print("  %d-wide: %6.2f steps | %6.2f box tests | %5.2f primitive tests   (hit fraction %.3f; steps x%.2f, box tests x%.2f of the binary walk)"
-                  % (1 << levels, steps, boxes, prims, hits, steps / base[0], boxes / base[1]))
+            label = {1: "2-wide", 2: "4-wide by level", 3: "8-wide by level", 5: "4-wide by area (shipped)"}[levels]
+            print("  %-26s %6.2f steps | %6.2f box tests | %5.2f primitive tests   (hit fraction %.3f; steps x%.2f, box tests x%.2f of the binary walk)"
+                  % (label + ":", steps, boxes, prims, hits, steps / base[0], boxes / base[1]))
 
 
 if __name__ == "__main__":
