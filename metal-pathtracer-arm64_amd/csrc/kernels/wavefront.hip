@@ -654,7 +654,14 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_extend(SceneVie
         }
     }
     WaveFeeder feeder;
-    feeder.init(workCounter, lists.total, listed ? 256u : feederChunk);
+    // (a short list is dealt out in chunks of less than 256, down to one wave-load per resident wave: see k_connect)
+#ifdef PTR_CONNECT_CHUNK_FIXED   // (A/B switch)
+    const uint32_t listChunk = 256u;
+#else
+    const uint32_t listWaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t listChunk = min(256u, max(64u, ((lists.total + listWaves - 1u) / listWaves + 63u) & ~63u));
+#endif
+    feeder.init(workCounter, lists.total, listed ? listChunk : feederChunk);
     Trav t;
     t.cur = 0u;
     bool active = false;
@@ -1830,7 +1837,16 @@ __global__ void __launch_bounds__(kTraceBlock) PTR_EXTEND_ATTR k_connect(RenderP
     SubLists lists;
     lists.init(pool.connectCount, pool.connectRegion);
     WaveFeeder feeder;
-    feeder.init(workCounter, lists.total, 256u);
+    // a list with fewer than 256 entries per resident wave is dealt out in smaller chunks, down to one wave-load each: on a scene that
+    // queues few connections (config 5: 0.2 M records per launch over a 29 M-triangle tree) chunks of 256 put four latency-bound
+    // batches one after the other on a quarter of the waves while the others had nothing
+#ifdef PTR_CONNECT_CHUNK_FIXED   // (A/B switch)
+    const uint32_t connectChunk = 256u;
+#else
+    const uint32_t connectWaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t connectChunk = min(256u, max(64u, ((lists.total + connectWaves - 1u) / connectWaves + 63u) & ~63u));
+#endif
+    feeder.init(workCounter, lists.total, connectChunk);
     Trav t;
     t.cur = 0u;
     bool active = false;
