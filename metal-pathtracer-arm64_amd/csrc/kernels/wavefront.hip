@@ -913,15 +913,17 @@ constexpr uint32_t shadeRecords(uint32_t mats) {
     const bool delta = (mats & ((1u << 1) | (1u << 2) | (1u << 7))) != 0u;
     return 1u | (env ? 2u : 0u) | ((env && delta) ? 4u : 0u) | (delta ? 8u : 0u) | ((mats & (1u << 2)) ? 16u : 0u);
 }
-// waves per SIMD of each set's instantiation (512 / waves = its register budget)
+// waves per SIMD of each set's instantiation (512 / waves = its register budget).  Compiled without the SLP vectoriser (csrc/Makefile:
+// its packed-fp32 pairs cost more moves and registers than they saved instructions) the diffuse and basic sets need 72 / 76 registers
+// and run 6 waves, the metallic-roughness set 81 and the metal set 96 (5 waves).
 #ifndef PTR_SHADE_WAVES_DIFFUSE
-#define PTR_SHADE_WAVES_DIFFUSE 5
+#define PTR_SHADE_WAVES_DIFFUSE 6
 #endif
 #ifndef PTR_SHADE_WAVES_BASIC
-#define PTR_SHADE_WAVES_BASIC 5
+#define PTR_SHADE_WAVES_BASIC 6
 #endif
 #ifndef PTR_SHADE_WAVES_METAL
-#define PTR_SHADE_WAVES_METAL 4
+#define PTR_SHADE_WAVES_METAL 5
 #endif
 #ifndef PTR_SHADE_WAVES_PBR
 #define PTR_SHADE_WAVES_PBR 5

@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 CS=$ROOT/metal-pathtracer-arm64_amd/csrc
 mkdir -p $ROOT/variants
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I$ROOT/include -I$CS/host -I$CS/kernels "$@" \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -I$ROOT/include -I$CS/host -I$CS/kernels "$@" \
   -c $CS/kernels/wavefront.hip -o /tmp/wavefront_$NAME.o
 # (the backend sees the same layout switches as the kernels: PTR_POOL_AOS, ...)
 /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -I$ROOT/include -I$CS/host -I$CS/kernels "$@" -c $CS/host/hip_backend.cpp -o /tmp/hip_backend_$NAME.o
