@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--solo", action="store_true",
                     help="profiling runs: the path-slot pool as ONE group on one stream, so kernels never overlap and rocprofv3 / PMC "
-                         "figures are clean per-kernel numbers (the product default runs 4 groups concurrently)")
+                         "figures are clean per-kernel numbers (the product default runs two groups, each with its k_connect beside the next k_extend)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo); numbers are not comparable")
     args = ap.parse_args()
@@ -246,7 +246,7 @@ def main():
     # ---- algorithmic traffic: one counting render of the same kernels (untimed, deterministic) ----
     cstats = scene.render_device(settings, args.spp, local.data_ptr(), stream.cuda_stream, rank, world, count=True, want_stats=True)
     # ---- the dominant kernel alone: same render with the pool as ONE group, so no other kernel shares the chip with
-    # k_extend while it is timed (the timed region above runs up to 4 groups concurrently on separate streams) ----
+    # k_extend while it is timed (the timed region above runs the pool's groups concurrently on separate streams) ----
     sstats = scene.render_device(settings, args.spp, local.data_ptr(), stream.cuda_stream, rank, world, count=False, want_stats=True,
                                  solo=True)
     counters = torch.tensor([cstats.extendNodesVisited, cstats.extendLeafPrimTests, cstats.nodesVisited, cstats.leafPrimTests,
@@ -321,8 +321,8 @@ def main():
                 "launches_per_render": solo["launches_per_render"] if solo else None,
                 "timed_region": {"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_launch_ms, 4),
                                  "bytes_per_launch": round(ext_bytes_per_launch), "launches_per_render": round(launches_per_render, 1),
-                                 "note": "inside the timed region the pool runs as 4 concurrent groups: a launch covers a quarter of the pool "
-                                         "and shares the chip with other kernels"},
+                                 "note": "inside the timed region the pool runs as concurrent groups (two of 16 Mi slots, each with its k_connect beside the "
+                                         "next k_extend): a launch covers part of the pool and shares the chip with other kernels"},
                 "whole_path_gbs_per_gpu": round(path_gbs, 1),
                 "bytes_per_sample": round(path_bytes / total_samples, 1),
                 "rays_per_sample": round((ext_rays + sh_rays) / total_samples, 3),

@@ -139,10 +139,19 @@ struct PtrDeviceScene {
     // k_tail_run (one lane per path, no launches between bounces) instead of further extend / shade / connect rounds; 0 = never
     uint64_t tailBelow = 512ull << 10;
     uint64_t poolSlots = 32ull << 20;        // resident path slots at most (PTR_POOL_SLOTS)
-    uint32_t poolGroups = 4;   // the pool is split into this many independent groups, one HIP stream each
+    // The pool is split into this many independent groups.  Two by default, each on a main stream (k_extend, k_shade) and a side stream
+    // on which the k_connect of an iteration runs beside the k_extend of the next (they share nothing: one reads the rays k_shade wrote,
+    // the other its connection records): four streams in flight, which is what the runtime's four hardware queues carry without
+    // serialising.  (Rounds 1-3 ran four groups of one stream each; profiles/r3_ab_connect_overlap.txt.)
+    // Frames of a few milliseconds (a pool of at most 8 Mi slots: config 1) keep four groups of one stream each: -6 % with two.
+    uint32_t poolGroups = 0;      // PTR_POOL_GROUPS (0: two groups, four for small pools)
+    bool connectOverlap = true;   // PTR_CONNECT_OVERLAP=0: k_connect on the group's own stream
+    uint32_t maxPoolGroups() const { return poolGroups ? poolGroups : 4u; }
     uint32_t feederChunk = 256;   // slots per work-head claim while the pool is full (it grows as the pool drains)
     std::vector<hipStream_t> groupStreams;   // streams of groups 1.. (group 0 runs on the caller's stream)
     std::vector<hipEvent_t> groupEvents;
+    std::vector<hipStream_t> sideStreams;    // per group: the stream of its k_connect launches (see poolGroups)
+    std::vector<hipEvent_t> sideEvents;      // per group: k_shade of the iteration done / k_connect of the iteration done
     int refillBelow = 40;
     uint32_t spillLevels = 0;   // stack levels beyond the LDS part that the scene's tree can need (sizes the spill area)
     DeviceBuffer<uint4> medium;
@@ -163,6 +172,8 @@ struct PtrDeviceScene {
         if (pinnedAlive) (void)hipHostFree(pinnedAlive);
         for (hipStream_t st : groupStreams) (void)hipStreamDestroy(st);
         for (hipEvent_t e : groupEvents) (void)hipEventDestroy(e);
+        for (hipStream_t st : sideStreams) (void)hipStreamDestroy(st);
+        for (hipEvent_t e : sideEvents) (void)hipEventDestroy(e);
     }
 };
 
@@ -478,13 +489,14 @@ void uploadScene(const PtrSceneDesc& desc, const PreparedScene& ps, PtrDeviceSce
     if (knobs.tailBelow >= 0) ds.tailBelow = static_cast<uint64_t>(knobs.tailBelow);
     if (knobs.poolSlots != 0) ds.poolSlots = knobs.poolSlots;
     if (knobs.poolGroups != 0) ds.poolGroups = knobs.poolGroups;
+    ds.connectOverlap = knobs.connectOverlap != 0;
     // stack entries a ray of this tree can need: one per binary level for the two-box walk, three per level of the wide tree for the
     // four-wide walk (prepareGeometry keeps 3 x depth + 4 within the stack), the root beside an oversize leaf, and a margin
     const uint32_t wideLevels = ps.pg.wideCount > 0u ? ps.pg.wideDepth : 0u;
     const uint32_t stackNeed = std::min<uint32_t>(kTraversalStackDepth, std::max(3u * wideLevels, static_cast<uint32_t>(bvh.maxDepth)) + 4u);
     v.stackLimit = std::max(stackNeed, kLdsStackLevels);
     ds.spillLevels = v.stackLimit - kLdsStackLevels;
-    ds.spill.ensure(std::max<size_t>(spillWordsPerGroup(ds) * ds.poolGroups, 1u));
+    ds.spill.ensure(std::max<size_t>(spillWordsPerGroup(ds) * ds.maxPoolGroups() * 2u, 1u));   // a group's k_extend and k_connect may run side by side: an area each
     ds.scalars.ensure(static_cast<size_t>(kScalarCount) * kMaxPoolGroups);
     ds.counters.ensure(kCounterSlots);
     ds.zeros.ensure(16);
@@ -741,7 +753,8 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         uint32_t busyStage = 0, busyTurn = 0;
         bool shadeListed = false;
     };
-    uint32_t groupCount = std::min<uint32_t>(soloGroup ? 1u : ds.poolGroups, std::max<uint32_t>(1u, slots >> 20));   // >= 1 Mi slots per group
+    const uint32_t wantGroups = ds.poolGroups ? ds.poolGroups : (slots > (8u << 20) ? 2u : 4u);
+    uint32_t groupCount = std::min<uint32_t>(soloGroup ? 1u : wantGroups, std::max<uint32_t>(1u, slots >> 20));   // >= 1 Mi slots per group
     const uint32_t groupSlots = ((slots + groupCount - 1u) / groupCount + 255u) & ~255u;
     groupCount = (slots + groupSlots - 1u) / groupSlots;
     while (ds.groupStreams.size() + 1 < groupCount) {
@@ -755,6 +768,19 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
         ds.groupEvents.push_back(e);
     }
     const size_t spillWords = spillWordsPerGroup(ds);
+    // k_connect beside the next k_extend: only while the streams fit the hardware queues (two groups at most), and never in a solo
+    // render, whose point is kernels that do not overlap
+    const bool overlap = ds.connectOverlap && !soloGroup && groupCount <= 2u;
+    while (overlap && ds.sideStreams.size() < groupCount) {
+        hipStream_t st;
+        HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        ds.sideStreams.push_back(st);
+        for (int k = 0; k < 2; ++k) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ds.sideEvents.push_back(e);
+        }
+    }
     // connect lists: sub-list w % 64 takes the entries of k_shade's wave w, at most 64 each
     const uint32_t connectRegion = ((groupSlots + 63u) / 64u + kConnectQueues - 1u) / kConnectQueues * 64u;
     const size_t connectListWords = static_cast<size_t>(connectRegion) * kConnectQueues;
@@ -891,7 +917,19 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
             // it still walks the slots: it is launched once the last count of live slots says its list is about to pay
             PathPool shadePool = gr.pool;
             if (!gr.shadeListed) shadePool.busyIn = nullptr;
+            if (overlap && iterations > 0) HIP_CHECK(hipStreamWaitEvent(gr.stream, ds.sideEvents[2 * static_cast<uint32_t>(&gr - groups.data()) + 1], 0));
             timedLaunch(1, gr.stream, [&] { launchShade(rp, ds.view, shadePool, resets, count, gr.stream); });
+            if (overlap) {
+                // k_connect of this iteration on the side stream, after this k_shade; the next k_shade waits for it (above)
+                const uint32_t gi = static_cast<uint32_t>(&gr - groups.data());
+                hipStream_t side = ds.sideStreams[gi];
+                HIP_CHECK(hipEventRecord(ds.sideEvents[2 * gi], gr.stream));          // shade(i) done
+                HIP_CHECK(hipStreamWaitEvent(side, ds.sideEvents[2 * gi], 0));
+                LaunchConfig ccfg = gr.cfg;
+                ccfg.spill = ds.spill.ptr + (ds.maxPoolGroups() + gi) * spillWords;
+                timedLaunch(2, side, [&] { launchConnect(rp, ds.view, gr.pool, ccfg, count, side); });
+                HIP_CHECK(hipEventRecord(ds.sideEvents[2 * gi + 1], side));           // connect(i) done
+            } else
             timedLaunch(2, gr.stream, [&] { launchConnect(rp, ds.view, gr.pool, gr.cfg, count, gr.stream); });
             if (gr.busyStage != 0u) {
                 gr.busyStage = 2u;
@@ -970,6 +1008,7 @@ void renderPass(PtrDeviceScene& ds, const PtrSettings& settings, uint32_t spp, u
             if (iterations >= maxIterations) throw HipError{"wavefront loop did not terminate"};
         }
     }
+    for (uint32_t g = 0; overlap && g < groupCount; ++g) HIP_CHECK(hipStreamWaitEvent(groups[g].stream, ds.sideEvents[2 * g + 1], 0));
     for (uint32_t g = 1; g < groupCount; ++g) {
         HIP_CHECK(hipEventRecord(ds.groupEvents[g], groups[g].stream));
         HIP_CHECK(hipStreamWaitEvent(stream, ds.groupEvents[g], 0));

@@ -35,6 +35,7 @@ Knobs readKnobs() {
     k.poolSlots = static_cast<uint64_t>(std::min<long long>(std::max<long long>(numberOr("PTR_POOL_SLOTS", 0), 0), 64ll << 20));
     if (k.poolSlots != 0 && k.poolSlots < 1024) k.poolSlots = 1024;
     k.poolGroups = static_cast<uint32_t>(std::min<long long>(std::max<long long>(numberOr("PTR_POOL_GROUPS", 0), 0), 8));
+    k.connectOverlap = static_cast<int>(numberOr("PTR_CONNECT_OVERLAP", -1));
     k.wideNodes = static_cast<int>(numberOr("PTR_WIDE_NODES", -1));
     k.quantizedNodes = static_cast<int>(numberOr("PTR_QUANTIZED_NODES", -1));
     k.tailBelow = numberOr("PTR_TAIL_BELOW", -1);

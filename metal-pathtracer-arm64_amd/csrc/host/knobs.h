@@ -9,7 +9,8 @@ namespace ptr {
 
 struct Knobs {
     uint64_t poolSlots = 0;        // PTR_POOL_SLOTS        resident path slots at most (0: default 32 Mi; capped at 64 Mi)
-    uint32_t poolGroups = 0;       // PTR_POOL_GROUPS       concurrent groups of the pool, 1..8 (0: default 4)
+    uint32_t poolGroups = 0;       // PTR_POOL_GROUPS       concurrent groups of the pool, 1..8 (0: default - 2, or 4 for pools of at most 8 Mi slots)
+    int connectOverlap = -1;       // PTR_CONNECT_OVERLAP   0: k_connect on its group's own stream (-1: default, beside the next k_extend when the pool runs as <= 2 groups)
     int wideNodes = -1;            // PTR_WIDE_NODES        0: the persistent kernels walk the binary nodes; 2: four-wide nodes collapsed by level (-1: default, four-wide by area)
     int quantizedNodes = -1;       // PTR_QUANTIZED_NODES   0 / 1: force 64 B float / 32 B quantised nodes (-1: decided by the scene's grid)
     int64_t tailBelow = -1;        // PTR_TAIL_BELOW        live slots below which the end-of-frame kernels take over (0: never; -1: default)

@@ -688,7 +688,9 @@ def test_scheduling_knobs_do_not_change_the_image():
     base, base_counts = render({})
     assert np.isfinite(base).all() and base.mean() > 0.01 and base_counts[4] == 1920 * 1080 * 12
     # every environment variable the library reads (csrc/host/knobs.h) appears here
-    for env in ({"PTR_POOL_GROUPS": "1"}, {"PTR_TAIL_BELOW": "0"}, {"PTR_POOL_SLOTS": str(3 << 20), "PTR_REFILL_BELOW": "24"},
+    for env in ({"PTR_POOL_GROUPS": "1"}, {"PTR_POOL_GROUPS": "4"},   # (default: two groups, each with its k_connect beside the next k_extend)
+                {"PTR_CONNECT_OVERLAP": "0"},   # k_connect on its group's own stream
+                {"PTR_TAIL_BELOW": "0"}, {"PTR_POOL_SLOTS": str(3 << 20), "PTR_REFILL_BELOW": "24"},
                 {"PTR_WIDE_NODES": "0"},        # the binary walk instead of the four-wide nodes (same tree, one level at a time)
                 {"PTR_WIDE_NODES": "2"},        # four-wide nodes collapsed by level instead of by box area (same tree, other groupings)
                 {"PTR_QUANTIZED_NODES": "0"},   # 64 B float nodes (box tests only prune: the hits are the same)
