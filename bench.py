@@ -338,8 +338,10 @@ def main():
         valu = None
         ext = per_kernel.get("extend")
         if ext and ext.get("valu_issue") is not None:
-            valu = {"kernel": ext["kernel"], "issue": ext["valu_issue"], "lane_utilisation": ext["valu_lane_utilisation"],
-                    "useful": round(ext["valu_issue"] * ext["valu_lane_utilisation"], 4),
+            # (instructions and active cycles come from two PMC passes of the record: their quotient can read a per cent or two above 1)
+            issue = min(1.0, ext["valu_issue"])
+            valu = {"kernel": ext["kernel"], "issue": issue, "issue_recorded": ext["valu_issue"], "lane_utilisation": ext["valu_lane_utilisation"],
+                    "useful": round(issue * ext["valu_lane_utilisation"], 4),
                     "source": "recorded: %s (SQ_INSTS_VALU x 4 / (GRBM_GUI_ACTIVE x 128); SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64))" % solo_rel,
                     "note": "the binding resource of the traversal kernels on this workload: share of SIMD cycles that issue a VALU instruction x share of "
                             "the 64 lanes those instructions keep busy"}
